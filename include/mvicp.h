@@ -1,0 +1,141 @@
+/* mvicp.h — C ABI of libmvicp_hip.so: the MI355X (gfx950) multiview LM-ICP hot path.
+ *
+ * This is the drop-in boundary.  The reference (adrelino/mv-lm-icp) has no FFI: its
+ * seams are plain C++ members/free functions.  Each entry point below names the reference interface
+ * it replaces (file:line relative to the reference tree).  Plain pointers and sizes only; every call
+ * returns 0 on success or a negative mvicp_status, and mvicp_last_error() holds the message.  The
+ * library owns all device memory; the caller owns every host buffer it passes.  One context drives
+ * one GPU (one process per GPU; see mvicp_set_shard / mvicp_comm_init for the multi-GPU path).
+ *
+ * Conventions
+ *   pose    : 16 doubles, 4x4 COLUMN-major = Eigen::Isometry3d::data()  (include/frame.h:42)
+ *   points  : n x 3 doubles AoS = &std::vector<Eigen::Vector3d>[0]      (include/frame.h:38-39)
+ *   edge e  : directed src -> dst = Frame::neighbours[j] of frame src    (include/frame.h:24-29,46)
+ *   indices : int32, local to their frame
+ */
+#ifndef MVICP_H
+#define MVICP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mvicp_ctx mvicp_ctx;
+
+enum mvicp_status {
+  MVICP_OK = 0,
+  MVICP_ERR_ARG = -1,      /* bad argument / call order */
+  MVICP_ERR_HIP = -2,      /* HIP runtime error (no GPU, OOM, launch failure) */
+  MVICP_ERR_STATE = -3,    /* frames/graph/correspondences not set */
+  MVICP_ERR_COMM = -4,     /* RCCL failure */
+  MVICP_ERR_NUMERIC = -5   /* LM solve failed (non-finite / not positive definite) */
+};
+
+/* Rotation parameterization of the LM solve = which reference optimizer is mirrored. */
+enum mvicp_param {
+  MVICP_PARAM_EIGEN_QUATERNION = 0, /* ICP_Ceres::ceresOptimizer            src/internal/icp-ceres.cpp:220-323 */
+  MVICP_PARAM_ANGLE_AXIS = 1,       /* ICP_Ceres::ceresOptimizer_ceresAngleAxis              :325-395 */
+  MVICP_PARAM_SOPHUS_SE3 = 2        /* ICP_Ceres::ceresOptimizer_sophusSE3                   :398-475 */
+};
+
+/* Nearest-neighbour kernels (all exact; identical results by construction). */
+enum mvicp_nn_method {
+  MVICP_NN_AUTO = 0,
+  MVICP_NN_BRUTE = 1, /* LDS-tiled exhaustive scan */
+  MVICP_NN_GRID = 2   /* spatial-hash (uniform grid) search with exact far-query fallback */
+};
+
+const char* mvicp_last_error(void);
+/* "name major.minor" of the build, and the gfx arch the kernels were compiled for. */
+const char* mvicp_version(void);
+
+/* ---- lifetime -------------------------------------------------------------------------------- */
+int mvicp_create(int device, mvicp_ctx** out);
+int mvicp_destroy(mvicp_ctx* ctx);
+
+/* ---- data upload (once; clouds are static in their local frame) ------------------------------- */
+/* Replaces Frame::pts / Frame::nor as the kernel-visible copy (include/frame.h:38-39) and the lazy
+ * KD-tree build of Frame::getClosestPoint (src/internal/frame.cpp:188-193): the per-cloud NN
+ * structure is built here, once.  nrm may be NULL (point-to-point only). */
+int mvicp_set_num_frames(mvicp_ctx* ctx, int n_frames);
+int mvicp_set_frame(mvicp_ctx* ctx, int frame, const double* xyz, const double* nrm, int n);
+
+/* Pose graph = all Frame::neighbours[j].neighbourIdx (frame.cpp:67-89 builds it; main_multiview.cpp:
+ * 104-117).  Edge order is the reference's loop order: src ascending, then neighbour order. */
+int mvicp_set_graph(mvicp_ctx* ctx, int n_edges, const int* src, const int* dst);
+
+/* Multi-GPU: this rank owns a contiguous chunk of the edge list (balanced by N_src).  Call before
+ * mvicp_set_graph.  Default rank 0 of 1. */
+int mvicp_set_shard(mvicp_ctx* ctx, int rank, int world);
+/* The partition rule itself (pure host function, no context): owner[e] in [0, world) for edges with n_src[e]
+ * source points each.  Contiguous chunks, balanced by source points. */
+int mvicp_edge_owner(int n_edges, const int* n_src, int world, int* owner);
+/* RCCL communicator for the per-edge normal-equation all-reduce.  librccl_path: the librccl.so to
+ * dlopen (pass the one torch already loaded, or NULL for "librccl.so.1").  unique_id: 128 bytes
+ * produced by mvicp_comm_unique_id on rank 0 and broadcast by the launcher. */
+int mvicp_comm_unique_id(const char* librccl_path, void* unique_id_128);
+int mvicp_comm_init(mvicp_ctx* ctx, const char* librccl_path, const void* unique_id_128, int rank, int world);
+
+/* ---- S1: correspondence search ----------------------------------------------------------------
+ * Replaces, for ALL non-fixed frames at once, Frame::computeClosestPointsToNeighbours(frames, thresh)
+ * (include/frame.h:54, src/internal/frame.cpp:91-185; caller main_multiview.cpp:119-127).
+ *   poses  : n_frames x 16;  fixed : n_frames bytes (edges whose src is fixed are skipped, frame.cpp:93)
+ *   thresh : the float cutoff (frame.h:54)
+ *   counts / weights (n_edges, may be NULL): |correspondances| and OutgoingEdge::weight =
+ *            (float)(1.5 * upper median distance) (frame.cpp:166-176).  weight of an empty edge = 0. */
+int mvicp_correspond(mvicp_ctx* ctx, const double* poses, const unsigned char* fixed, float thresh, int nn_method,
+                     int* counts, float* weights);
+/* Copy edge e's list back as Frame::neighbours[j].correspondances (frame.h:18-22): ascending `first`. */
+int mvicp_get_correspondences(mvicp_ctx* ctx, int edge, int cap, int* first, int* second, double* dist);
+/* Install an explicit list (pairwise known-correspondence case, main_pairwise.cpp:60-61; tests). */
+int mvicp_set_correspondences(mvicp_ctx* ctx, int edge, int n, const int* first, const int* second, float weight);
+
+/* S1': batch form of Frame::getClosestPoint (frame.h:55, frame.cpp:187-206): queries are already in
+ * the frame's local coordinates; returns index and SQUARED distance per query. */
+int mvicp_nn_query(mvicp_ctx* ctx, int frame, const double* queries, int n, int nn_method, int* idx, double* d2);
+
+/* ---- normal equations ---------------------------------------------------------------------------
+ * Per edge: the 12x12 Gauss-Newton block of  sum rho(||r||^2)/2  in canonical right-perturbation
+ * coordinates [upsilon_s, omega_s, upsilon_d, omega_d]  (T <- T exp(delta)), i.e. what
+ * Ceres accumulates from the residual blocks of include/icp-ceres.h:49-316 + SoftLOneLoss(edge.weight)
+ * (icp-ceres.cpp:284,374,449).  out: n_edges x 91 = [78 upper-triangular row-major H | 12 g | cost]. */
+#define MVICP_EDGE_BLOCK 91
+int mvicp_linearize(mvicp_ctx* ctx, const double* poses, int point_to_plane, int robust, double* out);
+
+/* ---- S2: the LM solve ----------------------------------------------------------------------------
+ * Replaces ICP_Ceres::ceresOptimizer / _ceresAngleAxis / _sophusSE3 (frames, pointToPlane, robust)
+ * (include/icp-ceres.h:40-42; caller main_multiview.cpp:158-161).  poses in/out (frames[i]->pose).
+ * fixed[0] is forced to 1 like icp-ceres.cpp:244,341,417. */
+typedef struct mvicp_summary {
+  double initial_cost, final_cost;
+  int iterations;        /* LM iterations after the initial evaluation (<= max_iterations) */
+  int successful_steps;
+  int termination;       /* 0 max-iterations, 1 gradient tol, 2 parameter tol, 3 function tol, 4 radius, -1 failure */
+  int evaluations;       /* device linearize launches */
+} mvicp_summary;
+int mvicp_optimize(mvicp_ctx* ctx, double* poses, unsigned char* fixed, int param, int point_to_plane, int robust,
+                   int max_iterations /* reference: 50, icp-ceres.cpp:81 */, mvicp_summary* summary);
+
+/* Host-only form of the same solver over a caller-supplied evaluator (no GPU touched by this call):
+ * eval(user, poses[n_frames x 16], blocks[n_edges x 91]) must fill the per-edge canonical blocks exactly
+ * as mvicp_linearize does.  mvicp_optimize is this with the device evaluator plugged in. */
+typedef int (*mvicp_eval_fn)(void* user, const double* poses, double* blocks);
+int mvicp_lm_solve(int n_frames, int n_edges, const int* src, const int* dst, double* poses, unsigned char* fixed, int param,
+                   int max_iterations, mvicp_eval_fn eval, void* user, mvicp_summary* summary);
+
+/* ---- profiling (HIP events on the library's own stream) ------------------------------------------ */
+int mvicp_profile_enable(mvicp_ctx* ctx, int on);
+int mvicp_profile_reset(mvicp_ctx* ctx);
+/* kernel in {"nn","compact","select","linearize","reduce"}: total ms, launches, algorithmic bytes. */
+int mvicp_profile_get(mvicp_ctx* ctx, const char* kernel, double* total_ms, long long* launches, double* alg_bytes);
+/* Opaque hipStream_t the library launches on (so a harness can bracket it with its own events). */
+void* mvicp_stream(mvicp_ctx* ctx);
+int mvicp_sync(mvicp_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVICP_H */

@@ -1,0 +1,519 @@
+// C-ABI of libmvicp_hip.so (include/mvicp.h): context, uploads, the correspondence pipeline
+// (S1: NN -> cutoff/compaction -> median), per-edge normal equations, profiling.
+// The LM solve (S2) lives in host/lm.cpp; the RCCL glue in comm.cpp.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "common.h"
+#include "comm.h"
+
+namespace mvicp {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+void scratch_reset(mvicp_ctx* c) { c->scratch_used = 0; }
+
+int scratch_upload(mvicp_ctx* c, const void* src, size_t bytes, void** dptr) {
+  const size_t aligned = (bytes + 255) & ~(size_t)255;
+  if (c->scratch_used + aligned > c->scratch_bytes) {
+    // grow: wait for in-flight users, then reallocate (callers re-upload everything after a reset)
+    if (c->scratch_used != 0) { set_error("scratch overflow (%zu + %zu > %zu)", c->scratch_used, aligned, c->scratch_bytes); return MVICP_ERR_STATE; }
+    MV_HIP(hipStreamSynchronize(c->stream));
+    if (c->d_scratch) MV_HIP(hipFree(c->d_scratch));
+    c->scratch_bytes = std::max<size_t>(aligned * 4, 1 << 20);
+    MV_HIP(hipMalloc((void**)&c->d_scratch, c->scratch_bytes));
+  }
+  void* d = c->d_scratch + c->scratch_used;
+  // stream-ordered w.r.t. earlier kernels that may still read the scratch, then synchronous for the host source
+  MV_HIP(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, c->stream));
+  MV_HIP(hipStreamSynchronize(c->stream));
+  c->scratch_used += aligned;
+  *dptr = d;
+  return MVICP_OK;
+}
+
+ProfScope::ProfScope(mvicp_ctx* ctx, const char* nm, double bytes) : c(ctx), name(nm), on(ctx->profile) {
+  if (!on) return;
+  ProfEntry& pe = c->prof[name];
+  auto get = [&]() {
+    hipEvent_t ev = nullptr;
+    if (!pe.pool.empty()) { ev = pe.pool.back(); pe.pool.pop_back(); }
+    else if (hipEventCreate(&ev) != hipSuccess) ev = nullptr;
+    return ev;
+  };
+  a = get(); b = get();
+  pe.bytes += bytes;
+  pe.launches += 1;
+  if (a) (void)hipEventRecord(a, c->stream);
+}
+ProfScope::~ProfScope() {
+  if (!on) return;
+  if (b) (void)hipEventRecord(b, c->stream);
+  if (a && b) c->prof[name].pending.push_back(std::make_pair(a, b));
+}
+void prof_collect(mvicp_ctx* c) {
+  for (auto& kv : c->prof) {
+    ProfEntry& pe = kv.second;
+    for (auto& pr : pe.pending) {
+      float ms = 0.f;
+      if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) pe.ms += ms;
+      pe.pool.push_back(pr.first);
+      pe.pool.push_back(pr.second);
+    }
+    pe.pending.clear();
+  }
+}
+
+namespace {
+
+template <typename T> int dev_alloc(T** p, size_t n) {
+  *p = nullptr;
+  if (n == 0) n = 1;
+  MV_HIP(hipMalloc((void**)p, sizeof(T) * n));
+  return MVICP_OK;
+}
+template <typename T> void dev_free(T*& p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+
+void free_graph(mvicp_ctx* c) {
+  dev_free(c->d_esrc); dev_free(c->d_edst); dev_free(c->d_cap_off); dev_free(c->d_nsrc); dev_free(c->d_count); dev_free(c->d_a);
+  dev_free(c->d_xf); dev_free(c->d_rel); dev_free(c->d_nn_idx); dev_free(c->d_nn_d2); dev_free(c->d_first); dev_free(c->d_second);
+  dev_free(c->d_cd2); dev_free(c->d_stream); dev_free(c->d_cblock_off); dev_free(c->d_cblock_cnt); dev_free(c->d_sel_prefix);
+  dev_free(c->d_sel_k); dev_free(c->d_sel_hist); dev_free(c->d_median); dev_free(c->d_chunk_edge); dev_free(c->d_chunk_start);
+  dev_free(c->d_chunk_first); dev_free(c->d_partials); dev_free(c->d_out);
+  if (c->h_pin) (void)hipHostFree(c->h_pin);
+  c->h_pin = nullptr; c->h_pin_doubles = 0;
+  c->E = 0; c->total_cap = 0; c->n_cblocks = 0; c->n_chunks = 0; c->have_corr = false;
+}
+
+int bind(mvicp_ctx* c) {
+  if (!c) { set_error("null context"); return MVICP_ERR_ARG; }
+  MV_HIP(hipSetDevice(c->device));
+  return MVICP_OK;
+}
+
+// smallest double x such that the correctly rounded sqrt(x) >= t  ==>  (sqrt(d2) < t)  <=>  (d2 < x)
+double sqrt_bound(double t) {
+  double x = t * t;
+  while (std::sqrt(x) >= t && x > 0.0) x = std::nextafter(x, 0.0);
+  while (std::sqrt(x) < t) x = std::nextafter(x, INFINITY);
+  return x;
+}
+
+// Eigen 3x3 inverse (cofactor form), column-major — frame.cpp:118 `dstCloud.pose.linear().inverse()`.
+void inverse3(const double* m, double* r) {
+#define M(i, j) m[(i) + 3 * (j)]
+#define COF(i, j) (M(((i) + 1) % 3, ((j) + 1) % 3) * M(((i) + 2) % 3, ((j) + 2) % 3) - M(((i) + 1) % 3, ((j) + 2) % 3) * M(((i) + 2) % 3, ((j) + 1) % 3))
+  const double c00 = COF(0, 0), c10 = COF(1, 0), c20 = COF(2, 0);
+  const double det = (c00 * M(0, 0) + c10 * M(1, 0)) + c20 * M(2, 0);
+  const double invdet = 1.0 / det;
+  r[0] = c00 * invdet; r[3] = c10 * invdet; r[6] = c20 * invdet;
+  r[1] = COF(0, 1) * invdet; r[4] = COF(1, 1) * invdet; r[7] = COF(2, 1) * invdet;
+  r[2] = COF(0, 2) * invdet; r[5] = COF(1, 2) * invdet; r[8] = COF(2, 2) * invdet;
+#undef COF
+#undef M
+}
+
+int ensure_pin(mvicp_ctx* c, size_t doubles) {
+  if (doubles <= c->h_pin_doubles) return MVICP_OK;
+  if (c->h_pin) MV_HIP(hipHostFree(c->h_pin));
+  c->h_pin = nullptr;
+  MV_HIP(hipHostMalloc((void**)&c->h_pin, sizeof(double) * doubles, hipHostMallocDefault));
+  c->h_pin_doubles = doubles;
+  return MVICP_OK;
+}
+
+}  // namespace
+
+// Per-edge relative transform for the LM kernels: A = R_d^T R_s, t = R_d^T (t_s - t_d).
+int upload_rel(mvicp_ctx* c, const double* poses) {
+  double* h = c->h_pin;  // E x 12 at offset 0
+  for (int e = 0; e < c->E; ++e) {
+    const double* Ps = poses + 16 * (size_t)c->esrc[e];
+    const double* Pd = poses + 16 * (size_t)c->edst[e];
+    double* r = h + (size_t)e * kEdgeRel;
+    for (int j = 0; j < 3; ++j)
+      for (int i = 0; i < 3; ++i) r[i + 3 * j] = Pd[0 + 4 * i] * Ps[0 + 4 * j] + Pd[1 + 4 * i] * Ps[1 + 4 * j] + Pd[2 + 4 * i] * Ps[2 + 4 * j];
+    const double dt[3] = {Ps[12] - Pd[12], Ps[13] - Pd[13], Ps[14] - Pd[14]};
+    for (int i = 0; i < 3; ++i) r[9 + i] = Pd[0 + 4 * i] * dt[0] + Pd[1 + 4 * i] * dt[1] + Pd[2 + 4 * i] * dt[2];
+  }
+  MV_HIP(hipMemcpyAsync(c->d_rel, h, sizeof(double) * (size_t)c->E * kEdgeRel, hipMemcpyHostToDevice, c->stream));
+  return MVICP_OK;
+}
+
+// One device evaluation of all per-edge blocks at `poses` -> host `out` (E x 91), all-reduced over ranks.
+int evaluate_blocks(mvicp_ctx* c, const double* poses, int plane, int robust, double* out) {
+  if (!c->have_corr) { set_error("no correspondences: call mvicp_correspond or mvicp_set_correspondences first"); return MVICP_ERR_STATE; }
+  if (plane) {
+    for (int e = 0; e < c->E; ++e)
+      if (c->owned[e] && c->h_count[e] > 0 && c->frames[c->edst[e]].nor == nullptr) {
+        set_error("point-to-plane needs normals on frame %d", c->edst[e]);
+        return MVICP_ERR_STATE;
+      }
+  }
+  MV_CHECK(upload_rel(c, poses));
+  MV_CHECK(launch_linearize(c, plane, robust));
+  const size_t n = (size_t)c->E * MVICP_EDGE_BLOCK;
+  if (c->comm) MV_CHECK(comm_allreduce_sum(c, c->d_out, n));
+  double* h = c->h_pin + (size_t)c->E * kEdgeRel;
+  MV_HIP(hipMemcpyAsync(h, c->d_out, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  MV_HIP(hipStreamSynchronize(c->stream));
+  std::memcpy(out, h, sizeof(double) * n);
+  return MVICP_OK;
+}
+
+}  // namespace mvicp
+
+using namespace mvicp;
+
+extern "C" {
+
+const char* mvicp_last_error(void) { return g_err; }
+const char* mvicp_version(void) { return "mvicp_hip 0.1 (gfx950)"; }
+
+int mvicp_create(int device, mvicp_ctx** out) {
+  if (!out) { set_error("out is null"); return MVICP_ERR_ARG; }
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    set_error("no HIP device available (%s): libmvicp_hip has no CPU fallback", e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    return MVICP_ERR_HIP;
+  }
+  if (device < 0 || device >= ndev) { set_error("device %d out of range [0,%d)", device, ndev); return MVICP_ERR_ARG; }
+  mvicp_ctx* c = new mvicp_ctx();
+  c->device = device;
+  MV_HIP(hipSetDevice(device));
+  MV_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  *out = c;
+  return MVICP_OK;
+}
+
+int mvicp_destroy(mvicp_ctx* c) {
+  if (!c) return MVICP_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  comm_destroy(c);
+  free_graph(c);
+  for (FrameDev& f : c->frames) { dev_free(f.pts); dev_free(f.nor); free_grid(f.grid); }
+  dev_free(c->d_split_idx); dev_free(c->d_split_d2); dev_free(c->d_scratch);
+  for (auto& kv : c->prof) {
+    for (auto& pr : kv.second.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (hipEvent_t ev : kv.second.pool) (void)hipEventDestroy(ev);
+  }
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+  return MVICP_OK;
+}
+
+int mvicp_set_num_frames(mvicp_ctx* c, int n_frames) {
+  MV_CHECK(bind(c));
+  if (n_frames < 0) { set_error("n_frames < 0"); return MVICP_ERR_ARG; }
+  if (c->E) free_graph(c);
+  for (FrameDev& f : c->frames) { dev_free(f.pts); dev_free(f.nor); free_grid(f.grid); }
+  c->frames.assign(n_frames, FrameDev());
+  c->n_frames = n_frames;
+  return MVICP_OK;
+}
+
+int mvicp_set_frame(mvicp_ctx* c, int frame, const double* xyz, const double* nrm, int n) {
+  MV_CHECK(bind(c));
+  if (frame < 0 || frame >= c->n_frames) { set_error("frame %d out of range [0,%d)", frame, c->n_frames); return MVICP_ERR_ARG; }
+  if (n < 0 || (n > 0 && !xyz)) { set_error("bad cloud (n=%d)", n); return MVICP_ERR_ARG; }
+  if (c->E) { set_error("set frames before mvicp_set_graph"); return MVICP_ERR_STATE; }
+  FrameDev& f = c->frames[frame];
+  dev_free(f.pts); dev_free(f.nor); free_grid(f.grid);
+  f.has_grid = false;
+  f.n = n;
+  MV_CHECK(dev_alloc(&f.pts, 3 * (size_t)n));
+  if (n) MV_HIP(hipMemcpy(f.pts, xyz, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice));
+  if (nrm) {
+    MV_CHECK(dev_alloc(&f.nor, 3 * (size_t)n));
+    if (n) MV_HIP(hipMemcpy(f.nor, nrm, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice));
+  }
+  if (n > 0) MV_CHECK(build_grid(c, f, xyz));
+  return MVICP_OK;
+}
+
+int mvicp_set_shard(mvicp_ctx* c, int rank, int world) {
+  MV_CHECK(bind(c));
+  if (world < 1 || rank < 0 || rank >= world) { set_error("bad shard %d/%d", rank, world); return MVICP_ERR_ARG; }
+  if (c->E) { set_error("call mvicp_set_shard before mvicp_set_graph"); return MVICP_ERR_STATE; }
+  c->rank = rank; c->world = world;
+  return MVICP_OK;
+}
+
+int mvicp_edge_owner(int n_edges, const int* n_src, int world, int* owner) {
+  if (n_edges < 0 || world < 1 || (n_edges > 0 && (!n_src || !owner))) { set_error("bad arguments"); return MVICP_ERR_ARG; }
+  double total = 0, cum = 0;
+  for (int e = 0; e < n_edges; ++e) total += n_src[e];
+  for (int e = 0; e < n_edges; ++e) {
+    const double n = n_src[e];
+    int o = total > 0 ? (int)std::floor((cum + 0.5 * n) * world / total) : 0;
+    owner[e] = std::min(std::max(o, 0), world - 1);
+    cum += n;
+  }
+  return MVICP_OK;
+}
+
+int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) {
+  MV_CHECK(bind(c));
+  if (n_edges < 0 || (n_edges > 0 && (!src || !dst))) { set_error("bad edge list"); return MVICP_ERR_ARG; }
+  for (int e = 0; e < n_edges; ++e)
+    if (src[e] < 0 || src[e] >= c->n_frames || dst[e] < 0 || dst[e] >= c->n_frames || src[e] == dst[e]) {
+      set_error("edge %d (%d->%d) invalid", e, src[e], dst[e]);
+      return MVICP_ERR_ARG;
+    }
+  free_graph(c);
+  const int E = n_edges;
+  c->E = E;
+  c->esrc.assign(src, src + E);
+  c->edst.assign(dst, dst + E);
+  c->owned.assign(E, 0);
+  c->active.assign(E, 0);
+  c->h_count.assign(E, 0);
+  c->h_weight.assign(E, 0.f);
+  // contiguous edge chunks balanced by N_src
+  {
+    std::vector<int> ns(E), owner(E);
+    for (int e = 0; e < E; ++e) ns[e] = c->frames[src[e]].n;
+    MV_CHECK(mvicp_edge_owner(E, ns.data(), c->world, owner.data()));
+    for (int e = 0; e < E; ++e) c->owned[e] = owner[e] == c->rank;
+  }
+  c->cap_off.assign(E + 1, 0);
+  c->cblock_off.assign(E + 1, 0);
+  c->chunk_first.assign(E + 1, 0);
+  std::vector<int> chunk_edge, chunk_start;
+  for (int e = 0; e < E; ++e) {
+    const long long n = c->owned[e] ? c->frames[src[e]].n : 0;
+    c->cap_off[e + 1] = c->cap_off[e] + ((n + 63) / 64) * 64;
+    c->cblock_off[e + 1] = c->cblock_off[e] + (int)((n + kCompactBlock - 1) / kCompactBlock);
+    const int nch = (int)((n + kLinChunk - 1) / kLinChunk);
+    c->chunk_first[e + 1] = c->chunk_first[e] + nch;
+    for (int k = 0; k < nch; ++k) { chunk_edge.push_back(e); chunk_start.push_back(k * kLinChunk); }
+  }
+  c->total_cap = c->cap_off[E];
+  c->n_cblocks = c->cblock_off[E];
+  c->n_chunks = c->chunk_first[E];
+  const size_t cap = (size_t)c->total_cap;
+  MV_CHECK(dev_alloc(&c->d_esrc, E)); MV_CHECK(dev_alloc(&c->d_edst, E)); MV_CHECK(dev_alloc(&c->d_cap_off, E + 1));
+  MV_CHECK(dev_alloc(&c->d_nsrc, E)); MV_CHECK(dev_alloc(&c->d_count, E)); MV_CHECK(dev_alloc(&c->d_a, E));
+  MV_CHECK(dev_alloc(&c->d_xf, (size_t)E * kEdgeXf)); MV_CHECK(dev_alloc(&c->d_rel, (size_t)E * kEdgeRel));
+  MV_CHECK(dev_alloc(&c->d_nn_idx, cap)); MV_CHECK(dev_alloc(&c->d_nn_d2, cap));
+  MV_CHECK(dev_alloc(&c->d_first, cap)); MV_CHECK(dev_alloc(&c->d_second, cap)); MV_CHECK(dev_alloc(&c->d_cd2, cap));
+  MV_CHECK(dev_alloc(&c->d_stream, 9 * cap));
+  MV_CHECK(dev_alloc(&c->d_cblock_off, E + 1)); MV_CHECK(dev_alloc(&c->d_cblock_cnt, (size_t)c->n_cblocks));
+  MV_CHECK(dev_alloc(&c->d_sel_prefix, E)); MV_CHECK(dev_alloc(&c->d_sel_k, E)); MV_CHECK(dev_alloc(&c->d_sel_hist, (size_t)E * 256));
+  MV_CHECK(dev_alloc(&c->d_median, E));
+  MV_CHECK(dev_alloc(&c->d_chunk_edge, (size_t)c->n_chunks)); MV_CHECK(dev_alloc(&c->d_chunk_start, (size_t)c->n_chunks));
+  MV_CHECK(dev_alloc(&c->d_chunk_first, E + 1));
+  MV_CHECK(dev_alloc(&c->d_partials, (size_t)c->n_chunks * MVICP_EDGE_BLOCK)); MV_CHECK(dev_alloc(&c->d_out, (size_t)E * MVICP_EDGE_BLOCK));
+  if (E) {
+    MV_HIP(hipMemcpy(c->d_esrc, src, sizeof(int) * E, hipMemcpyHostToDevice));
+    MV_HIP(hipMemcpy(c->d_edst, dst, sizeof(int) * E, hipMemcpyHostToDevice));
+    MV_HIP(hipMemset(c->d_count, 0, sizeof(int) * E));
+    MV_HIP(hipMemset(c->d_nsrc, 0, sizeof(int) * E));
+    MV_HIP(hipMemset(c->d_a, 0, sizeof(double) * E));
+  }
+  MV_HIP(hipMemcpy(c->d_cap_off, c->cap_off.data(), sizeof(long long) * (E + 1), hipMemcpyHostToDevice));
+  MV_HIP(hipMemcpy(c->d_cblock_off, c->cblock_off.data(), sizeof(int) * (E + 1), hipMemcpyHostToDevice));
+  MV_HIP(hipMemcpy(c->d_chunk_first, c->chunk_first.data(), sizeof(int) * (E + 1), hipMemcpyHostToDevice));
+  if (c->n_chunks) {
+    MV_HIP(hipMemcpy(c->d_chunk_edge, chunk_edge.data(), sizeof(int) * c->n_chunks, hipMemcpyHostToDevice));
+    MV_HIP(hipMemcpy(c->d_chunk_start, chunk_start.data(), sizeof(int) * c->n_chunks, hipMemcpyHostToDevice));
+  }
+  MV_CHECK(ensure_pin(c, (size_t)E * (kEdgeXf + kEdgeRel + MVICP_EDGE_BLOCK + 8) + 64));
+  return MVICP_OK;
+}
+
+int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fixed, float thresh, int nn_method, int* counts, float* weights) {
+  MV_CHECK(bind(c));
+  if (!poses) { set_error("poses is null"); return MVICP_ERR_ARG; }
+  if (c->E == 0) { set_error("no graph: call mvicp_set_graph first"); return MVICP_ERR_STATE; }
+  const int E = c->E;
+  // per-edge query transforms (frame.cpp:117-118,131,136) + active mask (frame.cpp:93)
+  std::vector<int> nsrc(E, 0);
+  double* hx = c->h_pin;
+  for (int e = 0; e < E; ++e) {
+    c->active[e] = c->owned[e] && !(fixed && fixed[c->esrc[e]]);
+    nsrc[e] = c->active[e] ? c->frames[c->esrc[e]].n : 0;
+    const double* Ps = poses + 16 * (size_t)c->esrc[e];
+    const double* Pd = poses + 16 * (size_t)c->edst[e];
+    double* x = hx + (size_t)e * kEdgeXf;
+    double Rd[9];
+    for (int j = 0; j < 3; ++j)
+      for (int i = 0; i < 3; ++i) { x[i + 3 * j] = Ps[i + 4 * j]; Rd[i + 3 * j] = Pd[i + 4 * j]; }
+    for (int i = 0; i < 3; ++i) { x[9 + i] = Ps[12 + i]; x[21 + i] = Pd[12 + i]; }
+    inverse3(Rd, x + 12);
+  }
+  MV_HIP(hipMemcpyAsync(c->d_xf, hx, sizeof(double) * (size_t)E * kEdgeXf, hipMemcpyHostToDevice, c->stream));
+  MV_HIP(hipStreamSynchronize(c->stream));
+  std::memcpy(hx, nsrc.data(), sizeof(int) * E);
+  MV_HIP(hipMemcpyAsync(c->d_nsrc, hx, sizeof(int) * E, hipMemcpyHostToDevice, c->stream));
+
+  const double bound = sqrt_bound((double)thresh);
+  int method = nn_method;
+  if (method == MVICP_NN_AUTO) method = MVICP_NN_GRID;
+  if (method == MVICP_NN_GRID) {
+    for (int e = 0; e < E; ++e)
+      if (c->active[e] && !c->frames[c->edst[e]].has_grid) method = MVICP_NN_BRUTE;
+  }
+  if (method == MVICP_NN_BRUTE) MV_CHECK(launch_nn_brute_edges(c));
+  else if (method == MVICP_NN_GRID) MV_CHECK(launch_nn_grid_edges(c, bound));
+  else { set_error("unknown nn_method %d", nn_method); return MVICP_ERR_ARG; }
+
+  MV_CHECK(launch_compact(c, bound));
+  MV_CHECK(launch_gather_stream(c));
+  MV_CHECK(launch_select_median(c));
+  // counts + median d2 back; weight = (float)(1.5 * sqrt(median d2))  (frame.cpp:168-176)
+  int* hc = reinterpret_cast<int*>(c->h_pin);
+  double* hm = c->h_pin + E;  // leave room: E ints fit in E doubles
+  MV_HIP(hipMemcpyAsync(hc, c->d_count, sizeof(int) * E, hipMemcpyDeviceToHost, c->stream));
+  MV_HIP(hipMemcpyAsync(hm, c->d_median, sizeof(double) * E, hipMemcpyDeviceToHost, c->stream));
+  MV_HIP(hipStreamSynchronize(c->stream));
+  std::vector<double> pack(2 * (size_t)E, 0.0);
+  for (int e = 0; e < E; ++e)
+    if (c->owned[e]) { pack[2 * e] = c->active[e] ? hc[e] : 0; pack[2 * e + 1] = (c->active[e] && hc[e] > 0) ? hm[e] : 0.0; }
+  if (c->comm) MV_CHECK(comm_allreduce_host(c, pack.data(), pack.size()));
+  double* ha = c->h_pin;
+  for (int e = 0; e < E; ++e) {
+    c->h_count[e] = (int)pack[2 * e];
+    const double nth = std::sqrt(pack[2 * e + 1]);
+    c->h_weight[e] = c->h_count[e] > 0 ? (float)(nth * 1.5) : 0.f;
+    ha[e] = (double)c->h_weight[e];
+    if (counts) counts[e] = c->h_count[e];
+    if (weights) weights[e] = c->h_weight[e];
+  }
+  MV_HIP(hipMemcpyAsync(c->d_a, ha, sizeof(double) * E, hipMemcpyHostToDevice, c->stream));
+  MV_HIP(hipStreamSynchronize(c->stream));
+  c->have_corr = true;
+  if (c->profile) prof_collect(c);
+  return MVICP_OK;
+}
+
+int mvicp_get_correspondences(mvicp_ctx* c, int edge, int cap, int* first, int* second, double* dist) {
+  MV_CHECK(bind(c));
+  if (edge < 0 || edge >= c->E) { set_error("edge %d out of range", edge); return MVICP_ERR_ARG; }
+  if (!c->have_corr) { set_error("no correspondences yet"); return MVICP_ERR_STATE; }
+  if (!c->owned[edge]) { set_error("edge %d is owned by another rank", edge); return MVICP_ERR_STATE; }
+  const int n = c->h_count[edge];
+  if (cap < n) { set_error("capacity %d < count %d", cap, n); return MVICP_ERR_ARG; }
+  const size_t off = (size_t)c->cap_off[edge];
+  MV_HIP(hipStreamSynchronize(c->stream));
+  if (first) MV_HIP(hipMemcpy(first, c->d_first + off, sizeof(int) * n, hipMemcpyDeviceToHost));
+  if (second) MV_HIP(hipMemcpy(second, c->d_second + off, sizeof(int) * n, hipMemcpyDeviceToHost));
+  if (dist) {
+    MV_HIP(hipMemcpy(dist, c->d_cd2 + off, sizeof(double) * n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) dist[i] = std::sqrt(dist[i]);  // frame.cpp:139 pointDist = sqrt(pointDistSquared), IEEE on the host
+  }
+  return n;
+}
+
+int mvicp_set_correspondences(mvicp_ctx* c, int edge, int n, const int* first, const int* second, float weight) {
+  MV_CHECK(bind(c));
+  if (edge < 0 || edge >= c->E) { set_error("edge %d out of range", edge); return MVICP_ERR_ARG; }
+  if (!c->owned[edge]) { set_error("edge %d is owned by another rank", edge); return MVICP_ERR_STATE; }
+  const int ns = c->frames[c->esrc[edge]].n, nd = c->frames[c->edst[edge]].n;
+  if (n < 0 || n > ns) { set_error("n=%d exceeds the edge capacity N_src=%d", n, ns); return MVICP_ERR_ARG; }
+  for (int i = 0; i < n; ++i)
+    if (first[i] < 0 || first[i] >= ns || second[i] < 0 || second[i] >= nd) { set_error("correspondence %d out of range", i); return MVICP_ERR_ARG; }
+  const size_t off = (size_t)c->cap_off[edge];
+  MV_HIP(hipStreamSynchronize(c->stream));
+  if (n) {
+    MV_HIP(hipMemcpy(c->d_first + off, first, sizeof(int) * n, hipMemcpyHostToDevice));
+    MV_HIP(hipMemcpy(c->d_second + off, second, sizeof(int) * n, hipMemcpyHostToDevice));
+    MV_HIP(hipMemset(c->d_cd2 + off, 0, sizeof(double) * n));
+  }
+  const double a = (double)weight;
+  MV_HIP(hipMemcpy(c->d_count + edge, &n, sizeof(int), hipMemcpyHostToDevice));
+  MV_HIP(hipMemcpy(c->d_a + edge, &a, sizeof(double), hipMemcpyHostToDevice));
+  c->h_count[edge] = n;
+  c->h_weight[edge] = weight;
+  c->have_corr = true;
+  MV_CHECK(launch_gather_stream(c));
+  MV_HIP(hipStreamSynchronize(c->stream));
+  return MVICP_OK;
+}
+
+int mvicp_nn_query(mvicp_ctx* c, int frame, const double* queries, int n, int nn_method, int* idx, double* d2) {
+  MV_CHECK(bind(c));
+  if (frame < 0 || frame >= c->n_frames) { set_error("frame %d out of range", frame); return MVICP_ERR_ARG; }
+  if (n < 0 || (n && (!queries || !idx || !d2))) { set_error("bad query buffers"); return MVICP_ERR_ARG; }
+  const FrameDev& f = c->frames[frame];
+  if (f.n == 0) { set_error("frame %d is empty (nanoflann throws here: nanoflann.hpp:904)", frame); return MVICP_ERR_STATE; }
+  if (n == 0) return MVICP_OK;
+  double* dq = nullptr; int* di = nullptr; double* dd = nullptr;
+  MV_CHECK(dev_alloc(&dq, 3 * (size_t)n)); MV_CHECK(dev_alloc(&di, (size_t)n)); MV_CHECK(dev_alloc(&dd, (size_t)n));
+  MV_HIP(hipMemcpy(dq, queries, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice));
+  int method = nn_method == MVICP_NN_AUTO ? MVICP_NN_GRID : nn_method;
+  if (method == MVICP_NN_GRID && !f.has_grid) method = MVICP_NN_BRUTE;
+  int st;
+  if (method == MVICP_NN_BRUTE) st = launch_nn_brute_queries(c, f, dq, n, di, dd);
+  else if (method == MVICP_NN_GRID) st = launch_nn_grid_queries(c, f, dq, n, di, dd);
+  else { set_error("unknown nn_method %d", nn_method); st = MVICP_ERR_ARG; }
+  if (st == MVICP_OK) {
+    hipError_t e1 = hipStreamSynchronize(c->stream);
+    hipError_t e2 = hipMemcpy(idx, di, sizeof(int) * n, hipMemcpyDeviceToHost);
+    hipError_t e3 = hipMemcpy(d2, dd, sizeof(double) * n, hipMemcpyDeviceToHost);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { set_error("nn_query copy-back failed"); st = MVICP_ERR_HIP; }
+  }
+  dev_free(dq); dev_free(di); dev_free(dd);
+  if (c->profile) prof_collect(c);
+  return st;
+}
+
+int mvicp_linearize(mvicp_ctx* c, const double* poses, int point_to_plane, int robust, double* out) {
+  MV_CHECK(bind(c));
+  if (!poses || !out) { set_error("null argument"); return MVICP_ERR_ARG; }
+  if (c->E == 0) { set_error("no graph"); return MVICP_ERR_STATE; }
+  MV_CHECK(evaluate_blocks(c, poses, point_to_plane, robust, out));
+  if (c->profile) prof_collect(c);
+  return MVICP_OK;
+}
+
+int mvicp_profile_enable(mvicp_ctx* c, int on) {
+  MV_CHECK(bind(c));
+  c->profile = on != 0;
+  return MVICP_OK;
+}
+int mvicp_profile_reset(mvicp_ctx* c) {
+  MV_CHECK(bind(c));
+  MV_HIP(hipStreamSynchronize(c->stream));
+  prof_collect(c);
+  for (auto& kv : c->prof) { kv.second.ms = 0; kv.second.launches = 0; kv.second.bytes = 0; }
+  return MVICP_OK;
+}
+int mvicp_profile_get(mvicp_ctx* c, const char* kernel, double* total_ms, long long* launches, double* alg_bytes) {
+  MV_CHECK(bind(c));
+  MV_HIP(hipStreamSynchronize(c->stream));
+  prof_collect(c);
+  auto it = c->prof.find(kernel ? kernel : "");
+  if (it == c->prof.end()) {
+    if (total_ms) *total_ms = 0;
+    if (launches) *launches = 0;
+    if (alg_bytes) *alg_bytes = 0;
+    return MVICP_OK;
+  }
+  if (total_ms) *total_ms = it->second.ms;
+  if (launches) *launches = it->second.launches;
+  if (alg_bytes) *alg_bytes = it->second.bytes;
+  return MVICP_OK;
+}
+void* mvicp_stream(mvicp_ctx* c) { return c ? (void*)c->stream : nullptr; }
+int mvicp_sync(mvicp_ctx* c) {
+  MV_CHECK(bind(c));
+  MV_HIP(hipStreamSynchronize(c->stream));
+  return MVICP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,116 @@
+// RCCL over xGMI: the only collective on the path is an in-place fp64 sum all-reduce of the per-edge
+// normal-equation blocks (E x 91 doubles, <= 92 KB at 126 edges) once per LM evaluation, plus one
+// E x 2 all-reduce per ICP round for counts / median d2.  Every edge slot is written by exactly one
+// rank (the others contribute +0.0), so the sum is exact and the result is bit-identical for any
+// number of GPUs.  Latency-bound, not link-bound: one collective per evaluation, nothing to bucket.
+#include "comm.h"
+
+#include <dlfcn.h>
+
+#include <cstring>
+
+namespace mvicp {
+
+struct Id128 { char b[128]; };  // ncclUniqueId, passed by value
+
+struct RcclApi {
+  void* handle = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, Id128, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  double* d_small = nullptr; size_t small_n = 0;
+};
+
+namespace {
+RcclApi* g_api = nullptr;
+
+RcclApi* load(const char* path) {
+  if (g_api) return g_api;
+  const char* p = (path && *path) ? path : "librccl.so.1";
+  void* h = dlopen(p, RTLD_NOW | RTLD_GLOBAL);
+  if (!h && !(path && *path)) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) { set_error("dlopen(%s) failed: %s", p, dlerror()); return nullptr; }
+  RcclApi* a = new RcclApi();
+  a->handle = h;
+  a->GetUniqueId = (int (*)(void*))dlsym(h, "ncclGetUniqueId");
+  a->CommInitRank = (int (*)(void**, int, Id128, int))dlsym(h, "ncclCommInitRank");
+  a->AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclAllReduce");
+  a->CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+  a->GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+  if (!a->GetUniqueId || !a->CommInitRank || !a->AllReduce || !a->CommDestroy) {
+    set_error("%s lacks the nccl* entry points", p);
+    delete a;
+    return nullptr;
+  }
+  g_api = a;
+  return a;
+}
+const char* errstr(RcclApi* a, int r) { return a->GetErrorString ? a->GetErrorString(r) : "rccl error"; }
+}  // namespace
+
+int comm_unique_id(const char* path, void* id128) {
+  RcclApi* a = load(path);
+  if (!a) return MVICP_ERR_COMM;
+  const int r = a->GetUniqueId(id128);
+  if (r != 0) { set_error("ncclGetUniqueId: %s", errstr(a, r)); return MVICP_ERR_COMM; }
+  return MVICP_OK;
+}
+
+int comm_init(mvicp_ctx* c, const char* path, const void* id128, int rank, int world) {
+  RcclApi* a = load(path);
+  if (!a) return MVICP_ERR_COMM;
+  if (rank != c->rank || world != c->world) { set_error("comm rank/world %d/%d differs from the shard %d/%d", rank, world, c->rank, c->world); return MVICP_ERR_ARG; }
+  Id128 id;
+  std::memcpy(id.b, id128, 128);
+  void* comm = nullptr;
+  const int r = a->CommInitRank(&comm, world, id, rank);
+  if (r != 0) { set_error("ncclCommInitRank: %s", errstr(a, r)); return MVICP_ERR_COMM; }
+  c->rccl = a;
+  c->comm = comm;
+  return MVICP_OK;
+}
+
+void comm_destroy(mvicp_ctx* c) {
+  if (c->comm && c->rccl) c->rccl->CommDestroy(c->comm);
+  c->comm = nullptr;
+}
+
+int comm_allreduce_sum(mvicp_ctx* c, double* d_buf, size_t n) {
+  if (!c->comm) return MVICP_OK;
+  const int r = c->rccl->AllReduce(d_buf, d_buf, n, /*ncclFloat64*/ 8, /*ncclSum*/ 0, c->comm, c->stream);
+  if (r != 0) { set_error("ncclAllReduce: %s", errstr(c->rccl, r)); return MVICP_ERR_COMM; }
+  return MVICP_OK;
+}
+
+int comm_allreduce_host(mvicp_ctx* c, double* h_buf, size_t n) {
+  if (!c->comm) return MVICP_OK;
+  RcclApi* a = c->rccl;
+  if (a->small_n < n) {
+    if (a->d_small) (void)hipFree(a->d_small);
+    MV_HIP(hipMalloc((void**)&a->d_small, sizeof(double) * n));
+    a->small_n = n;
+  }
+  MV_HIP(hipMemcpyAsync(a->d_small, h_buf, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+  MV_CHECK(comm_allreduce_sum(c, a->d_small, n));
+  MV_HIP(hipMemcpyAsync(h_buf, a->d_small, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  MV_HIP(hipStreamSynchronize(c->stream));
+  return MVICP_OK;
+}
+
+}  // namespace mvicp
+
+using namespace mvicp;
+extern "C" {
+int mvicp_comm_unique_id(const char* librccl_path, void* unique_id_128) {
+  if (!unique_id_128) { set_error("null id"); return MVICP_ERR_ARG; }
+  return comm_unique_id(librccl_path, unique_id_128);
+}
+int mvicp_comm_init(mvicp_ctx* c, const char* librccl_path, const void* unique_id_128, int rank, int world) {
+  if (!c || !unique_id_128) { set_error("null argument"); return MVICP_ERR_ARG; }
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) { set_error("hipSetDevice failed"); return MVICP_ERR_HIP; }
+  return comm_init(c, librccl_path, unique_id_128, rank, world);
+}
+}

@@ -1,0 +1,160 @@
+// Internal declarations shared by the HIP translation units of libmvicp_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mvicp.h"
+
+namespace mvicp {
+
+void set_error(const char* fmt, ...);
+
+#define MV_HIP(expr)                                                                          \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      mvicp::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e));  \
+      return MVICP_ERR_HIP;                                                                   \
+    }                                                                                         \
+  } while (0)
+
+#define MV_CHECK(call)            \
+  do {                            \
+    int _s = (call);              \
+    if (_s != MVICP_OK) return _s; \
+  } while (0)
+
+constexpr int kLinChunk = 4096;      // correspondences per linearize workgroup
+constexpr int kLinThreads = 256;
+constexpr int kCompactBlock = 1024;  // queries per compaction workgroup
+constexpr int kEdgeXf = 24;          // Rs(9) ts(3) Rdinv(9) td(3), column-major
+constexpr int kEdgeRel = 12;         // R_ds(9, column-major) t_ds(3)
+
+// Uniform grid (spatial hash) over one cloud; see nn_grid.hip.
+struct GridDev {
+  int dims[3] = {0, 0, 0};
+  double origin[3] = {0, 0, 0};
+  double cell = 0.0, inv_cell = 0.0;
+  int n_cells = 0;
+  int* cell_start = nullptr;  // n_cells + 1
+  double* spts = nullptr;     // n x 3 sorted by cell
+  int* sidx = nullptr;        // n: original index of sorted point
+  // left-balanced KD-tree for far queries (host built)
+  double* kd_pts = nullptr;   // n x 3 in tree order
+  int* kd_idx = nullptr;      // n original indices
+  signed char* kd_dim = nullptr;  // split dimension per node
+};
+
+struct FrameDev {
+  int n = 0;
+  double* pts = nullptr;  // n x 3 AoS, original order
+  double* nor = nullptr;  // n x 3 or null
+  GridDev grid;
+  bool has_grid = false;
+};
+
+struct ProfEntry {
+  double ms = 0.0;
+  long long launches = 0;
+  double bytes = 0.0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  std::vector<hipEvent_t> pool;
+};
+
+struct RcclApi;  // comm.cpp
+
+}  // namespace mvicp
+
+struct mvicp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int n_frames = 0;
+  std::vector<mvicp::FrameDev> frames;
+
+  // graph + sharding
+  int rank = 0, world = 1;
+  int E = 0;
+  std::vector<int> esrc, edst;
+  std::vector<char> owned;         // E
+  std::vector<long long> cap_off;  // E+1: prefix of N_src over OWNED edges (0-width for others)
+  long long total_cap = 0;
+  std::vector<int> h_count;        // E, valid after correspond / set_correspondences (owned edges)
+  std::vector<float> h_weight;     // E
+  bool have_corr = false;
+
+  // device per-edge tables
+  int* d_esrc = nullptr; int* d_edst = nullptr;
+  long long* d_cap_off = nullptr;   // E+1
+  int* d_nsrc = nullptr;            // E: N_src if owned and active else 0
+  int* d_count = nullptr;           // E
+  double* d_a = nullptr;            // E: SoftLOne scale (double)(float)weight
+  double* d_xf = nullptr;           // E x kEdgeXf
+  double* d_rel = nullptr;          // E x kEdgeRel
+  // per-query (total_cap)
+  int* d_nn_idx = nullptr; double* d_nn_d2 = nullptr;
+  // per-correspondence (total_cap)
+  int* d_first = nullptr; int* d_second = nullptr; double* d_cd2 = nullptr;
+  double* d_stream = nullptr;       // 9 x total_cap SoA: px py pz qx qy qz nx ny nz
+  // compaction scratch
+  int n_cblocks = 0;                // total compaction blocks over owned edges
+  std::vector<int> cblock_off;      // E+1
+  int* d_cblock_off = nullptr; int* d_cblock_cnt = nullptr;
+  // select scratch
+  unsigned long long* d_sel_prefix = nullptr; int* d_sel_k = nullptr; unsigned int* d_sel_hist = nullptr; double* d_median = nullptr;
+  // linearize chunks
+  int n_chunks = 0;
+  std::vector<int> chunk_first;     // E+1
+  int* d_chunk_edge = nullptr; int* d_chunk_start = nullptr; int* d_chunk_first = nullptr;
+  double* d_partials = nullptr;     // n_chunks x 91
+  double* d_out = nullptr;          // E x 91
+  // pinned host staging
+  double* h_pin = nullptr; size_t h_pin_doubles = 0;
+  // brute-force split scratch
+  int* d_split_idx = nullptr; double* d_split_d2 = nullptr; size_t split_cap = 0;
+
+  // table scratch
+  char* d_scratch = nullptr; size_t scratch_bytes = 0, scratch_used = 0;
+  std::vector<char> active;        // E: owned && src not fixed (set by correspond)
+
+  // comm
+  mvicp::RcclApi* rccl = nullptr;
+  void* comm = nullptr;
+
+  // profiling
+  bool profile = false;
+  std::map<std::string, mvicp::ProfEntry> prof;
+};
+
+namespace mvicp {
+
+// kernels (each defined in its own TU)
+int launch_nn_brute_edges(mvicp_ctx* c);                                             // nn_brute.hip
+int launch_nn_brute_queries(mvicp_ctx* c, const FrameDev& f, const double* d_q, int n, int* d_idx, double* d_d2);
+int launch_nn_grid_edges(mvicp_ctx* c, double d2_bound);                              // nn_grid.hip
+int launch_nn_grid_queries(mvicp_ctx* c, const FrameDev& f, const double* d_q, int n, int* d_idx, double* d_d2);
+int build_grid(mvicp_ctx* c, FrameDev& f, const double* h_xyz);
+void free_grid(GridDev& g);
+int launch_compact(mvicp_ctx* c, double d2_bound);                                    // corr.hip
+int launch_gather_stream(mvicp_ctx* c);
+int launch_select_median(mvicp_ctx* c);
+int launch_linearize(mvicp_ctx* c, int plane, int robust);                            // linearize.hip
+
+// small host->device table uploads through a persistent bump-allocated scratch buffer; the copy is a
+// synchronous hipMemcpy (tables are tiny) so the pageable source may die right after the call.
+void scratch_reset(mvicp_ctx* c);
+int scratch_upload(mvicp_ctx* c, const void* src, size_t bytes, void** dptr);
+
+// profiling helpers
+struct ProfScope {
+  mvicp_ctx* c; const char* name; hipEvent_t a = nullptr, b = nullptr; bool on;
+  ProfScope(mvicp_ctx* c, const char* name, double bytes);
+  ~ProfScope();
+};
+void prof_collect(mvicp_ctx* c);
+
+}  // namespace mvicp

@@ -1,0 +1,281 @@
+// K3/K4 — cutoff filter + stable compaction, packed-stream gather, exact median (radix select).
+//
+// Replaces the tail of Frame::computeClosestPointsToNeighbours (src/internal/frame.cpp:156-176):
+//   if (sqrt(d2) < thresh) push {k, idx, dist}        -> flag / exclusive scan / scatter, ascending k
+//   nth_element(dists, size/2); weight = 1.5 * median -> radix select on the fp64 bit pattern of d2
+// The acceptance test is evaluated as `d2 < bound` where the host has computed `bound` = the smallest
+// double whose correctly rounded sqrt is >= (double)thresh, so the decision is bit-identical to the
+// reference's `sqrt(d2) < thresh` without a device sqrt.  sqrt is monotone, so the median of the
+// distances is the sqrt of the median of d2; the host takes that one sqrt (IEEE, exact).
+//
+// The gather kernel also materialises, once per ICP round, the per-correspondence operand stream the
+// LM evaluations re-read up to ~100 times: SoA px py pz qx qy qz nx ny nz (72 B per correspondence,
+// coalesced) instead of 2 random 24-B gathers per evaluation.
+#include "common.h"
+
+namespace mvicp {
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int IPT = kCompactBlock / NT;  // 4 consecutive queries per thread
+
+__device__ __forceinline__ int find_edge(const int* __restrict__ off, int E, int b) {
+  int lo = 0, hi = E;  // largest e with off[e] <= b
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (off[mid] <= b) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ int block_exclusive_scan(int v, int* __restrict__ wave_tot, int* total) {
+  // inclusive scan inside the wave (64 lanes) by shuffles, then across the 4 waves through LDS
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) {
+    const int t = wave_tot[w];
+    if (w < wave) base += t;
+    tot += t;
+  }
+  *total = tot;
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(NT) void count_kernel(const int* __restrict__ cblock_off, int E, const int* __restrict__ nsrc,
+                                                   const long long* __restrict__ cap_off, const int* __restrict__ nn_idx,
+                                                   const double* __restrict__ nn_d2, double bound, int* __restrict__ cblock_cnt) {
+  __shared__ int wave_tot[NT / 64];
+  const int b = blockIdx.x;
+  const int e = find_edge(cblock_off, E, b);
+  const int lb = b - cblock_off[e];
+  const int n = nsrc[e];
+  const long long base = cap_off[e];
+  int cnt = 0;
+#pragma unroll
+  for (int i = 0; i < IPT; ++i) {
+    const int k = lb * kCompactBlock + threadIdx.x * IPT + i;
+    if (k < n) cnt += (nn_idx[base + k] >= 0 && nn_d2[base + k] < bound) ? 1 : 0;
+  }
+  int total;
+  block_exclusive_scan(cnt, wave_tot, &total);
+  if (threadIdx.x == 0) cblock_cnt[b] = total;
+}
+
+// one workgroup per edge: exclusive scan of its block counts (<= ~1k blocks for 1M points), in place.
+__global__ __launch_bounds__(NT) void scan_kernel(const int* __restrict__ cblock_off, int* __restrict__ cblock_cnt, int* __restrict__ count) {
+  __shared__ int wave_tot[NT / 64];
+  __shared__ int carry_s;
+  const int e = blockIdx.x;
+  const int b0 = cblock_off[e], b1 = cblock_off[e + 1];
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int s = b0; s < b1; s += NT) {
+    const int b = s + threadIdx.x;
+    const int v = (b < b1) ? cblock_cnt[b] : 0;
+    int total;
+    const int ex = block_exclusive_scan(v, wave_tot, &total);
+    const int carry = carry_s;
+    if (b < b1) cblock_cnt[b] = carry + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = carry + total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) count[e] = carry_s;
+}
+
+__global__ __launch_bounds__(NT) void scatter_kernel(const int* __restrict__ cblock_off, int E, const int* __restrict__ nsrc,
+                                                     const long long* __restrict__ cap_off, const int* __restrict__ nn_idx,
+                                                     const double* __restrict__ nn_d2, double bound, const int* __restrict__ cblock_cnt,
+                                                     int* __restrict__ first, int* __restrict__ second, double* __restrict__ cd2) {
+  __shared__ int wave_tot[NT / 64];
+  const int b = blockIdx.x;
+  const int e = find_edge(cblock_off, E, b);
+  const int lb = b - cblock_off[e];
+  const int n = nsrc[e];
+  const long long base = cap_off[e];
+  int idx[IPT];
+  double d2[IPT];
+  bool ok[IPT];
+  int cnt = 0;
+#pragma unroll
+  for (int i = 0; i < IPT; ++i) {
+    const int k = lb * kCompactBlock + threadIdx.x * IPT + i;
+    ok[i] = false;
+    if (k < n) {
+      idx[i] = nn_idx[base + k];
+      d2[i] = nn_d2[base + k];
+      ok[i] = idx[i] >= 0 && d2[i] < bound;
+    }
+    cnt += ok[i] ? 1 : 0;
+  }
+  int total;
+  int pos = cblock_cnt[b] + block_exclusive_scan(cnt, wave_tot, &total);
+#pragma unroll
+  for (int i = 0; i < IPT; ++i) {
+    if (!ok[i]) continue;
+    const int k = lb * kCompactBlock + threadIdx.x * IPT + i;
+    first[base + pos] = k;
+    second[base + pos] = idx[i];
+    cd2[base + pos] = d2[i];
+    ++pos;
+  }
+}
+
+// packed operand stream for the LM evaluations
+__global__ __launch_bounds__(NT) void gather_kernel(const int* __restrict__ cblock_off, int E, const int* __restrict__ count,
+                                                    const long long* __restrict__ cap_off, long long total_cap, const int* __restrict__ first,
+                                                    const int* __restrict__ second, const double* const* __restrict__ src_pts,
+                                                    const double* const* __restrict__ dst_pts, const double* const* __restrict__ dst_nor,
+                                                    double* __restrict__ stream) {
+  const int b = blockIdx.x;
+  const int e = find_edge(cblock_off, E, b);
+  const int lb = b - cblock_off[e];
+  const int cnt = count[e];
+  if (lb * kCompactBlock >= cnt) return;
+  const long long base = cap_off[e];
+  const double* __restrict__ sp = src_pts[e];
+  const double* __restrict__ dp = dst_pts[e];
+  const double* __restrict__ dn = dst_nor[e];
+  for (int i = 0; i < IPT; ++i) {
+    const int pos = lb * kCompactBlock + i * NT + threadIdx.x;
+    if (pos >= cnt) break;
+    const size_t f = (size_t)first[base + pos], s = (size_t)second[base + pos];
+    const size_t o = (size_t)(base + pos);
+    stream[0 * total_cap + o] = sp[3 * f];
+    stream[1 * total_cap + o] = sp[3 * f + 1];
+    stream[2 * total_cap + o] = sp[3 * f + 2];
+    stream[3 * total_cap + o] = dp[3 * s];
+    stream[4 * total_cap + o] = dp[3 * s + 1];
+    stream[5 * total_cap + o] = dp[3 * s + 2];
+    if (dn != nullptr) {
+      stream[6 * total_cap + o] = dn[3 * s];
+      stream[7 * total_cap + o] = dn[3 * s + 1];
+      stream[8 * total_cap + o] = dn[3 * s + 2];
+    }
+  }
+}
+
+// ---- radix select (8 passes x 8 bits, MSB first) over the fp64 patterns of the accepted d2 ------
+__global__ void select_init_kernel(const int* __restrict__ count, unsigned long long* __restrict__ prefix, int* __restrict__ kth,
+                                   unsigned int* __restrict__ hist, int E) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < E * 256) hist[t] = 0u;
+  if (t < E) { prefix[t] = 0ull; kth[t] = count[t] / 2; }  // dists.begin() + size()/2  (frame.cpp:166)
+}
+
+__global__ __launch_bounds__(NT) void select_hist_kernel(const int* __restrict__ cblock_off, int E, const int* __restrict__ count,
+                                                         const long long* __restrict__ cap_off, const double* __restrict__ cd2,
+                                                         const unsigned long long* __restrict__ prefix, int pass, unsigned int* __restrict__ hist) {
+  __shared__ unsigned int lh[256];
+  const int b = blockIdx.x;
+  const int e = find_edge(cblock_off, E, b);
+  const int lb = b - cblock_off[e];
+  const int cnt = count[e];
+  if (lb * kCompactBlock >= cnt) return;
+  lh[threadIdx.x] = 0u;
+  __syncthreads();
+  const long long base = cap_off[e];
+  const unsigned long long pre = prefix[e];
+  const int shift = 8 * pass;
+  for (int i = 0; i < IPT; ++i) {
+    const int pos = lb * kCompactBlock + i * NT + threadIdx.x;
+    if (pos < cnt) {
+      const unsigned long long key = (unsigned long long)__double_as_longlong(cd2[base + pos]);
+      const bool match = (pass == 7) || ((key >> (shift + 8)) == (pre >> (shift + 8)));
+      if (match) atomicAdd(&lh[(key >> shift) & 255ull], 1u);
+    }
+  }
+  __syncthreads();
+  const unsigned int v = lh[threadIdx.x];
+  if (v) atomicAdd(&hist[e * 256 + threadIdx.x], v);
+}
+
+__global__ __launch_bounds__(256) void select_pick_kernel(unsigned long long* __restrict__ prefix, int* __restrict__ kth,
+                                                          unsigned int* __restrict__ hist, const int* __restrict__ count, int pass,
+                                                          double* __restrict__ median) {
+  __shared__ unsigned int sh[256];
+  const int e = blockIdx.x;
+  sh[threadIdx.x] = hist[e * 256 + threadIdx.x];
+  hist[e * 256 + threadIdx.x] = 0u;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (count[e] > 0) {
+      unsigned int k = (unsigned int)kth[e], cum = 0;
+      int bin = 255;
+      for (int i = 0; i < 256; ++i) {
+        if (cum + sh[i] > k) { bin = i; break; }
+        cum += sh[i];
+      }
+      const unsigned long long p = prefix[e] | ((unsigned long long)bin << (8 * pass));
+      prefix[e] = p;
+      kth[e] = (int)(k - cum);
+      if (pass == 0) median[e] = __longlong_as_double((long long)p);
+    } else if (pass == 0) {
+      median[e] = 0.0;
+    }
+  }
+}
+
+}  // namespace
+
+int launch_compact(mvicp_ctx* c, double d2_bound) {
+  if (c->n_cblocks == 0) return MVICP_OK;
+  double bytes = 0;
+  for (int e = 0; e < c->E; ++e) if (c->owned[e]) bytes += 2.0 * 12.0 * c->frames[c->esrc[e]].n;
+  ProfScope ps(c, "compact", bytes);
+  hipLaunchKernelGGL(count_kernel, dim3(c->n_cblocks), dim3(NT), 0, c->stream, c->d_cblock_off, c->E, c->d_nsrc, c->d_cap_off, c->d_nn_idx,
+                     c->d_nn_d2, d2_bound, c->d_cblock_cnt);
+  hipLaunchKernelGGL(scan_kernel, dim3(c->E), dim3(NT), 0, c->stream, c->d_cblock_off, c->d_cblock_cnt, c->d_count);
+  hipLaunchKernelGGL(scatter_kernel, dim3(c->n_cblocks), dim3(NT), 0, c->stream, c->d_cblock_off, c->E, c->d_nsrc, c->d_cap_off, c->d_nn_idx,
+                     c->d_nn_d2, d2_bound, c->d_cblock_cnt, c->d_first, c->d_second, c->d_cd2);
+  MV_HIP(hipGetLastError());
+  return MVICP_OK;
+}
+
+int launch_gather_stream(mvicp_ctx* c) {
+  if (c->n_cblocks == 0) return MVICP_OK;
+  // per-edge base pointers (device table lives in the pinned staging area's device twin: small, rebuilt per call)
+  std::vector<const double*> tab(3 * (size_t)c->E, nullptr);
+  for (int e = 0; e < c->E; ++e) {
+    tab[e] = c->frames[c->esrc[e]].pts;
+    tab[c->E + e] = c->frames[c->edst[e]].pts;
+    tab[2 * c->E + e] = c->frames[c->edst[e]].nor;
+  }
+  const double** d_tab = nullptr;
+  scratch_reset(c);
+  MV_CHECK(scratch_upload(c, tab.data(), sizeof(double*) * tab.size(), (void**)&d_tab));
+  {
+    ProfScope ps(c, "gather", 0.0);
+    hipLaunchKernelGGL(gather_kernel, dim3(c->n_cblocks), dim3(NT), 0, c->stream, c->d_cblock_off, c->E, c->d_count, c->d_cap_off, c->total_cap,
+                       c->d_first, c->d_second, d_tab, d_tab + c->E, d_tab + 2 * c->E, c->d_stream);
+  }
+  MV_HIP(hipGetLastError());
+  return MVICP_OK;
+}
+
+int launch_select_median(mvicp_ctx* c) {
+  if (c->n_cblocks == 0 || c->E == 0) return MVICP_OK;
+  ProfScope ps(c, "select", 0.0);
+  hipLaunchKernelGGL(select_init_kernel, dim3((c->E * 256 + 255) / 256), dim3(256), 0, c->stream, c->d_count, c->d_sel_prefix, c->d_sel_k,
+                     c->d_sel_hist, c->E);
+  for (int pass = 7; pass >= 0; --pass) {
+    hipLaunchKernelGGL(select_hist_kernel, dim3(c->n_cblocks), dim3(NT), 0, c->stream, c->d_cblock_off, c->E, c->d_count, c->d_cap_off, c->d_cd2,
+                       c->d_sel_prefix, pass, c->d_sel_hist);
+    hipLaunchKernelGGL(select_pick_kernel, dim3(c->E), dim3(256), 0, c->stream, c->d_sel_prefix, c->d_sel_k, c->d_sel_hist, c->d_count, pass,
+                       c->d_median);
+  }
+  MV_HIP(hipGetLastError());
+  return MVICP_OK;
+}
+
+}  // namespace mvicp

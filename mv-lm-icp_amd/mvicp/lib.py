@@ -1,0 +1,262 @@
+"""ctypes binding of include/mvicp.h.  No compute happens here; every call goes through the C ABI."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libmvicp_hip.so")
+
+PARAM_EIGEN_QUATERNION, PARAM_ANGLE_AXIS, PARAM_SOPHUS_SE3 = 0, 1, 2
+NN_AUTO, NN_BRUTE, NN_GRID = 0, 1, 2
+EDGE_BLOCK = 91
+
+SYMBOLS = [
+    "mvicp_last_error", "mvicp_version", "mvicp_create", "mvicp_destroy", "mvicp_set_num_frames", "mvicp_set_frame",
+    "mvicp_set_graph", "mvicp_set_shard", "mvicp_edge_owner", "mvicp_comm_unique_id", "mvicp_comm_init", "mvicp_correspond",
+    "mvicp_get_correspondences", "mvicp_set_correspondences", "mvicp_nn_query", "mvicp_linearize", "mvicp_optimize",
+    "mvicp_lm_solve", "mvicp_profile_enable", "mvicp_profile_reset", "mvicp_profile_get", "mvicp_stream", "mvicp_sync",
+]
+
+
+class MvicpError(RuntimeError):
+    pass
+
+
+class Summary(C.Structure):
+    _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double), ("iterations", C.c_int), ("successful_steps", C.c_int),
+                ("termination", C.c_int), ("evaluations", C.c_int)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double))
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load libmvicp_hip.so (fails loudly if it has not been built: there is no Python/CPU fallback)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise MvicpError(f"{p} not found: build it with `make -C mv-lm-icp_amd` (or __graft_entry__.build())")
+    lib = C.CDLL(p, mode=C.RTLD_GLOBAL)
+    vp, ip, dp, fp, u8p = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_ubyte)
+    lib.mvicp_last_error.restype = C.c_char_p
+    lib.mvicp_version.restype = C.c_char_p
+    lib.mvicp_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.mvicp_destroy.argtypes = [vp]
+    lib.mvicp_set_num_frames.argtypes = [vp, C.c_int]
+    lib.mvicp_set_frame.argtypes = [vp, C.c_int, dp, dp, C.c_int]
+    lib.mvicp_set_graph.argtypes = [vp, C.c_int, ip, ip]
+    lib.mvicp_set_shard.argtypes = [vp, C.c_int, C.c_int]
+    lib.mvicp_edge_owner.argtypes = [C.c_int, ip, C.c_int, ip]
+    lib.mvicp_comm_unique_id.argtypes = [C.c_char_p, vp]
+    lib.mvicp_comm_init.argtypes = [vp, C.c_char_p, vp, C.c_int, C.c_int]
+    lib.mvicp_correspond.argtypes = [vp, dp, u8p, C.c_float, C.c_int, ip, fp]
+    lib.mvicp_get_correspondences.argtypes = [vp, C.c_int, C.c_int, ip, ip, dp]
+    lib.mvicp_set_correspondences.argtypes = [vp, C.c_int, C.c_int, ip, ip, C.c_float]
+    lib.mvicp_nn_query.argtypes = [vp, C.c_int, dp, C.c_int, C.c_int, ip, dp]
+    lib.mvicp_linearize.argtypes = [vp, dp, C.c_int, C.c_int, dp]
+    lib.mvicp_optimize.argtypes = [vp, dp, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Summary)]
+    lib.mvicp_lm_solve.argtypes = [C.c_int, C.c_int, ip, ip, dp, u8p, C.c_int, C.c_int, EVAL_FN, vp, C.POINTER(Summary)]
+    lib.mvicp_profile_enable.argtypes = [vp, C.c_int]
+    lib.mvicp_profile_reset.argtypes = [vp]
+    lib.mvicp_profile_get.argtypes = [vp, C.c_char_p, dp, C.POINTER(C.c_longlong), dp]
+    lib.mvicp_stream.argtypes = [vp]
+    lib.mvicp_stream.restype = vp
+    lib.mvicp_sync.argtypes = [vp]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def _check(lib, st):
+    if st < 0:
+        raise MvicpError(f"mvicp status {st}: {lib.mvicp_last_error().decode()}")
+    return st
+
+
+def poses_to_c(poses):
+    """(K,4,4) row-major numpy matrices -> K x 16 column-major doubles (Eigen Isometry3d::data())."""
+    P = np.asarray(poses, dtype=np.float64)
+    return np.ascontiguousarray(np.transpose(P, (0, 2, 1)).reshape(len(P), 16))
+
+
+def poses_from_c(buf):
+    return np.ascontiguousarray(np.transpose(np.asarray(buf, dtype=np.float64).reshape(-1, 4, 4), (0, 2, 1)))
+
+
+def edge_owner(n_src, world):
+    lib = load_library()
+    n_src = np.ascontiguousarray(n_src, dtype=np.int32)
+    owner = np.zeros(len(n_src), dtype=np.int32)
+    _check(lib, lib.mvicp_edge_owner(len(n_src), _ip(n_src), world, _ip(owner)))
+    return owner
+
+
+def lm_solve_host(n_frames, src, dst, poses, fixed, param, eval_callback, max_iterations=50):
+    """mvicp_lm_solve with a Python evaluator: eval_callback(poses(K,4,4)) -> blocks (E,91).  Host only."""
+    lib = load_library()
+    src = np.ascontiguousarray(src, dtype=np.int32)
+    dst = np.ascontiguousarray(dst, dtype=np.int32)
+    E = len(src)
+    P = poses_to_c(poses)
+    fx = np.ascontiguousarray(fixed, dtype=np.uint8).copy()
+    err = []
+
+    def _cb(_user, p_ptr, b_ptr):
+        try:
+            pp = np.ctypeslib.as_array(p_ptr, shape=(n_frames, 16)).copy()
+            blocks = np.asarray(eval_callback(poses_from_c(pp)), dtype=np.float64).reshape(E, EDGE_BLOCK)
+            np.ctypeslib.as_array(b_ptr, shape=(E, EDGE_BLOCK))[:] = blocks
+            return 0
+        except Exception as ex:  # pragma: no cover - surfaced below
+            err.append(ex)
+            return -1
+
+    sm = Summary()
+    cb = EVAL_FN(_cb)
+    st = lib.mvicp_lm_solve(n_frames, E, _ip(src), _ip(dst), _dp(P), fx.ctypes.data_as(C.POINTER(C.c_ubyte)), param, max_iterations, cb, None, C.byref(sm))
+    if err:
+        raise err[0]
+    _check(lib, st)
+    return poses_from_c(P), sm.as_dict()
+
+
+class Engine:
+    """One GPU context.  Mirrors the reference loop: set_frames -> set_graph -> (correspond -> optimize)*."""
+
+    def __init__(self, device=0, rank=0, world=1):
+        self.lib = load_library()
+        h = C.c_void_p()
+        _check(self.lib, self.lib.mvicp_create(device, C.byref(h)))
+        self.h = h
+        self.n_frames = 0
+        self.E = 0
+        self.rank, self.world = rank, world
+        if world > 1:
+            _check(self.lib, self.lib.mvicp_set_shard(self.h, rank, world))
+
+    def close(self):
+        if self.h:
+            self.lib.mvicp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- uploads
+    def set_frames(self, pts_list, nor_list=None):
+        self.n_frames = len(pts_list)
+        _check(self.lib, self.lib.mvicp_set_num_frames(self.h, self.n_frames))
+        self.npts = []
+        for i, p in enumerate(pts_list):
+            p = np.ascontiguousarray(p, dtype=np.float64)
+            n = None if nor_list is None or nor_list[i] is None else np.ascontiguousarray(nor_list[i], dtype=np.float64)
+            _check(self.lib, self.lib.mvicp_set_frame(self.h, i, _dp(p), _dp(n) if n is not None else None, len(p)))
+            self.npts.append(len(p))
+
+    def set_graph(self, src, dst):
+        self.src = np.ascontiguousarray(src, dtype=np.int32)
+        self.dst = np.ascontiguousarray(dst, dtype=np.int32)
+        self.E = len(self.src)
+        _check(self.lib, self.lib.mvicp_set_graph(self.h, self.E, _ip(self.src), _ip(self.dst)))
+
+    def comm_init(self, unique_id, librccl_path=None):
+        buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
+        path = librccl_path.encode() if librccl_path else None
+        _check(self.lib, self.lib.mvicp_comm_init(self.h, path, C.cast(buf, C.c_void_p), self.rank, self.world))
+
+    @staticmethod
+    def comm_unique_id(librccl_path=None):
+        lib = load_library()
+        buf = (C.c_char * 128)()
+        path = librccl_path.encode() if librccl_path else None
+        _check(lib, lib.mvicp_comm_unique_id(path, C.cast(buf, C.c_void_p)))
+        return bytes(buf)
+
+    # ---- S1
+    def correspond(self, poses, fixed, thresh, nn_method=NN_AUTO):
+        P = poses_to_c(poses)
+        fx = np.ascontiguousarray(fixed, dtype=np.uint8)
+        counts = np.zeros(self.E, dtype=np.int32)
+        weights = np.zeros(self.E, dtype=np.float32)
+        _check(self.lib, self.lib.mvicp_correspond(self.h, _dp(P), fx.ctypes.data_as(C.POINTER(C.c_ubyte)), np.float32(thresh), nn_method,
+                                                   _ip(counts), weights.ctypes.data_as(C.POINTER(C.c_float))))
+        self.counts = counts
+        return counts, weights
+
+    def get_correspondences(self, edge):
+        cap = self.npts[self.src[edge]]
+        first = np.zeros(cap, dtype=np.int32)
+        second = np.zeros(cap, dtype=np.int32)
+        dist = np.zeros(cap, dtype=np.float64)
+        n = _check(self.lib, self.lib.mvicp_get_correspondences(self.h, edge, cap, _ip(first), _ip(second), _dp(dist)))
+        return first[:n].copy(), second[:n].copy(), dist[:n].copy()
+
+    def set_correspondences(self, edge, first, second, weight=0.0):
+        first = np.ascontiguousarray(first, dtype=np.int32)
+        second = np.ascontiguousarray(second, dtype=np.int32)
+        _check(self.lib, self.lib.mvicp_set_correspondences(self.h, edge, len(first), _ip(first), _ip(second), np.float32(weight)))
+
+    def nn_query(self, frame, queries, nn_method=NN_AUTO):
+        q = np.ascontiguousarray(queries, dtype=np.float64)
+        idx = np.zeros(len(q), dtype=np.int32)
+        d2 = np.zeros(len(q), dtype=np.float64)
+        _check(self.lib, self.lib.mvicp_nn_query(self.h, frame, _dp(q), len(q), nn_method, _ip(idx), _dp(d2)))
+        return idx, d2
+
+    # ---- normal equations / S2
+    def linearize(self, poses, point_to_plane, robust):
+        P = poses_to_c(poses)
+        out = np.zeros((self.E, EDGE_BLOCK), dtype=np.float64)
+        _check(self.lib, self.lib.mvicp_linearize(self.h, _dp(P), int(point_to_plane), int(robust), _dp(out)))
+        return out
+
+    def optimize(self, poses, fixed, param=PARAM_SOPHUS_SE3, point_to_plane=True, robust=True, max_iterations=50):
+        P = poses_to_c(poses)
+        fx = np.ascontiguousarray(fixed, dtype=np.uint8).copy()
+        sm = Summary()
+        _check(self.lib, self.lib.mvicp_optimize(self.h, _dp(P), fx.ctypes.data_as(C.POINTER(C.c_ubyte)), param, int(point_to_plane), int(robust),
+                                                 max_iterations, C.byref(sm)))
+        return poses_from_c(P), sm.as_dict()
+
+    # ---- profiling
+    def profile(self, on=True):
+        _check(self.lib, self.lib.mvicp_profile_enable(self.h, int(on)))
+
+    def profile_reset(self):
+        _check(self.lib, self.lib.mvicp_profile_reset(self.h))
+
+    def profile_get(self, kernel):
+        ms, n, b = C.c_double(), C.c_longlong(), C.c_double()
+        _check(self.lib, self.lib.mvicp_profile_get(self.h, kernel.encode(), C.byref(ms), C.byref(n), C.byref(b)))
+        return ms.value, n.value, b.value
+
+    def sync(self):
+        _check(self.lib, self.lib.mvicp_sync(self.h))
+
+
+def unpack_block(b):
+    """91 -> (H 12x12 symmetric, g 12, cost)."""
+    H = np.zeros((12, 12))
+    iu = np.triu_indices(12)
+    H[iu] = b[:78]
+    H = H + np.triu(H, 1).T
+    return H, np.array(b[78:90]), float(b[90])
