@@ -126,6 +126,13 @@ typedef int (*mvicp_eval_fn)(void* user, const double* poses, double* blocks);
 int mvicp_lm_solve(int n_frames, int n_edges, const int* src, const int* dst, double* poses, unsigned char* fixed, int param,
                    int max_iterations, mvicp_eval_fn eval, void* user, mvicp_summary* summary);
 
+/* Tuning / test switches.  "nn_tree_only" (0/1): skip the hash-grid fast path and answer every query with the
+ * exact AABB-tree descent (same results; used by the parity tests to exercise the fallback on every query). */
+int mvicp_set_option(mvicp_ctx* ctx, const char* name, double value);
+/* NN census accumulated while profiling is enabled: out[0..3] = queries, candidate points examined,
+ * tree nodes tested, queries that needed the tree fallback. */
+int mvicp_nn_census(mvicp_ctx* ctx, double* out4);
+
 /* ---- profiling (HIP events on the library's own stream) ------------------------------------------ */
 int mvicp_profile_enable(mvicp_ctx* ctx, int on);
 int mvicp_profile_reset(mvicp_ctx* ctx);

@@ -481,6 +481,20 @@ int mvicp_linearize(mvicp_ctx* c, const double* poses, int point_to_plane, int r
   return MVICP_OK;
 }
 
+int mvicp_set_option(mvicp_ctx* c, const char* name, double value) {
+  MV_CHECK(bind(c));
+  if (!name) { set_error("null option name"); return MVICP_ERR_ARG; }
+  if (std::strcmp(name, "nn_tree_only") == 0) { c->nn_tree_only = value != 0.0; return MVICP_OK; }
+  set_error("unknown option '%s'", name);
+  return MVICP_ERR_ARG;
+}
+int mvicp_nn_census(mvicp_ctx* c, double* out4) {
+  MV_CHECK(bind(c));
+  if (!out4) { set_error("null output"); return MVICP_ERR_ARG; }
+  out4[0] = c->nn_queries; out4[1] = c->nn_candidates; out4[2] = c->nn_nodes; out4[3] = c->nn_far;
+  return MVICP_OK;
+}
+
 int mvicp_profile_enable(mvicp_ctx* c, int on) {
   MV_CHECK(bind(c));
   c->profile = on != 0;
@@ -491,6 +505,7 @@ int mvicp_profile_reset(mvicp_ctx* c) {
   MV_HIP(hipStreamSynchronize(c->stream));
   prof_collect(c);
   for (auto& kv : c->prof) { kv.second.ms = 0; kv.second.launches = 0; kv.second.bytes = 0; }
+  c->nn_candidates = c->nn_nodes = c->nn_far = c->nn_queries = 0;
   return MVICP_OK;
 }
 int mvicp_profile_get(mvicp_ctx* c, const char* kernel, double* total_ms, long long* launches, double* alg_bytes) {

@@ -40,14 +40,14 @@ struct GridDev {
   int dims[3] = {0, 0, 0};
   double origin[3] = {0, 0, 0};
   double cell = 0.0, inv_cell = 0.0;
-  int n_cells = 0;
-  int* cell_start = nullptr;  // n_cells + 1
-  double* spts = nullptr;     // n x 3 sorted by cell
-  int* sidx = nullptr;        // n: original index of sorted point
-  // left-balanced KD-tree for far queries (host built)
-  double* kd_pts = nullptr;   // n x 3 in tree order
-  int* kd_idx = nullptr;      // n original indices
-  signed char* kd_dim = nullptr;  // split dimension per node
+  int n_cells = 0;             // occupied cells
+  double* spts = nullptr;      // n x 3 sorted by Morton(cell)
+  int* sidx = nullptr;         // n: original index of sorted point
+  void* table = nullptr;       // open-addressing hash: cell -> (start, count), 16-B entries
+  unsigned int table_mask = 0; int table_shift = 0;
+  float* bvh = nullptr;        // implicit complete AABB tree, 6 floats per node (outward rounded)
+  int depth = 0;
+  double struct_bytes = 0.0;
 };
 
 struct FrameDev {
@@ -124,6 +124,10 @@ struct mvicp_ctx {
   // comm
   mvicp::RcclApi* rccl = nullptr;
   void* comm = nullptr;
+
+  // options / NN census (profiling only)
+  bool nn_tree_only = false;
+  double nn_candidates = 0, nn_nodes = 0, nn_far = 0, nn_queries = 0;
 
   // profiling
   bool profile = false;

@@ -1,23 +1,441 @@
-// K2 — spatial-hash (uniform grid) exact NN.  (placeholder TU: structure build + kernels land next)
+// K2 — spatial-hash exact 1-NN with an exact hierarchical fallback (the production NN path).
+//
+// Replaces nanoflann's KD-tree (include/nanoflann.hpp:859-867 build, :900-911/:1199-1247 search) behind
+// Frame::getClosestPoint (src/internal/frame.cpp:187-206) and the per-query transform of
+// Frame::computeClosestPointsToNeighbours (frame.cpp:117-118,131,136).  Same bit-exact contract as K1:
+// fp64 distance d0*d0+d1*d1+d2*d2 left to right, no fma (include/frame.h:70-76), lowest original index
+// wins exact ties — independent of traversal order because every comparison is the total order
+// (d2, index).
+//
+// Per cloud, built ONCE at upload (clouds are static in their local frame, like the reference's lazily
+// built tree, frame.cpp:188-193):
+//   * points sorted by the Morton code of their grid cell (cell edge h ~ a few point spacings);
+//     `spts` (sorted xyz) + `sidx` (original index).  The sorted order is also the QUERY order of a source
+//     cloud: neighbouring lanes ask about neighbouring places, so hash slots / point runs / tree nodes are
+//     shared inside a wave and stay in L2.
+//   * an open-addressing hash table  cell -> (start, count)  (16-B entries, <= 50 % load): the spatial hash.
+//   * an implicit complete binary tree over the sorted array (leaf j = points [j n / 2^D, (j+1) n / 2^D),
+//     4..8 points) with float AABBs rounded OUTWARD per node, heap-indexed: no pointers.
+// Query = (1) scan the 2x2x2 cell block around the query through the hash; the best candidate is provably
+// the global NN iff it is closer than the distance to the block's faces (>= h/2); (2) otherwise an exact
+// branch-and-bound descent of the AABB tree seeded with that candidate (or with the cutoff bound: matches
+// at or beyond the cutoff are discarded by frame.cpp:156 anyway, so nothing beyond it needs resolving).
+// Pruning is exact in floating point: the box lower bound is evaluated with the SAME rounded operations as
+// the point distance, and every rounding is monotone, so lb <= d2 for every point in the box; nodes are
+// skipped only when lb > best (ties are still visited for the index rule).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <unordered_set>
+
 #include "common.h"
 
 namespace mvicp {
 
-int build_grid(mvicp_ctx* c, FrameDev& f, const double* h_xyz) {
-  (void)c; (void)h_xyz;
-  f.has_grid = false;
+namespace {
+
+constexpr int NT = 256;
+constexpr int MAXD = 24;
+constexpr unsigned long long EMPTY = ~0ull;
+
+struct HashEntry { unsigned long long key; unsigned int start, count; };
+
+struct GridView {  // device view of one cloud's structure
+  const double* spts; const int* sidx; int n;
+  const HashEntry* table; unsigned int mask; int shift;
+  double ox, oy, oz, h, inv_h;
+  int dx, dy, dz;
+  const float* bvh; int depth;
+};
+
+struct GridJob {
+  GridView dst;
+  const double* q; const int* qidx;  // queries (sorted source points + their original index) or raw queries (qidx null)
+  const double* xf;                  // kEdgeXf or null
+  int n;
+  int* out_idx; double* out_d2;
+};
+
+__host__ __device__ __forceinline__ unsigned long long cell_key(int ix, int iy, int iz) {
+  return (unsigned long long)ix | ((unsigned long long)iy << 21) | ((unsigned long long)iz << 42);
+}
+__host__ __device__ __forceinline__ unsigned int hash_slot(unsigned long long k, int shift) {
+  return (unsigned int)((k * 0x9E3779B97F4A7C15ull) >> shift);
+}
+
+__device__ __forceinline__ void xf_point(const double* __restrict__ x, double p0, double p1, double p2, double& q0, double& q1, double& q2) {
+  double g[3], u[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    g[i] = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(x[i], p0), __dmul_rn(x[i + 3], p1)), __dmul_rn(x[i + 6], p2)), x[9 + i]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) u[i] = __dsub_rn(g[i], x[21 + i]);
+  q0 = __dadd_rn(__dadd_rn(__dmul_rn(x[12 + 0], u[0]), __dmul_rn(x[12 + 3], u[1])), __dmul_rn(x[12 + 6], u[2]));
+  q1 = __dadd_rn(__dadd_rn(__dmul_rn(x[12 + 1], u[0]), __dmul_rn(x[12 + 4], u[1])), __dmul_rn(x[12 + 7], u[2]));
+  q2 = __dadd_rn(__dadd_rn(__dmul_rn(x[12 + 2], u[0]), __dmul_rn(x[12 + 5], u[1])), __dmul_rn(x[12 + 8], u[2]));
+}
+
+__device__ __forceinline__ double dist2(double qx, double qy, double qz, double x, double y, double z) {
+  const double d0 = __dsub_rn(qx, x), d1 = __dsub_rn(qy, y), d2 = __dsub_rn(qz, z);
+  return __dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2));
+}
+
+// exact-order lower bound of dist2(q, p) over all p in the (outward rounded) box
+__device__ __forceinline__ double box_lb(double qx, double qy, double qz, const float* __restrict__ b) {
+  const double g0 = fmax(fmax(__dsub_rn((double)b[0], qx), __dsub_rn(qx, (double)b[3])), 0.0);
+  const double g1 = fmax(fmax(__dsub_rn((double)b[1], qy), __dsub_rn(qy, (double)b[4])), 0.0);
+  const double g2 = fmax(fmax(__dsub_rn((double)b[2], qz), __dsub_rn(qz, (double)b[5])), 0.0);
+  return __dadd_rn(__dadd_rn(__dmul_rn(g0, g0), __dmul_rn(g1, g1)), __dmul_rn(g2, g2));
+}
+
+__device__ __forceinline__ void scan_range(const GridView& g, int lo, int hi, double qx, double qy, double qz, double& best, int& bi) {
+  for (int j = lo; j < hi; ++j) {
+    const double* p = g.spts + 3 * (size_t)j;
+    const double d = dist2(qx, qy, qz, p[0], p[1], p[2]);
+    if (d <= best) {
+      const int oi = g.sidx[j];
+      if (d < best || oi < bi) { best = d; bi = oi; }
+    }
+  }
+}
+
+template <bool TREE_ONLY>
+__global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__ jobs, double bound, unsigned long long* __restrict__ stats) {
+  __shared__ int s_stack[MAXD + 1][NT];
+  __shared__ double sxf[kEdgeXf];
+  const GridJob& job = jobs[blockIdx.y];
+  const int i = blockIdx.x * NT + threadIdx.x;
+  if (blockIdx.x * NT >= job.n) return;
+  const bool has_xf = job.xf != nullptr;
+  if (has_xf && threadIdx.x < kEdgeXf) sxf[threadIdx.x] = job.xf[threadIdx.x];
+  __syncthreads();
+  if (i >= job.n) return;
+  const GridView& g = job.dst;
+
+  double qx, qy, qz;
+  {
+    const double p0 = job.q[3 * (size_t)i], p1 = job.q[3 * (size_t)i + 1], p2 = job.q[3 * (size_t)i + 2];
+    if (has_xf) xf_point(sxf, p0, p1, p2, qx, qy, qz);
+    else { qx = p0; qy = p1; qz = p2; }
+  }
+  const int out = job.qidx ? job.qidx[i] : i;
+
+  double best = bound;      // nothing at or beyond the cutoff bound needs resolving (frame.cpp:156)
+  int bi = 0x7fffffff;
+  bool resolved = false;
+  unsigned int n_cand = 0, n_nodes = 0;
+
+  if (!TREE_ONLY) {
+    // ---- (1) 2x2x2 block of cells nearest to the query, through the spatial hash
+    const double cx = (qx - g.ox) * g.inv_h - 0.5, cy = (qy - g.oy) * g.inv_h - 0.5, cz = (qz - g.oz) * g.inv_h - 0.5;
+    // queries far outside the grid cannot be resolved by the block test; clamp so the int conversion is safe
+    const double lim = 2.0e6;
+    const int bx = (int)floor(fmin(fmax(cx, -lim), lim)), by = (int)floor(fmin(fmax(cy, -lim), lim)), bz = (int)floor(fmin(fmax(cz, -lim), lim));
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int ix = bx + (c & 1), iy = by + ((c >> 1) & 1), iz = bz + (c >> 2);
+      if (ix < 0 || iy < 0 || iz < 0 || ix >= g.dx || iy >= g.dy || iz >= g.dz) continue;
+      const unsigned long long key = cell_key(ix, iy, iz);
+      unsigned int slot = hash_slot(key, g.shift);
+      while (true) {
+        const HashEntry e = g.table[slot];
+        if (e.key == key) {
+          scan_range(g, (int)e.start, (int)(e.start + e.count), qx, qy, qz, best, bi);
+          n_cand += e.count;
+          break;
+        }
+        if (e.key == EMPTY) break;
+        slot = (slot + 1) & g.mask;
+      }
+    }
+    // every point outside the block differs from q by at least `m` along some axis (cells are assigned with
+    // the same rounded expression; 0.1 % slack dwarfs any rounding in it)
+    const double fx = g.ox + bx * g.h, fy = g.oy + by * g.h, fz = g.oz + bz * g.h;
+    double m = fmin(fmin(qx - fx, fx + 2.0 * g.h - qx), fmin(fmin(qy - fy, fy + 2.0 * g.h - qy), fmin(qz - fz, fz + 2.0 * g.h - qz)));
+    m *= 0.999;
+    resolved = (m > 0.0) && (best < m * m) && (bi != 0x7fffffff);
+  }
+
+  if (!resolved) {
+    // ---- (2) exact branch-and-bound over the implicit AABB tree, seeded with the current best
+    const int D = g.depth;
+    int sp = 0;
+    s_stack[sp++][threadIdx.x] = 0;
+    while (sp > 0) {
+      int id = s_stack[--sp][threadIdx.x];
+      double lb = box_lb(qx, qy, qz, g.bvh + 6 * (size_t)id);
+      ++n_nodes;
+      if (lb > best) continue;
+      while (true) {
+        const int level = 31 - __clz(id + 1);
+        if (level == D) {
+          const long long j = (long long)id - ((1ll << D) - 1);
+          const int lo = (int)((j * g.n) >> D), hi = (int)(((j + 1) * g.n) >> D);
+          scan_range(g, lo, hi, qx, qy, qz, best, bi);
+          n_cand += (unsigned)(hi - lo);
+          break;
+        }
+        const int c0 = 2 * id + 1, c1 = c0 + 1;
+        const double l0 = box_lb(qx, qy, qz, g.bvh + 6 * (size_t)c0);
+        const double l1 = box_lb(qx, qy, qz, g.bvh + 6 * (size_t)c1);
+        n_nodes += 2;
+        const bool first0 = l0 <= l1;
+        const int nearc = first0 ? c0 : c1, farc = first0 ? c1 : c0;
+        const double ln = first0 ? l0 : l1, lf = first0 ? l1 : l0;
+        if (lf <= best) s_stack[sp++][threadIdx.x] = farc;
+        if (ln > best) break;
+        id = nearc;
+      }
+    }
+  }
+  if (bi == 0x7fffffff) bi = -1;
+  job.out_idx[out] = bi;
+  job.out_d2[out] = best;
+  if (stats) {
+    // candidate / node census for the algorithmic-byte model; wave-aggregated atomics
+    unsigned long long c = n_cand, nd = n_nodes, far = resolved ? 0 : 1;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { c += __shfl_xor(c, d, 64); nd += __shfl_xor(nd, d, 64); far += __shfl_xor(far, d, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[0], c); atomicAdd(&stats[1], nd); atomicAdd(&stats[2], far); }
+  }
+}
+
+// ---------------------------------------------------------------------------------------- host build
+inline unsigned long long morton3(unsigned int x, unsigned int y, unsigned int z) {
+  auto spread = [](unsigned long long v) {
+    v &= 0x1fffffull;
+    v = (v | v << 32) & 0x1f00000000ffffull;
+    v = (v | v << 16) & 0x1f0000ff0000ffull;
+    v = (v | v << 8) & 0x100f00f00f00f00full;
+    v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+    v = (v | v << 2) & 0x1249249249249249ull;
+    return v;
+  };
+  return spread(x) | (spread(y) << 1) | (spread(z) << 2);
+}
+
+struct HostGrid {
+  double o[3], h, inv_h;
+  int d[3];
+};
+
+inline void cell_of(const HostGrid& g, const double* p, int* c) {
+  for (int a = 0; a < 3; ++a) {
+    int v = (int)std::floor((p[a] - g.o[a]) * g.inv_h);
+    c[a] = std::min(std::max(v, 0), g.d[a] - 1);
+  }
+}
+
+size_t occupied_cells(const HostGrid& g, const double* xyz, int n, int stride) {
+  std::unordered_set<unsigned long long> s;
+  s.reserve((size_t)n / stride + 16);
+  int c[3];
+  for (int i = 0; i < n; i += stride) { cell_of(g, xyz + 3 * (size_t)i, c); s.insert(cell_key(c[0], c[1], c[2])); }
+  return s.size();
+}
+
+void make_grid(HostGrid& g, const double* lo, const double* hi, double h) {
+  g.h = h; g.inv_h = 1.0 / h;
+  for (int a = 0; a < 3; ++a) {
+    g.o[a] = lo[a] - 0.01 * h;
+    g.d[a] = std::max(1, (int)std::ceil((hi[a] - g.o[a]) * g.inv_h + 0.01) + 1);
+    g.d[a] = std::min(g.d[a], (1 << 21) - 1);
+  }
+}
+
+}  // namespace
+
+int build_grid(mvicp_ctx* c, FrameDev& f, const double* xyz) {
+  (void)c;
+  const int n = f.n;
+  GridDev& G = f.grid;
+  double lo[3] = {xyz[0], xyz[1], xyz[2]}, hi[3] = {xyz[0], xyz[1], xyz[2]};
+  for (int i = 1; i < n; ++i)
+    for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], xyz[3 * (size_t)i + a]); hi[a] = std::max(hi[a], xyz[3 * (size_t)i + a]); }
+  for (int i = 0; i < 3 * n; ++i)
+    if (!std::isfinite(xyz[i])) { set_error("non-finite coordinate in cloud"); return MVICP_ERR_ARG; }
+  double ext = std::max(std::max(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
+  if (!(ext > 0.0)) ext = 1.0;
+  // cell edge: aim at ~6 points per occupied cell.  Measure occupancy at two resolutions (the cloud is a surface,
+  // so occupied(h) ~ h^-dim with dim ~ 2), extrapolate, verify once.
+  const double target = 6.0;
+  double h = ext / std::max(2.0, std::cbrt((double)n));
+  HostGrid g;
+  if (n > 64) {
+    make_grid(g, lo, hi, h);
+    const double occ1 = (double)occupied_cells(g, xyz, n, 1);
+    make_grid(g, lo, hi, 2.0 * h);
+    const double occ2 = (double)occupied_cells(g, xyz, n, 1);
+    double dim = std::log(std::max(occ1, 1.0) / std::max(occ2, 1.0)) / std::log(2.0);
+    dim = std::min(3.0, std::max(1.0, dim));
+    const double want = (double)n / target;
+    h = h * std::pow(std::max(occ1, 1.0) / want, 1.0 / dim);
+    h = std::min(std::max(h, ext * 1e-6), ext);
+    for (int it = 0; it < 3; ++it) {
+      make_grid(g, lo, hi, h);
+      const double per = (double)n / (double)occupied_cells(g, xyz, n, 1);
+      if (per < 3.5) h *= std::pow(target / per, 1.0 / dim);
+      else if (per > 12.0) h *= std::pow(target / per, 1.0 / dim);
+      else break;
+    }
+  }
+  make_grid(g, lo, hi, h);
+
+  // sort by (Morton(cell), original index)
+  std::vector<unsigned long long> mkey(n), ckey(n);
+  int cc[3];
+  for (int i = 0; i < n; ++i) {
+    cell_of(g, xyz + 3 * (size_t)i, cc);
+    mkey[i] = morton3((unsigned)cc[0], (unsigned)cc[1], (unsigned)cc[2]);
+    ckey[i] = cell_key(cc[0], cc[1], cc[2]);
+  }
+  std::vector<int> order(n);
+  std::iota(order.begin(), order.end(), 0);
+  std::sort(order.begin(), order.end(), [&](int a, int b) { return mkey[a] != mkey[b] ? mkey[a] < mkey[b] : a < b; });
+  std::vector<double> spts(3 * (size_t)n);
+  for (int i = 0; i < n; ++i) std::memcpy(&spts[3 * (size_t)i], xyz + 3 * (size_t)order[i], 24);
+
+  // hash table of cell runs
+  std::vector<HashEntry> runs;
+  for (int i = 0; i < n;) {
+    int j = i + 1;
+    while (j < n && ckey[order[j]] == ckey[order[i]]) ++j;
+    runs.push_back(HashEntry{ckey[order[i]], (unsigned)i, (unsigned)(j - i)});
+    i = j;
+  }
+  int log2size = 4;
+  while ((1ull << log2size) < 2 * runs.size() + 2) ++log2size;
+  const unsigned int tsize = 1u << log2size, mask = tsize - 1;
+  const int shift = 64 - log2size;
+  std::vector<HashEntry> table(tsize, HashEntry{EMPTY, 0u, 0u});
+  for (const HashEntry& r : runs) {
+    unsigned int s = hash_slot(r.key, shift);
+    while (table[s].key != EMPTY) s = (s + 1) & mask;
+    table[s] = r;
+  }
+
+  // implicit complete AABB tree over the sorted array
+  int D = 0;
+  while (((long long)n + 7) / 8 > (1ll << D)) ++D;
+  if (D > MAXD - 1) { set_error("cloud too large for the NN tree (n=%d)", n); return MVICP_ERR_ARG; }
+  const size_t nodes = (1ull << (D + 1)) - 1;
+  std::vector<float> bvh(6 * nodes);
+  const float finf = std::numeric_limits<float>::infinity();
+  auto down = [](double v) { float f = (float)v; if ((double)f > v) f = std::nextafterf(f, -std::numeric_limits<float>::infinity()); return f; };
+  auto up = [](double v) { float f = (float)v; if ((double)f < v) f = std::nextafterf(f, std::numeric_limits<float>::infinity()); return f; };
+  const size_t leaf0 = (1ull << D) - 1;
+  for (long long j = 0; j < (1ll << D); ++j) {
+    const int a = (int)((j * n) >> D), b = (int)(((j + 1) * n) >> D);
+    float* bx = &bvh[6 * (leaf0 + (size_t)j)];
+    bx[0] = bx[1] = bx[2] = finf; bx[3] = bx[4] = bx[5] = -finf;  // empty leaf: lb = +inf, never visited
+    for (int k = a; k < b; ++k)
+      for (int ax = 0; ax < 3; ++ax) { bx[ax] = std::min(bx[ax], down(spts[3 * (size_t)k + ax])); bx[3 + ax] = std::max(bx[3 + ax], up(spts[3 * (size_t)k + ax])); }
+  }
+  for (long long id = (long long)leaf0 - 1; id >= 0; --id) {
+    const float* l = &bvh[6 * (size_t)(2 * id + 1)];
+    const float* r = &bvh[6 * (size_t)(2 * id + 2)];
+    float* bx = &bvh[6 * (size_t)id];
+    for (int ax = 0; ax < 3; ++ax) { bx[ax] = std::min(l[ax], r[ax]); bx[3 + ax] = std::max(l[3 + ax], r[3 + ax]); }
+  }
+
+  // upload
+  G.dims[0] = g.d[0]; G.dims[1] = g.d[1]; G.dims[2] = g.d[2];
+  G.origin[0] = g.o[0]; G.origin[1] = g.o[1]; G.origin[2] = g.o[2];
+  G.cell = g.h; G.inv_cell = g.inv_h;
+  G.n_cells = (int)runs.size();
+  G.table_mask = mask; G.table_shift = shift; G.depth = D;
+  MV_HIP(hipMalloc((void**)&G.spts, sizeof(double) * 3 * (size_t)n));
+  MV_HIP(hipMalloc((void**)&G.sidx, sizeof(int) * (size_t)n));
+  MV_HIP(hipMalloc((void**)&G.table, sizeof(HashEntry) * (size_t)tsize));
+  MV_HIP(hipMalloc((void**)&G.bvh, sizeof(float) * 6 * nodes));
+  MV_HIP(hipMemcpy(G.spts, spts.data(), sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice));
+  MV_HIP(hipMemcpy(G.sidx, order.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+  MV_HIP(hipMemcpy(G.table, table.data(), sizeof(HashEntry) * (size_t)tsize, hipMemcpyHostToDevice));
+  MV_HIP(hipMemcpy(G.bvh, bvh.data(), sizeof(float) * 6 * nodes, hipMemcpyHostToDevice));
+  G.struct_bytes = sizeof(HashEntry) * (double)tsize + sizeof(float) * 6.0 * nodes;
+  f.has_grid = true;
   return MVICP_OK;
 }
-void free_grid(GridDev& g) { (void)g; }
-int launch_nn_grid_edges(mvicp_ctx* c, double d2_bound) {
-  (void)c; (void)d2_bound;
-  set_error("grid NN not built");
-  return MVICP_ERR_STATE;
+
+void free_grid(GridDev& g) {
+  if (g.spts) (void)hipFree(g.spts);
+  if (g.sidx) (void)hipFree(g.sidx);
+  if (g.table) (void)hipFree(g.table);
+  if (g.bvh) (void)hipFree(g.bvh);
+  g = GridDev();
 }
+
+namespace {
+GridView view_of(const FrameDev& f) {
+  GridView v;
+  const GridDev& g = f.grid;
+  v.spts = g.spts; v.sidx = g.sidx; v.n = f.n;
+  v.table = (const HashEntry*)g.table; v.mask = g.table_mask; v.shift = g.table_shift;
+  v.ox = g.origin[0]; v.oy = g.origin[1]; v.oz = g.origin[2]; v.h = g.cell; v.inv_h = g.inv_cell;
+  v.dx = g.dims[0]; v.dy = g.dims[1]; v.dz = g.dims[2];
+  v.bvh = g.bvh; v.depth = g.depth;
+  return v;
+}
+
+int run(mvicp_ctx* c, const std::vector<GridJob>& jobs, double bound) {
+  if (jobs.empty()) return MVICP_OK;
+  int max_n = 0;
+  double nq = 0;
+  for (const GridJob& j : jobs) { max_n = std::max(max_n, j.n); nq += j.n; }
+  if (max_n == 0) return MVICP_OK;
+  GridJob* d_jobs = nullptr;
+  scratch_reset(c);
+  MV_CHECK(scratch_upload(c, jobs.data(), sizeof(GridJob) * jobs.size(), (void**)&d_jobs));
+  unsigned long long* d_stats = nullptr;
+  if (c->profile) {
+    const unsigned long long z[3] = {0, 0, 0};
+    MV_CHECK(scratch_upload(c, z, sizeof(z), (void**)&d_stats));
+  }
+  {
+    ProfScope ps(c, "nn", (36.0 + (c->nn_tree_only ? 0.0 : 128.0)) * nq);  // query 24 B + result 12 B + 8 hash slots x 16 B; candidate bytes come from the census below
+    if (c->nn_tree_only)
+      hipLaunchKernelGGL((nn_grid_kernel<true>), dim3((max_n + NT - 1) / NT, (unsigned)jobs.size()), dim3(NT), 0, c->stream, d_jobs, bound, d_stats);
+    else
+      hipLaunchKernelGGL((nn_grid_kernel<false>), dim3((max_n + NT - 1) / NT, (unsigned)jobs.size()), dim3(NT), 0, c->stream, d_jobs, bound, d_stats);
+  }
+  MV_HIP(hipGetLastError());
+  if (d_stats) {
+    unsigned long long st[3];
+    MV_HIP(hipMemcpyAsync(st, d_stats, sizeof(st), hipMemcpyDeviceToHost, c->stream));
+    MV_HIP(hipStreamSynchronize(c->stream));
+    ProfEntry& pe = c->prof["nn"];
+    pe.bytes += 28.0 * (double)st[0] + 24.0 * (double)st[1];  // candidates: 24 B xyz + 4 B index; tree nodes: 24 B AABB
+    c->nn_candidates += (double)st[0]; c->nn_nodes += (double)st[1]; c->nn_far += (double)st[2]; c->nn_queries += nq;
+  }
+  return MVICP_OK;
+}
+}  // namespace
+
+int launch_nn_grid_edges(mvicp_ctx* c, double d2_bound) {
+  std::vector<GridJob> jobs;
+  for (int e = 0; e < c->E; ++e) {
+    if (!c->active[e]) continue;
+    const FrameDev& s = c->frames[c->esrc[e]];
+    const FrameDev& d = c->frames[c->edst[e]];
+    if (!s.has_grid || !d.has_grid) { set_error("grid NN needs the per-cloud structure on frames %d and %d", c->esrc[e], c->edst[e]); return MVICP_ERR_STATE; }
+    GridJob j;
+    j.dst = view_of(d);
+    j.q = s.grid.spts; j.qidx = s.grid.sidx; j.xf = c->d_xf + (size_t)e * kEdgeXf; j.n = s.n;
+    j.out_idx = c->d_nn_idx + c->cap_off[e]; j.out_d2 = c->d_nn_d2 + c->cap_off[e];
+    jobs.push_back(j);
+  }
+  return run(c, jobs, d2_bound);
+}
+
 int launch_nn_grid_queries(mvicp_ctx* c, const FrameDev& f, const double* d_q, int n, int* d_idx, double* d_d2) {
-  (void)c; (void)f; (void)d_q; (void)n; (void)d_idx; (void)d_d2;
-  set_error("grid NN not built");
-  return MVICP_ERR_STATE;
+  if (!f.has_grid) { set_error("grid NN structure missing"); return MVICP_ERR_STATE; }
+  std::vector<GridJob> jobs(1);
+  jobs[0].dst = view_of(f);
+  jobs[0].q = d_q; jobs[0].qidx = nullptr; jobs[0].xf = nullptr; jobs[0].n = n;
+  jobs[0].out_idx = d_idx; jobs[0].out_d2 = d_d2;
+  return run(c, jobs, 1.7976931348623157e308);
 }
 
 }  // namespace mvicp

@@ -15,7 +15,7 @@ SYMBOLS = [
     "mvicp_last_error", "mvicp_version", "mvicp_create", "mvicp_destroy", "mvicp_set_num_frames", "mvicp_set_frame",
     "mvicp_set_graph", "mvicp_set_shard", "mvicp_edge_owner", "mvicp_comm_unique_id", "mvicp_comm_init", "mvicp_correspond",
     "mvicp_get_correspondences", "mvicp_set_correspondences", "mvicp_nn_query", "mvicp_linearize", "mvicp_optimize",
-    "mvicp_lm_solve", "mvicp_profile_enable", "mvicp_profile_reset", "mvicp_profile_get", "mvicp_stream", "mvicp_sync",
+    "mvicp_lm_solve", "mvicp_set_option", "mvicp_nn_census", "mvicp_profile_enable", "mvicp_profile_reset", "mvicp_profile_get", "mvicp_stream", "mvicp_sync",
 ]
 
 
@@ -64,6 +64,8 @@ def load_library(path=None):
     lib.mvicp_linearize.argtypes = [vp, dp, C.c_int, C.c_int, dp]
     lib.mvicp_optimize.argtypes = [vp, dp, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Summary)]
     lib.mvicp_lm_solve.argtypes = [C.c_int, C.c_int, ip, ip, dp, u8p, C.c_int, C.c_int, EVAL_FN, vp, C.POINTER(Summary)]
+    lib.mvicp_set_option.argtypes = [vp, C.c_char_p, C.c_double]
+    lib.mvicp_nn_census.argtypes = [vp, dp]
     lib.mvicp_profile_enable.argtypes = [vp, C.c_int]
     lib.mvicp_profile_reset.argtypes = [vp]
     lib.mvicp_profile_get.argtypes = [vp, C.c_char_p, dp, C.POINTER(C.c_longlong), dp]
@@ -236,6 +238,14 @@ class Engine:
         _check(self.lib, self.lib.mvicp_optimize(self.h, _dp(P), fx.ctypes.data_as(C.POINTER(C.c_ubyte)), param, int(point_to_plane), int(robust),
                                                  max_iterations, C.byref(sm)))
         return poses_from_c(P), sm.as_dict()
+
+    def set_option(self, name, value):
+        _check(self.lib, self.lib.mvicp_set_option(self.h, name.encode(), float(value)))
+
+    def nn_census(self):
+        out = np.zeros(4)
+        _check(self.lib, self.lib.mvicp_nn_census(self.h, _dp(out)))
+        return {"queries": out[0], "candidates": out[1], "nodes": out[2], "far": out[3]}
 
     # ---- profiling
     def profile(self, on=True):

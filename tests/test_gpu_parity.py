@@ -1,0 +1,296 @@
+"""-m gpu: the HIP path (through the C ABI) against the oracle and the committed nanoflann goldens.
+Bar: bit-exact for indices, squared distances, distances, counts and float weights; fp64 tolerance (stated per
+test) for the normal equations and poses."""
+import os
+
+import numpy as np
+import pytest
+
+import mvicp
+import orclib
+from mvicp import lib as L
+from mvicp import synth
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "bunny_nn.npz"))
+TREE = 102  # NN_GRID with the hash fast path disabled: every query takes the exact AABB-tree descent
+METHODS = [L.NN_BRUTE, L.NN_GRID, TREE]
+
+
+class _Eng(mvicp.Engine):
+    """Engine whose nn_method accepts TREE (sets the nn_tree_only option around the call)."""
+
+    def _m(self, method):
+        self.set_option("nn_tree_only", 1 if method == TREE else 0)
+        return L.NN_GRID if method == TREE else method
+
+    def nn_query(self, frame, queries, nn_method=L.NN_AUTO):
+        return super().nn_query(frame, queries, self._m(nn_method))
+
+    def correspond(self, poses, fixed, thresh, nn_method=L.NN_AUTO):
+        return super().correspond(poses, fixed, thresh, self._m(nn_method))
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = _Eng(0)
+    yield e
+    e.close()
+
+
+# ---------------------------------------------------------------- S1' / NN
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("tag", ["gt", "noisy"])
+def test_nn_query_matches_nanoflann_golden(eng, method, tag):
+    eng.set_frames([G["dst"]], [G["dst_nor"]])
+    idx, d2 = eng.nn_query(0, G["q_" + tag], method)
+    assert np.array_equal(idx, G["idx_" + tag])
+    assert np.array_equal(d2, G["d2_" + tag])
+
+
+@pytest.mark.parametrize("method", METHODS)
+def test_nn_edge_cases(eng, orc, method):
+    rng = np.random.default_rng(3)
+    dst = rng.uniform(-0.1, 0.1, (777, 3))  # ragged size (not a tile multiple)
+    eng.set_frames([dst], None)
+    q = np.vstack([dst[:40], dst[:40] * 9.0, rng.uniform(-0.3, 0.3, (133, 3)), [[5.0, 5.0, 5.0]]])
+    idx, d2 = eng.nn_query(0, q, method)
+    oi, od = orc.nn_brute(dst, q)
+    assert np.array_equal(idx, oi) and np.array_equal(d2, od)
+    assert np.all(d2[:40] == 0)
+    # single-point cloud, single query
+    eng.set_frames([dst[:1]], None)
+    idx, d2 = eng.nn_query(0, q[:5], method)
+    assert np.all(idx == 0)
+    # empty query batch is a no-op; empty cloud is an error (nanoflann throws: nanoflann.hpp:904)
+    idx, d2 = eng.nn_query(0, np.zeros((0, 3)), method)
+    assert len(idx) == 0
+    eng.set_frames([np.zeros((0, 3))], None)
+    with pytest.raises(mvicp.MvicpError):
+        eng.nn_query(0, q[:5], method)
+
+
+def test_duplicate_targets_pick_lowest_index(eng, orc):
+    rng = np.random.default_rng(4)
+    dst = rng.uniform(-0.1, 0.1, (600, 3))
+    dst[300:] = dst[:300]  # exact duplicates: lowest index must win in every kernel
+    eng.set_frames([dst], None)
+    q = dst[:300] + 1e-4
+    for m in METHODS:
+        idx, d2 = eng.nn_query(0, q, m)
+        oi, od = orc.nn_brute(dst, q)
+        assert np.array_equal(idx, oi) and np.array_equal(d2, od) and idx.max() < 300
+
+
+# ---------------------------------------------------------------- S1 / correspond
+def check_correspond(eng, orc, pts, nor, poses, fixed, src, dst, thresh, method):
+    eng.set_frames(pts, nor)
+    eng.set_graph(src, dst)
+    counts, weights = eng.correspond(poses, fixed, thresh, method)
+    for e, (s, d) in enumerate(zip(src, dst)):
+        if fixed[s]:
+            assert counts[e] == 0
+            continue
+        f, sec, dist, w, _, _ = orc.correspond_edge(pts[s], poses[s], pts[d], poses[d], thresh)
+        gf, gs, gd = eng.get_correspondences(e)
+        assert counts[e] == len(f)
+        assert np.array_equal(gf, f) and np.array_equal(gs, sec)
+        assert np.array_equal(gd, dist)  # bit-exact distances
+        if len(f):
+            assert weights[e] == w  # bit-exact float weight
+        else:
+            assert weights[e] == 0
+    return counts, weights
+
+
+@pytest.mark.parametrize("method", METHODS)
+def test_correspond_bunny_golden_pair(eng, orc, method):
+    pts = [G["dst"], G["src"]]
+    nor = [G["dst_nor"], G["src_nor"]]
+    poses = np.array([G["pose_dst"], G["pose_src_noisy"]])
+    counts, weights = check_correspond(eng, orc, pts, nor, poses, [1, 0], [1], [0], 0.05, method)
+    # against the nanoflann golden directly
+    f, s, d = eng.get_correspondences(0)
+    keep = np.sqrt(G["d2_noisy"]) < float(np.float32(0.05))
+    assert np.array_equal(f, np.nonzero(keep)[0]) and np.array_equal(s, G["idx_noisy"][keep])
+    assert np.array_equal(d, np.sqrt(G["d2_noisy"][keep]))
+
+
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("thresh", [0.05, 0.004, 1e-7])
+def test_correspond_synthetic_multiview(eng, orc, method, thresh):
+    pb = synth.make_problem(4, 3000)
+    check_correspond(eng, orc, pb["pts"], pb["nor"], pb["init"], pb["fixed"], pb["src"], pb["dst"], thresh, method)
+
+
+def test_correspond_ragged_sizes_and_fixed_sources(eng, orc):
+    rng = np.random.default_rng(9)
+    pb = synth.make_problem(3, 2500)
+    pts = [pb["pts"][0][:2500], pb["pts"][1][:1031], pb["pts"][2][:64]]
+    nor = [pb["nor"][0][:2500], pb["nor"][1][:1031], pb["nor"][2][:64]]
+    src = np.array([0, 1, 1, 2, 2]); dst = np.array([1, 0, 2, 1, 0])
+    check_correspond(eng, orc, pts, nor, pb["init"], [1, 0, 0], src, dst, 0.05, L.NN_BRUTE)
+    check_correspond(eng, orc, pts, nor, pb["init"], [1, 0, 1], src, dst, 0.05, L.NN_GRID)
+    check_correspond(eng, orc, pts, nor, pb["init"], [1, 0, 0], src, dst, 0.05, TREE)
+
+
+def test_grid_far_queries_and_clustered_clouds(eng, orc):
+    """Queries far outside the cloud, inside holes, and clouds with wildly non-uniform density: the hash block
+    test must hand over to the tree exactly when it cannot prove optimality."""
+    rng = np.random.default_rng(12)
+    a = rng.normal(0, 0.001, (3000, 3))                      # tight cluster
+    b = rng.uniform(-0.5, 0.5, (500, 3))                     # sparse halo
+    c = np.stack([np.linspace(-1, 1, 700), np.zeros(700), np.zeros(700)], 1)  # a line (degenerate bbox axes)
+    dst = np.vstack([a, b, c])
+    eng.set_frames([dst], None)
+    q = np.vstack([rng.uniform(-2, 2, (2000, 3)), rng.normal(0, 0.002, (2000, 3)), dst[::7] + 1e-9, [[100.0, -50.0, 3.0]], [[0.0, 0.0, 1e6]]])
+    oi, od = orc.nn_brute(dst, q)
+    for m in (L.NN_GRID, TREE):
+        idx, d2 = eng.nn_query(0, q, m)
+        assert np.array_equal(idx, oi) and np.array_equal(d2, od), m
+    # planar cloud (zero extent along z)
+    flat = np.concatenate([rng.uniform(-1, 1, (4000, 2)), np.zeros((4000, 1))], 1)
+    eng.set_frames([flat], None)
+    q = rng.uniform(-1.2, 1.2, (3000, 3)) * [1, 1, 0.05]
+    oi, od = orc.nn_brute(flat, q)
+    for m in (L.NN_GRID, TREE):
+        idx, d2 = eng.nn_query(0, q, m)
+        assert np.array_equal(idx, oi) and np.array_equal(d2, od), m
+
+
+# ---------------------------------------------------------------- normal equations
+@pytest.mark.parametrize("plane", [1, 0])
+@pytest.mark.parametrize("robust", [1, 0])
+def test_linearize_matches_oracle_blocks(eng, orc, plane, robust):
+    pb = synth.make_problem(4, 6000)
+    eng.set_frames(pb["pts"], pb["nor"])
+    eng.set_graph(pb["src"], pb["dst"])
+    counts, weights = eng.correspond(pb["init"], pb["fixed"], 0.05)
+    corr = [eng.get_correspondences(e)[:2] for e in range(eng.E)]
+    for poses in (pb["init"], pb["gt"]):
+        got = eng.linearize(poses, plane, robust)
+        want = orc.edge_blocks(pb["pts"], pb["nor"], pb["src"], pb["dst"], corr, weights, poses, plane, robust)
+        # fp64 sums of ~6000 terms in a different association order: relative 1e-11 of the block's scale
+        for e in range(eng.E):
+            scale = np.abs(want[e, :78]).max()
+            assert np.allclose(got[e, :78], want[e, :78], rtol=0, atol=1e-11 * scale), (e, np.abs(got[e, :78] - want[e, :78]).max() / scale)
+            gs = np.abs(want[e, 78:90]).max() + 1e-300
+            assert np.allclose(got[e, 78:90], want[e, 78:90], rtol=0, atol=1e-10 * gs)
+            assert abs(got[e, 90] - want[e, 90]) <= 1e-12 * abs(want[e, 90])
+
+
+def test_linearize_explicit_correspondences_and_chunk_boundaries(eng, orc):
+    # counts straddling the 4096-correspondence workgroup chunk and odd counts (the 16-B pair loads)
+    rng = np.random.default_rng(5)
+    N = 9001
+    pb = synth.make_problem(2, N)
+    eng.set_frames(pb["pts"], pb["nor"])
+    eng.set_graph([1], [0])
+    for n in (1, 2, 4095, 4096, 4097, 8193, 9001):
+        f = np.sort(rng.choice(N, n, replace=False)).astype(np.int32)
+        s = rng.integers(0, N, n).astype(np.int32)
+        eng.set_correspondences(0, f, s, 0.013)
+        got = eng.linearize(pb["init"], 1, 1)
+        want = orc.edge_blocks(pb["pts"], pb["nor"], [1], [0], [(f, s)], [np.float32(0.013)], pb["init"], 1, 1)
+        scale = np.abs(want[0, :78]).max()
+        assert np.allclose(got[0], want[0], rtol=1e-10, atol=1e-11 * scale), n
+    eng.set_correspondences(0, np.zeros(0, np.int32), np.zeros(0, np.int32), 0.0)
+    assert np.all(eng.linearize(pb["init"], 1, 1) == 0)
+
+
+# ---------------------------------------------------------------- S2 and the whole loop
+@pytest.mark.parametrize("param", [L.PARAM_SOPHUS_SE3, L.PARAM_ANGLE_AXIS, L.PARAM_EIGEN_QUATERNION])
+@pytest.mark.parametrize("plane", [1, 0])
+def test_optimize_matches_oracle(eng, orc, param, plane):
+    pb = synth.make_problem(4, 5000)
+    eng.set_frames(pb["pts"], pb["nor"])
+    eng.set_graph(pb["src"], pb["dst"])
+    counts, weights = eng.correspond(pb["init"], pb["fixed"], 0.05)
+    corr = [eng.get_correspondences(e)[:2] for e in range(eng.E)]
+    P, sm = eng.optimize(pb["init"], pb["fixed"], param, plane, True, 50)
+    prob = orc.make_problem(pb["pts"], pb["nor"], pb["fixed"], pb["src"], pb["dst"], corr, weights, param, plane, 1)
+    P_ref, sm_ref = orc.optimize(prob, pb["init"], 50)
+    assert sm["iterations"] == sm_ref["iterations"] and sm["termination"] == sm_ref["termination"], (sm, sm_ref)
+    for k in range(4):
+        dt, dr = synth.pose_diff(P[k], P_ref[k])
+        assert dt < 1e-9 and dr < 1e-9, (k, dt, dr)  # north-star tolerance is 1e-5 m / 1e-5 rad
+
+
+def run_icp_gpu(eng, pb, rounds, param, plane, method=L.NN_AUTO):
+    poses = pb["init"].copy()
+    for _ in range(rounds):
+        eng.correspond(poses, pb["fixed"], 0.05, method)
+        poses, sm = eng.optimize(poses, pb["fixed"], param, plane, True, 50)
+    return poses
+
+
+def run_icp_oracle(orc, pb, rounds, param, plane):
+    poses = pb["init"].copy()
+    for _ in range(rounds):
+        corr, w = [], []
+        for s, d in zip(pb["src"], pb["dst"]):
+            f, sec, dist, wt, _, _ = orc.correspond_edge(pb["pts"][s], poses[s], pb["pts"][d], poses[d], 0.05)
+            corr.append((f, sec)); w.append(wt)
+        prob = orc.make_problem(pb["pts"], pb["nor"], pb["fixed"], pb["src"], pb["dst"], corr, w, param, plane, 1)
+        poses, sm = orc.optimize(prob, poses, 50)
+    return poses
+
+
+@pytest.mark.parametrize("param,plane", [(L.PARAM_SOPHUS_SE3, 1), (L.PARAM_ANGLE_AXIS, 1), (L.PARAM_EIGEN_QUATERNION, 0)])
+def test_full_icp_loop_matches_oracle(eng, orc, param, plane):
+    """The loop body of main_multiview.cpp:150-169, 6 rounds, GPU vs the CPU restatement on the same inputs."""
+    pb = synth.make_problem(4, 4000)
+    eng.set_frames(pb["pts"], pb["nor"])
+    eng.set_graph(pb["src"], pb["dst"])
+    Pg = run_icp_gpu(eng, pb, 6, param, plane)
+    Po = run_icp_oracle(orc, pb, 6, param, plane)
+    for k in range(4):
+        dt, dr = synth.pose_diff(Pg[k], Po[k])
+        assert dt < 1e-8 and dr < 1e-8, (k, dt, dr)
+    if plane:  # (point-to-point on this near-spherical scene slides along the surface: parity holds, accuracy does not)
+        e0 = max(synth.pose_diff(pb["init"][k], pb["gt"][k])[0] for k in range(4))
+        e1 = max(synth.pose_diff(Pg[k], pb["gt"][k])[0] for k in range(4))
+        assert e1 < 0.6 * e0, (e0, e1)
+
+
+def test_pairwise_known_answer_on_gpu(eng):
+    """main_pairwise.cpp:44-61,117-133 through the device path (S3 = a 2-frame graph with index-aligned pairs):
+    every parameterization recovers P; README.md:141-146 quotes diff_tra <~ 1e-10."""
+    pts, nrm = G["dst"], G["dst_nor"]
+    P = synth.add_noise(np.eye(4), 0.3, 0.1, np.random.default_rng(1))
+    dstp = pts @ P[:3, :3].T + P[:3, 3]
+    dstn = nrm @ P[:3, :3].T
+    n = len(pts)
+    eng.set_frames([dstp, pts], [dstn, nrm])
+    eng.set_graph([1], [0])
+    eng.set_correspondences(0, np.arange(n, dtype=np.int32), np.arange(n, dtype=np.int32), 0.0)
+    for param in (0, 1, 2):
+        for plane in (0, 1):
+            Pout, sm = eng.optimize(np.array([np.eye(4), np.eye(4)]), [1, 0], param, plane, False, 50)
+            dt, dr = synth.pose_diff(P, Pout[1])
+            assert dt < 1e-9 and dr < 1e-9, (param, plane, dt, dr, sm)
+
+
+# ---------------------------------------------------------------- size-independent properties at full size
+def test_full_size_properties_cfg2(eng):
+    """BASELINE config 2 size (2 x 100k, point-to-plane): NN of a cloud against itself is the identity with d2 = 0;
+    brute force and grid agree bit-for-bit; linearize is invariant to a common rigid motion of both poses."""
+    pb = synth.make_problem(2, 100_000)
+    eng.set_frames(pb["pts"], pb["nor"])
+    eng.set_graph([1], [0])
+    for m in (L.NN_GRID, TREE):
+        idx, d2 = eng.nn_query(1, pb["pts"][1][:20000], m)
+        assert np.array_equal(idx, np.arange(20000)) and np.all(d2 == 0)
+    c1, w1 = eng.correspond(pb["init"], pb["fixed"], 0.05, L.NN_BRUTE)
+    a = eng.get_correspondences(0)
+    for m in (L.NN_GRID, TREE):
+        c2, w2 = eng.correspond(pb["init"], pb["fixed"], 0.05, m)
+        b = eng.get_correspondences(0)
+        assert c1[0] == c2[0] and w1[0] == w2[0] and all(np.array_equal(x, y) for x, y in zip(a, b)), m
+    assert np.all(np.diff(a[0]) > 0)  # ascending source index
+    blk = eng.linearize(pb["init"], 1, 1)
+    T = np.eye(4); T[:3, :3] = synth.so3_exp(np.array([0.3, -0.2, 0.5])); T[:3, 3] = [0.2, 0.1, -0.3]
+    moved = np.array([T @ P for P in pb["init"]])
+    blk2 = eng.linearize(moved, 1, 1)
+    scale = np.abs(blk[0, :78]).max()
+    assert np.allclose(blk, blk2, rtol=1e-9, atol=1e-12 * scale)
