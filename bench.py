@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("MVICP_WORKLOAD", "cfg4"))
     ap.add_argument("--nn", default="auto", choices=["auto", "brute", "grid"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--grid-target", type=float, default=None)
     args = ap.parse_args()
 
     import torch
@@ -116,6 +117,8 @@ def main():
     K, N, plane, param, desc = WORKLOADS[args.workload]
     pb = synth.make_problem(K, N)
     eng = mvicp.Engine(local, rank, world)
+    if args.grid_target:
+        eng.set_option("grid_target", args.grid_target)
     eng.set_frames(pb["pts"], pb["nor"])
     eng.set_graph(pb["src"], pb["dst"])
     if world > 1:
@@ -163,6 +166,7 @@ def main():
         elapsed = float(tt.item())
 
     prof = {k: eng.profile_get(k) for k in ("nn", "compact", "gather", "select", "linearize", "reduce")}
+    census = eng.nn_census()
     eng.profile(False)
 
     def roof(name):
@@ -189,6 +193,8 @@ def main():
                                   "lm_iterations": float(np.mean([l["lm_iters"] for l in log])), "device_evaluations": float(np.mean([l["evals"] for l in log])),
                                   "correspondences": float(np.mean([l["corr"] for l in log]))},
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
+            "nn_census_per_query": {"candidates": census["candidates"] / max(1.0, census["queries"]), "tree_nodes": census["nodes"] / max(1.0, census["queries"]),
+                                    "tree_fallback_fraction": census["far"] / max(1.0, census["queries"])},
             "pose_error_vs_gt": {"max_translation_m": err_t, "max_rotation_rad": err_r},
         }
         if world == 1 and not args.no_cpu_baseline:

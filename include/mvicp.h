@@ -127,7 +127,8 @@ int mvicp_lm_solve(int n_frames, int n_edges, const int* src, const int* dst, do
                    int max_iterations, mvicp_eval_fn eval, void* user, mvicp_summary* summary);
 
 /* Tuning / test switches.  "nn_tree_only" (0/1): skip the hash-grid fast path and answer every query with the
- * exact AABB-tree descent (same results; used by the parity tests to exercise the fallback on every query). */
+ * exact AABB-tree descent (same results; used by the parity tests to exercise the fallback on every query).
+ * "grid_target" (points per occupied hash cell the cell-edge heuristic aims at; set before mvicp_set_frame). */
 int mvicp_set_option(mvicp_ctx* ctx, const char* name, double value);
 /* NN census accumulated while profiling is enabled: out[0..3] = queries, candidate points examined,
  * tree nodes tested, queries that needed the tree fallback. */

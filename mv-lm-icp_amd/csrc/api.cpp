@@ -290,6 +290,14 @@ int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) {
     MV_CHECK(mvicp_edge_owner(E, ns.data(), c->world, owner.data()));
     for (int e = 0; e < E; ++e) c->owned[e] = owner[e] == c->rank;
   }
+  // linearize workgroup chunk: from the GLOBAL source-point total (identical on every rank, so per-edge sums
+  // have the same association order for any GPU count); small problems get small chunks to fill 256 CUs.
+  {
+    double total = 0;
+    for (int e = 0; e < E; ++e) total += c->frames[src[e]].n;
+    c->lin_chunk = total >= 6e6 ? 4096 : total >= 2e6 ? 2048 : total >= 5e5 ? 1024 : 512;
+  }
+  const int kLinChunk = c->lin_chunk;
   c->cap_off.assign(E + 1, 0);
   c->cblock_off.assign(E + 1, 0);
   c->chunk_first.assign(E + 1, 0);
@@ -317,7 +325,7 @@ int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) {
   MV_CHECK(dev_alloc(&c->d_median, E));
   MV_CHECK(dev_alloc(&c->d_chunk_edge, (size_t)c->n_chunks)); MV_CHECK(dev_alloc(&c->d_chunk_start, (size_t)c->n_chunks));
   MV_CHECK(dev_alloc(&c->d_chunk_first, E + 1));
-  MV_CHECK(dev_alloc(&c->d_partials, (size_t)c->n_chunks * MVICP_EDGE_BLOCK)); MV_CHECK(dev_alloc(&c->d_out, (size_t)E * MVICP_EDGE_BLOCK));
+  MV_CHECK(dev_alloc(&c->d_partials, (size_t)c->n_chunks * kLinPartial)); MV_CHECK(dev_alloc(&c->d_out, (size_t)E * MVICP_EDGE_BLOCK));
   if (E) {
     MV_HIP(hipMemcpy(c->d_esrc, src, sizeof(int) * E, hipMemcpyHostToDevice));
     MV_HIP(hipMemcpy(c->d_edst, dst, sizeof(int) * E, hipMemcpyHostToDevice));
@@ -485,6 +493,11 @@ int mvicp_set_option(mvicp_ctx* c, const char* name, double value) {
   MV_CHECK(bind(c));
   if (!name) { set_error("null option name"); return MVICP_ERR_ARG; }
   if (std::strcmp(name, "nn_tree_only") == 0) { c->nn_tree_only = value != 0.0; return MVICP_OK; }
+  if (std::strcmp(name, "grid_target") == 0) {
+    if (!(value >= 0.5 && value <= 64.0)) { set_error("grid_target out of range"); return MVICP_ERR_ARG; }
+    c->grid_target = value;
+    return MVICP_OK;
+  }
   set_error("unknown option '%s'", name);
   return MVICP_ERR_ARG;
 }

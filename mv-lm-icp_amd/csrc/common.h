@@ -29,7 +29,7 @@ void set_error(const char* fmt, ...);
     if (_s != MVICP_OK) return _s; \
   } while (0)
 
-constexpr int kLinChunk = 4096;      // correspondences per linearize workgroup
+constexpr int kLinPartial = 32;      // doubles per linearize workgroup partial (28 plane / 29 point, padded)
 constexpr int kLinThreads = 256;
 constexpr int kCompactBlock = 1024;  // queries per compaction workgroup
 constexpr int kEdgeXf = 24;          // Rs(9) ts(3) Rdinv(9) td(3), column-major
@@ -107,10 +107,11 @@ struct mvicp_ctx {
   // select scratch
   unsigned long long* d_sel_prefix = nullptr; int* d_sel_k = nullptr; unsigned int* d_sel_hist = nullptr; double* d_median = nullptr;
   // linearize chunks
+  int lin_chunk = 4096;             // correspondences per linearize workgroup (chosen from the GLOBAL problem size)
   int n_chunks = 0;
   std::vector<int> chunk_first;     // E+1
   int* d_chunk_edge = nullptr; int* d_chunk_start = nullptr; int* d_chunk_first = nullptr;
-  double* d_partials = nullptr;     // n_chunks x 91
+  double* d_partials = nullptr;     // n_chunks x kLinPartial
   double* d_out = nullptr;          // E x 91
   // pinned host staging
   double* h_pin = nullptr; size_t h_pin_doubles = 0;
@@ -127,6 +128,7 @@ struct mvicp_ctx {
 
   // options / NN census (profiling only)
   bool nn_tree_only = false;
+  double grid_target = 6.0;        // points per occupied cell the cell-edge heuristic aims at
   double nn_candidates = 0, nn_nodes = 0, nn_far = 0, nn_queries = 0;
 
   // profiling

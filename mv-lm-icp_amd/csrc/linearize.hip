@@ -5,21 +5,28 @@
 // Replaces what Ceres does with one AutoDiffCostFunction + SoftLOneLoss per correspondence
 // (src/internal/icp-ceres.cpp:270-292,360-378,435-453 on the functors of include/icp-ceres.h:49-316):
 // evaluate r and dr/d(pose_s, pose_d), scale both by sqrt(rho') (Ceres corrector for rho'' <= 0), and
-// accumulate the normal equations.  The Jacobian is taken in canonical right-perturbation coordinates
-// T <- T exp([upsilon, omega]) for both poses; the host LM maps it to the selected parameterization
-// (host/lm.cpp).  Derivation (docs/mv-lm-icp.tex:109-112,306-319), with
-//   A = R_d^T R_s, t = R_d^T (t_s - t_d), p~ = A p + t   (src point in the dst frame), m = A^T n:
-//   point-to-plane  r = n . (p~ - q)        J = [ m , p x m , -n , n x p~ ]                    (1 x 12)
-//   point-to-point  r = p~ - q  (= R_d^T (a-b), same norm)
-//                   J_k = [ A(k,:) , p x A(k,:) , -e_k , [q]x(k,:) ]   k = 0..2                 (3 x 12)
-//   rho(s) = 2 a^2 (sqrt(1 + s/a^2) - 1),  rho' = 1/sqrt(1 + s/a^2),  a = edge.weight  (SoftLOneLoss)
-//   H += rho' J^T J,  g += rho' J^T r,  cost += rho/2
+// accumulate the normal equations, in canonical right-perturbation coordinates T <- T exp([upsilon, omega])
+// for both poses (the host LM maps them to the selected parameterization, host/lm.cpp).
 //
-// Mapping: one 256-thread workgroup per chunk of kLinChunk correspondences of ONE edge; each lane owns
-// two adjacent correspondences per step (16-B loads from each SoA stream) and keeps the 91 running
-// sums (78 upper-triangular H + 12 g + cost) in registers; wave64 xor-shuffle reduction, LDS across the
-// 4 waves, one 91-double partial per workgroup; a second tiny kernel sums the partials of each edge in
-// fixed order -> results are deterministic and independent of how edges are sharded across GPUs.
+// Structure exploited (docs/mv-lm-icp.tex:109-112,306-319).  With the RELATIVE transform
+//   A = R_d^T R_s,  t = R_d^T (t_s - t_d),  p~ = A p + t  (source point in the dst frame),
+// and Ad = [[A, [t]x A], [0, A]] its adjoint, every Jacobian row is a fixed linear image of a 6-vector
+// that lives in the dst frame:
+//   point-to-plane  r = n . (p~ - q),  u = [n ; p~ x n],           J = [ Ad^T u ; -u ]
+//   point-to-point  r = p~ - q,        u_k = [e_k ; p~ x e_k],     J_k = [ Ad^T u_k ; -u_k + [0 ; r x e_k] ]
+// so instead of 78 + 12 + 1 running sums per lane only the weighted 6x6 moment block is accumulated:
+//   plane (28 sums):  U = sum w u u^T (21), v = sum w r u (6), cost
+//   point (29 sums):  sum w {1, p~ (3), p~ p~^T (6), r (3), p~ r^T (9), r r^T (6)}, cost
+// with w = rho'(|r|^2) = 1/sqrt(1 + |r|^2 / a^2), cost = sum rho/2, rho = 2 a^2 (sqrt(1 + s/a^2) - 1)
+// (ceres::SoftLOneLoss(a = edge.weight) [upstream]), and the 12x12 block is expanded ONCE per edge:
+//   H_ss = Ad^T S Ad, H_sd = -Ad^T (S - X), H_dd = S - X - X^T + Y, g = [Ad^T v ; -v]
+//   (plane: S = U, X = Y = 0; point: S = sum w [[I, -[p~]x],[[p~]x, -[p~]x^2]], X = sum w [[0,-[r]x],[0,-[p~]x[r]x]],
+//    Y = sum w [[0,0],[0,-[r]x^2]], v = sum w [r ; p~ x r]).
+//
+// Mapping: one 256-thread workgroup per chunk of `chunk` correspondences of ONE edge; ~60 accumulator
+// VGPRs per lane leave room to keep the next correspondences' loads in flight; transposed LDS block
+// reduction; one partial per workgroup; a second kernel sums each edge's partials in fixed order and does
+// the expansion -> deterministic, and independent of how edges are sharded across GPUs.
 #include "common.h"
 
 namespace mvicp {
@@ -28,88 +35,81 @@ namespace {
 
 constexpr int NT = kLinThreads;
 constexpr int NB = MVICP_EDGE_BLOCK;  // 91
+constexpr int NACC = kLinPartial;     // padded partial width (28 plane / 29 point)
+
+__device__ __forceinline__ double fast_rsqrt(double y) {
+  // y in [1, huge): v_rsq_f64 seed + two Newton steps (each squares the error) -> ~1 ulp
+  double r = __builtin_amdgcn_rsq(y);
+  r = r * (1.5 - 0.5 * y * r * r);
+  r = r * (1.5 - 0.5 * y * r * r);
+  return r;
+}
 
 template <bool PLANE, bool ROBUST>
-__device__ __forceinline__ void accumulate(double (&acc)[NB], const double* __restrict__ A, const double* __restrict__ t, double inv_a2, double a2,
+__device__ __forceinline__ void accumulate(double (&acc)[NACC], const double* __restrict__ A, const double* __restrict__ t, double inv_a2, double a2,
                                            double p0, double p1, double p2, double q0, double q1, double q2, double n0, double n1, double n2) {
-  const double pt0 = A[0] * p0 + A[3] * p1 + A[6] * p2 + t[0];
-  const double pt1 = A[1] * p0 + A[4] * p1 + A[7] * p2 + t[1];
-  const double pt2 = A[2] * p0 + A[5] * p1 + A[8] * p2 + t[2];
-  const double f0 = pt0 - q0, f1 = pt1 - q1, f2 = pt2 - q2;
+  const double x0 = A[0] * p0 + A[3] * p1 + A[6] * p2 + t[0];
+  const double x1 = A[1] * p0 + A[4] * p1 + A[7] * p2 + t[1];
+  const double x2 = A[2] * p0 + A[5] * p1 + A[8] * p2 + t[2];
+  const double f0 = x0 - q0, f1 = x1 - q1, f2 = x2 - q2;
   if (PLANE) {
     const double r = n0 * f0 + n1 * f1 + n2 * f2;
-    const double m0 = A[0] * n0 + A[1] * n1 + A[2] * n2;
-    const double m1 = A[3] * n0 + A[4] * n1 + A[5] * n2;
-    const double m2 = A[6] * n0 + A[7] * n1 + A[8] * n2;
-    double J[12];
-    J[0] = m0; J[1] = m1; J[2] = m2;
-    J[3] = p1 * m2 - p2 * m1; J[4] = p2 * m0 - p0 * m2; J[5] = p0 * m1 - p1 * m0;
-    J[6] = -n0; J[7] = -n1; J[8] = -n2;
-    J[9] = n1 * pt2 - n2 * pt1; J[10] = n2 * pt0 - n0 * pt2; J[11] = n0 * pt1 - n1 * pt0;
+    double u[6];
+    u[0] = n0; u[1] = n1; u[2] = n2;
+    u[3] = x1 * n2 - x2 * n1; u[4] = x2 * n0 - x0 * n2; u[5] = x0 * n1 - x1 * n0;
     const double s = r * r;
     double w = 1.0;
     if (ROBUST) {
-      const double tmp = sqrt(1.0 + s * inv_a2);
-      w = 1.0 / tmp;
-      acc[90] += a2 * (tmp - 1.0);
+      const double y = 1.0 + s * inv_a2;
+      w = fast_rsqrt(y);
+      acc[27] += a2 * (y * w - 1.0);
     } else {
-      acc[90] += 0.5 * s;
+      acc[27] += 0.5 * s;
     }
     int o = 0;
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      const double wj = w * J[i];
+    for (int i = 0; i < 6; ++i) {
+      const double wu = w * u[i];
 #pragma unroll
-      for (int j = i; j < 12; ++j) acc[o++] += wj * J[j];
-      acc[78 + i] += wj * r;
+      for (int j = i; j < 6; ++j) acc[o++] += wu * u[j];
+      acc[21 + i] += wu * r;
     }
   } else {
     const double s = f0 * f0 + f1 * f1 + f2 * f2;
     double w = 1.0;
     if (ROBUST) {
-      const double tmp = sqrt(1.0 + s * inv_a2);
-      w = 1.0 / tmp;
-      acc[90] += a2 * (tmp - 1.0);
+      const double y = 1.0 + s * inv_a2;
+      w = fast_rsqrt(y);
+      acc[28] += a2 * (y * w - 1.0);
     } else {
-      acc[90] += 0.5 * s;
+      acc[28] += 0.5 * s;
     }
-    const double fr[3] = {f0, f1, f2};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const double a0 = A[k], a1 = A[k + 3], a2k = A[k + 6];  // row k of A
-      double J[12];
-      J[0] = a0; J[1] = a1; J[2] = a2k;
-      J[3] = p1 * a2k - p2 * a1; J[4] = p2 * a0 - p0 * a2k; J[5] = p0 * a1 - p1 * a0;
-      J[6] = k == 0 ? -1.0 : 0.0; J[7] = k == 1 ? -1.0 : 0.0; J[8] = k == 2 ? -1.0 : 0.0;
-      // [q]x = [[0,-q2,q1],[q2,0,-q0],[-q1,q0,0]]
-      J[9] = k == 0 ? 0.0 : (k == 1 ? q2 : -q1);
-      J[10] = k == 0 ? -q2 : (k == 1 ? 0.0 : q0);
-      J[11] = k == 0 ? q1 : (k == 1 ? -q0 : 0.0);
-      int o = 0;
-#pragma unroll
-      for (int i = 0; i < 12; ++i) {
-        const double wj = w * J[i];
-#pragma unroll
-        for (int j = i; j < 12; ++j) acc[o++] += wj * J[j];
-        acc[78 + i] += wj * fr[k];
-      }
-    }
+    const double wx0 = w * x0, wx1 = w * x1, wx2 = w * x2;
+    const double wf0 = w * f0, wf1 = w * f1, wf2 = w * f2;
+    acc[0] += w;
+    acc[1] += wx0; acc[2] += wx1; acc[3] += wx2;
+    acc[4] += wx0 * x0; acc[5] += wx0 * x1; acc[6] += wx0 * x2; acc[7] += wx1 * x1; acc[8] += wx1 * x2; acc[9] += wx2 * x2;
+    acc[10] += wf0; acc[11] += wf1; acc[12] += wf2;
+    acc[13] += wx0 * f0; acc[14] += wx0 * f1; acc[15] += wx0 * f2;
+    acc[16] += wx1 * f0; acc[17] += wx1 * f1; acc[18] += wx1 * f2;
+    acc[19] += wx2 * f0; acc[20] += wx2 * f1; acc[21] += wx2 * f2;
+    acc[22] += wf0 * f0; acc[23] += wf0 * f1; acc[24] += wf0 * f2; acc[25] += wf1 * f1; acc[26] += wf1 * f2; acc[27] += wf2 * f2;
   }
 }
 
 template <bool PLANE, bool ROBUST>
-__global__ __launch_bounds__(NT, 2) void linearize_kernel(const int* __restrict__ chunk_edge, const int* __restrict__ chunk_start,
-                                                           const int* __restrict__ count, const long long* __restrict__ cap_off, long long total_cap,
-                                                           const double* __restrict__ rel, const double* __restrict__ a_scale,
-                                                           const double* __restrict__ stream, double* __restrict__ partials) {
+__global__ __launch_bounds__(NT) void linearize_kernel(const int* __restrict__ chunk_edge, const int* __restrict__ chunk_start, int chunk,
+                                                       const int* __restrict__ count, const long long* __restrict__ cap_off, long long total_cap,
+                                                       const double* __restrict__ rel, const double* __restrict__ a_scale,
+                                                       const double* __restrict__ stream, double* __restrict__ partials) {
   const int c = blockIdx.x;
   const int e = chunk_edge[c];
   const int start = chunk_start[c];
   const int cnt = count[e];
   if (start >= cnt) return;
-  const int end = min(cnt, start + kLinChunk);
+  const int end = min(cnt, start + chunk);
   __shared__ double srel[kEdgeRel];
-  __shared__ double red[NT / 64][NB];
+  __shared__ double red[NACC / 2][NT + 1];
   if (threadIdx.x < kEdgeRel) srel[threadIdx.x] = rel[(size_t)e * kEdgeRel + threadIdx.x];
   __syncthreads();
   double A[9], t[3];
@@ -120,70 +120,193 @@ __global__ __launch_bounds__(NT, 2) void linearize_kernel(const int* __restrict_
   double a2 = 1.0, inv_a2 = 1.0;
   if (ROBUST) { const double a = a_scale[e]; a2 = a * a; inv_a2 = 1.0 / a2; }
 
-  double acc[NB];
+  double acc[NACC];
 #pragma unroll
-  for (int i = 0; i < NB; ++i) acc[i] = 0.0;
+  for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
 
   const size_t base = (size_t)cap_off[e];  // multiple of 64 -> 16-B aligned double2 loads
   const double* __restrict__ s0 = stream + base;
   constexpr int NS = PLANE ? 9 : 6;
-  for (int pos = start + 2 * threadIdx.x; pos < end; pos += 2 * NT) {
-    double v0[9], v1[9];
-    const bool two = pos + 1 < end;
+  // two adjacent correspondences per lane per step (16-B loads); the next step's loads are issued before
+  // the current step's arithmetic so two steps of HBM latency overlap.
+  int pos = start + 2 * threadIdx.x;
+  double2 cur[9], nxt[9];
 #pragma unroll
-    for (int j = 0; j < NS; ++j) {
-      const double* sp = s0 + (size_t)j * total_cap + pos;
-      if (two) {
-        const double2 d = *reinterpret_cast<const double2*>(sp);
-        v0[j] = d.x; v1[j] = d.y;
-      } else {
-        v0[j] = sp[0]; v1[j] = 0.0;
-      }
+  for (int j = 0; j < 9; ++j) { cur[j] = make_double2(0.0, 0.0); nxt[j] = make_double2(0.0, 0.0); }
+  auto load = [&](double2 (&v)[9], int at) {
+    if (at + 1 < end) {
+#pragma unroll
+      for (int j = 0; j < NS; ++j) v[j] = *reinterpret_cast<const double2*>(s0 + (size_t)j * total_cap + at);
+    } else if (at < end) {
+#pragma unroll
+      for (int j = 0; j < NS; ++j) { v[j].x = s0[(size_t)j * total_cap + at]; v[j].y = 0.0; }
     }
-    if (!PLANE) { v0[6] = v0[7] = v0[8] = 0.0; v1[6] = v1[7] = v1[8] = 0.0; }
-    accumulate<PLANE, ROBUST>(acc, A, t, inv_a2, a2, v0[0], v0[1], v0[2], v0[3], v0[4], v0[5], v0[6], v0[7], v0[8]);
-    if (two) accumulate<PLANE, ROBUST>(acc, A, t, inv_a2, a2, v1[0], v1[1], v1[2], v1[3], v1[4], v1[5], v1[6], v1[7], v1[8]);
+  };
+  load(cur, pos);
+  while (pos < end) {
+    const int npos = pos + 2 * NT;
+    load(nxt, npos);
+    accumulate<PLANE, ROBUST>(acc, A, t, inv_a2, a2, cur[0].x, cur[1].x, cur[2].x, cur[3].x, cur[4].x, cur[5].x, cur[6].x, cur[7].x, cur[8].x);
+    if (pos + 1 < end)
+      accumulate<PLANE, ROBUST>(acc, A, t, inv_a2, a2, cur[0].y, cur[1].y, cur[2].y, cur[3].y, cur[4].y, cur[5].y, cur[6].y, cur[7].y, cur[8].y);
+#pragma unroll
+    for (int j = 0; j < 9; ++j) cur[j] = nxt[j];
+    pos = npos;
   }
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // Block reduction through LDS, transposed: every thread stores value j into row j (stride-1 across lanes:
+  // conflict-free ds_write_b64), then 16 threads per row add 16 columns each and finish with a 4-step xor-shuffle
+  // inside their lane group (two passes of 16 rows keep the LDS footprint at 33 KB).  Fixed association order -> deterministic.
 #pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    double v = acc[i];
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass) __syncthreads();
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    if (lane == 0) red[wave][i] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < NB) {
-    double v = red[0][threadIdx.x];
-#pragma unroll
-    for (int w = 1; w < NT / 64; ++w) v += red[w][threadIdx.x];
-    partials[(size_t)c * NB + threadIdx.x] = v;
+    for (int j = 0; j < NACC / 2; ++j) red[j][threadIdx.x] = acc[pass * (NACC / 2) + j];
+    __syncthreads();
+    const int row = threadIdx.x >> 4, part = threadIdx.x & 15;  // 16 rows x 16 parts
+    double sum = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < NT / 16; ++k) sum += red[row][part + 16 * k];
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    sum += __shfl_xor(sum, 4, 64);
+    sum += __shfl_xor(sum, 8, 64);
+    if (part == 0) partials[(size_t)c * NACC + pass * (NACC / 2) + row] = sum;
   }
 }
 
-__global__ __launch_bounds__(128) void reduce_kernel(const int* __restrict__ chunk_first, const int* __restrict__ count,
-                                                     const double* __restrict__ partials, double* __restrict__ out) {
+// ---- per edge: fixed-order sum of the workgroup partials, then expansion to the canonical 12x12 block
+__device__ __forceinline__ void cross_mat(const double* a, double* M) {  // row-major [a]x
+  M[0] = 0; M[1] = -a[2]; M[2] = a[1];
+  M[3] = a[2]; M[4] = 0; M[5] = -a[0];
+  M[6] = -a[1]; M[7] = a[0]; M[8] = 0;
+}
+
+template <bool PLANE>
+__global__ __launch_bounds__(64) void reduce_expand_kernel(const int* __restrict__ chunk_first, int chunk, const int* __restrict__ count,
+                                                           const double* __restrict__ rel, const double* __restrict__ partials,
+                                                           double* __restrict__ out) {
   const int e = blockIdx.x;
   const int tid = threadIdx.x;
-  if (tid >= NB) return;
+  __shared__ double m[2][NACC];
+  __shared__ double S[36], X[36], Y[36], Ad[36], T1[36], T2[36], H[144], v[6];
   const int c0 = chunk_first[e];
-  const int nchunks = min(chunk_first[e + 1] - c0, (count[e] + kLinChunk - 1) / kLinChunk);
-  double v = 0.0;
-  for (int c = 0; c < nchunks; ++c) v += partials[(size_t)(c0 + c) * NB + tid];
-  out[(size_t)e * NB + tid] = v;
+  const int nchunks = min(chunk_first[e + 1] - c0, (count[e] + chunk - 1) / chunk);
+  {
+    // 64 threads: two interleaved fixed-order partial sums per value, combined in fixed order
+    const int val = tid & (NACC - 1), half = tid >> 5;
+    double s = 0.0;
+    for (int c = half; c < nchunks; c += 2) s += partials[(size_t)(c0 + c) * NACC + val];
+    m[half][val] = s;
+  }
+  if (tid < 36) { S[tid] = 0.0; X[tid] = 0.0; Y[tid] = 0.0; Ad[tid] = 0.0; }
+  __syncthreads();
+  if (tid < NACC) m[0][tid] += m[1][tid];
+  __syncthreads();
+  const double* mm = m[0];
+  const double* A = rel + (size_t)e * kEdgeRel;  // column-major 3x3
+  const double* t = A + 9;
+  if (tid < 9) {
+    // Ad = [[A, [t]x A],[0, A]]   (row-major 6x6)
+    const int i = tid / 3, j = tid % 3;
+    double tx[9];
+    cross_mat(t, tx);
+    const double a = A[i + 3 * j];
+    Ad[i * 6 + j] = a;
+    Ad[(3 + i) * 6 + 3 + j] = a;
+    Ad[i * 6 + 3 + j] = tx[i * 3 + 0] * A[0 + 3 * j] + tx[i * 3 + 1] * A[1 + 3 * j] + tx[i * 3 + 2] * A[2 + 3 * j];
+    if (PLANE) {
+      if (tid < 6) v[tid] = mm[21 + tid];
+    } else {
+      const double w = mm[0];
+      const double px[3] = {mm[1], mm[2], mm[3]};
+      const double P[9] = {mm[4], mm[5], mm[6], mm[5], mm[7], mm[8], mm[6], mm[8], mm[9]};            // sum w p p^T
+      const double rr[3] = {mm[10], mm[11], mm[12]};
+      const double PR[9] = {mm[13], mm[14], mm[15], mm[16], mm[17], mm[18], mm[19], mm[20], mm[21]};  // sum w p r^T (row-major)
+      const double RR[9] = {mm[22], mm[23], mm[24], mm[23], mm[25], mm[26], mm[24], mm[26], mm[27]};
+      double pxm[9], rxm[9];
+      cross_mat(px, pxm);
+      cross_mat(rr, rxm);
+      const double trP = P[0] + P[4] + P[8], trRR = RR[0] + RR[4] + RR[8], trPR = PR[0] + PR[4] + PR[8];
+      const double I = i == j ? 1.0 : 0.0;
+      // S = sum w [[I, -[p]x],[[p]x, |p|^2 I - p p^T]]
+      S[i * 6 + j] = w * I;
+      S[i * 6 + 3 + j] = -pxm[i * 3 + j];
+      S[(3 + i) * 6 + j] = pxm[i * 3 + j];
+      S[(3 + i) * 6 + 3 + j] = trP * I - P[i * 3 + j];
+      // X = sum w [[0, -[r]x],[0, -[p]x[r]x]],  [p]x[r]x = r p^T - (p.r) I
+      X[i * 6 + 3 + j] = -rxm[i * 3 + j];
+      X[(3 + i) * 6 + 3 + j] = -(PR[j * 3 + i] - trPR * I);
+      // Y = sum w [[0,0],[0, |r|^2 I - r r^T]]
+      Y[(3 + i) * 6 + 3 + j] = trRR * I - RR[i * 3 + j];
+      if (tid == 0) {
+        // v = sum w [r ; p x r],  (p x r) from the antisymmetric part of p r^T
+        v[0] = rr[0]; v[1] = rr[1]; v[2] = rr[2];
+        v[3] = PR[1 * 3 + 2] - PR[2 * 3 + 1];
+        v[4] = PR[2 * 3 + 0] - PR[0 * 3 + 2];
+        v[5] = PR[0 * 3 + 1] - PR[1 * 3 + 0];
+      }
+    }
+  }
+  if (PLANE && tid >= 16 && tid < 16 + 21) {
+    // unpack U (upper triangle, row-major) into the full symmetric S
+    const int k = tid - 16;
+    int i = 0, o = k;
+    while (o >= 6 - i) { o -= 6 - i; ++i; }
+    const int j = i + o;
+    S[i * 6 + j] = mm[k];
+    S[j * 6 + i] = mm[k];
+  }
+  __syncthreads();
+  if (tid < 36) {
+    const int i = tid / 6, j = tid % 6;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s += S[i * 6 + k] * Ad[k * 6 + j];
+    T1[tid] = s;                 // S Ad
+    T2[tid] = S[tid] - X[tid];   // S - X
+  }
+  __syncthreads();
+  double* o = out + (size_t)e * NB;
+  if (tid < 36) {
+    const int i = tid / 6, j = tid % 6;
+    double hss = 0.0, hsd = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { hss += Ad[k * 6 + i] * T1[k * 6 + j]; hsd += Ad[k * 6 + i] * T2[k * 6 + j]; }
+    H[i * 12 + j] = hss;                                                             // H_ss = Ad^T S Ad
+    H[i * 12 + 6 + j] = -hsd;                                                        // H_sd = -Ad^T (S - X)
+    H[(6 + i) * 12 + 6 + j] = S[i * 6 + j] - X[i * 6 + j] - X[j * 6 + i] + Y[i * 6 + j];  // H_dd
+  } else if (tid < 42) {
+    const int i = tid - 36;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s += Ad[k * 6 + i] * v[k];
+    o[78 + i] = s;           // g_s = Ad^T v
+    o[84 + i] = -v[i];       // g_d = -v
+  } else if (tid == 42) {
+    o[90] = count[e] > 0 ? mm[PLANE ? 27 : 28] : 0.0;
+  }
+  __syncthreads();
+  for (int k = tid; k < 78; k += 64) {
+    int i = 0, r = k;
+    while (r >= 12 - i) { r -= 12 - i; ++i; }
+    const int j = i + r;
+    // H_ss and H_dd are symmetric up to rounding: average the two triangles so the block is exactly symmetric
+    o[k] = (i < 6 && j >= 6) ? H[i * 12 + j] : 0.5 * (H[i * 12 + j] + H[j * 12 + i]);
+  }
 }
 
 }  // namespace
 
 int launch_linearize(mvicp_ctx* c, int plane, int robust) {
   if (c->E == 0) return MVICP_OK;
+  const int chunk = c->lin_chunk;
   if (c->n_chunks > 0) {
     double bytes = 0;
     for (int e = 0; e < c->E; ++e) if (c->owned[e]) bytes += (plane ? 72.0 : 48.0) * c->h_count[e];
     ProfScope ps(c, "linearize", bytes);
-#define LAUNCH(P, R)                                                                                                                        \
-  hipLaunchKernelGGL((linearize_kernel<P, R>), dim3(c->n_chunks), dim3(NT), 0, c->stream, c->d_chunk_edge, c->d_chunk_start, c->d_count,    \
+#define LAUNCH(P, R)                                                                                                                           \
+  hipLaunchKernelGGL((linearize_kernel<P, R>), dim3(c->n_chunks), dim3(NT), 0, c->stream, c->d_chunk_edge, c->d_chunk_start, chunk, c->d_count, \
                      c->d_cap_off, c->total_cap, c->d_rel, c->d_a, c->d_stream, c->d_partials)
     if (plane && robust) LAUNCH(true, true);
     else if (plane) LAUNCH(true, false);
@@ -193,7 +316,10 @@ int launch_linearize(mvicp_ctx* c, int plane, int robust) {
   }
   {
     ProfScope ps(c, "reduce", 0.0);
-    hipLaunchKernelGGL(reduce_kernel, dim3(c->E), dim3(128), 0, c->stream, c->d_chunk_first, c->d_count, c->d_partials, c->d_out);
+    if (plane)
+      hipLaunchKernelGGL((reduce_expand_kernel<true>), dim3(c->E), dim3(64), 0, c->stream, c->d_chunk_first, chunk, c->d_count, c->d_rel, c->d_partials, c->d_out);
+    else
+      hipLaunchKernelGGL((reduce_expand_kernel<false>), dim3(c->E), dim3(64), 0, c->stream, c->d_chunk_first, chunk, c->d_count, c->d_rel, c->d_partials, c->d_out);
   }
   MV_HIP(hipGetLastError());
   return MVICP_OK;

@@ -248,7 +248,6 @@ void make_grid(HostGrid& g, const double* lo, const double* hi, double h) {
 }  // namespace
 
 int build_grid(mvicp_ctx* c, FrameDev& f, const double* xyz) {
-  (void)c;
   const int n = f.n;
   GridDev& G = f.grid;
   double lo[3] = {xyz[0], xyz[1], xyz[2]}, hi[3] = {xyz[0], xyz[1], xyz[2]};
@@ -260,7 +259,7 @@ int build_grid(mvicp_ctx* c, FrameDev& f, const double* xyz) {
   if (!(ext > 0.0)) ext = 1.0;
   // cell edge: aim at ~6 points per occupied cell.  Measure occupancy at two resolutions (the cloud is a surface,
   // so occupied(h) ~ h^-dim with dim ~ 2), extrapolate, verify once.
-  const double target = 6.0;
+  const double target = c->grid_target;
   double h = ext / std::max(2.0, std::cbrt((double)n));
   HostGrid g;
   if (n > 64) {
@@ -276,8 +275,8 @@ int build_grid(mvicp_ctx* c, FrameDev& f, const double* xyz) {
     for (int it = 0; it < 3; ++it) {
       make_grid(g, lo, hi, h);
       const double per = (double)n / (double)occupied_cells(g, xyz, n, 1);
-      if (per < 3.5) h *= std::pow(target / per, 1.0 / dim);
-      else if (per > 12.0) h *= std::pow(target / per, 1.0 / dim);
+      if (per < 0.6 * target) h *= std::pow(target / per, 1.0 / dim);
+      else if (per > 1.8 * target) h *= std::pow(target / per, 1.0 / dim);
       else break;
     }
   }
