@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--steps", type=int, default=19)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("MVICP_WORKLOAD", "cfg4"))
-    ap.add_argument("--nn", default="auto", choices=["auto", "brute", "grid"])
+    ap.add_argument("--nn", default="auto", choices=["auto", "brute", "grid", "tile"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--grid-target", type=float, default=None)
     args = ap.parse_args()
@@ -129,7 +129,7 @@ def main():
             uid.copy_(torch.frombuffer(bytearray(mvicp.Engine.comm_unique_id(rccl)), dtype=torch.uint8))
         dist.broadcast(uid, 0)
         eng.comm_init(bytes(uid.cpu().numpy().tobytes()), rccl)
-    method = {"auto": L.NN_AUTO, "brute": L.NN_BRUTE, "grid": L.NN_GRID}[args.nn]
+    method = {"auto": L.NN_AUTO, "brute": L.NN_BRUTE, "grid": L.NN_GRID, "tile": L.NN_TILE}[args.nn]
 
     poses = pb["init"].copy()
     log = []

@@ -207,6 +207,7 @@ int mvicp_destroy(mvicp_ctx* c) {
   free_graph(c);
   for (FrameDev& f : c->frames) { dev_free(f.pts); dev_free(f.nor); free_grid(f.grid); }
   dev_free(c->d_split_idx); dev_free(c->d_split_d2); dev_free(c->d_scratch);
+  if (c->d_census) (void)hipFree(c->d_census);
   for (auto& kv : c->prof) {
     for (auto& pr : kv.second.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (hipEvent_t ev : kv.second.pool) (void)hipEventDestroy(ev);
@@ -372,12 +373,13 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   const double bound = sqrt_bound((double)thresh);
   int method = nn_method;
   if (method == MVICP_NN_AUTO) method = MVICP_NN_GRID;
-  if (method == MVICP_NN_GRID) {
+  if (method == MVICP_NN_GRID || method == MVICP_NN_TILE) {
     for (int e = 0; e < E; ++e)
-      if (c->active[e] && !c->frames[c->edst[e]].has_grid) method = MVICP_NN_BRUTE;
+      if (c->active[e] && (!c->frames[c->edst[e]].has_grid || !c->frames[c->esrc[e]].has_grid)) method = MVICP_NN_BRUTE;
   }
   if (method == MVICP_NN_BRUTE) MV_CHECK(launch_nn_brute_edges(c));
   else if (method == MVICP_NN_GRID) MV_CHECK(launch_nn_grid_edges(c, bound));
+  else if (method == MVICP_NN_TILE) MV_CHECK(launch_nn_tile_edges(c, bound));
   else { set_error("unknown nn_method %d", nn_method); return MVICP_ERR_ARG; }
 
   MV_CHECK(launch_compact(c, bound));
@@ -463,7 +465,7 @@ int mvicp_nn_query(mvicp_ctx* c, int frame, const double* queries, int n, int nn
   double* dq = nullptr; int* di = nullptr; double* dd = nullptr;
   MV_CHECK(dev_alloc(&dq, 3 * (size_t)n)); MV_CHECK(dev_alloc(&di, (size_t)n)); MV_CHECK(dev_alloc(&dd, (size_t)n));
   MV_HIP(hipMemcpy(dq, queries, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice));
-  int method = nn_method == MVICP_NN_AUTO ? MVICP_NN_GRID : nn_method;
+  int method = (nn_method == MVICP_NN_AUTO || nn_method == MVICP_NN_TILE) ? MVICP_NN_GRID : nn_method;  // raw queries are not patch-ordered
   if (method == MVICP_NN_GRID && !f.has_grid) method = MVICP_NN_BRUTE;
   int st;
   if (method == MVICP_NN_BRUTE) st = launch_nn_brute_queries(c, f, dq, n, di, dd);
@@ -493,6 +495,8 @@ int mvicp_set_option(mvicp_ctx* c, const char* name, double value) {
   MV_CHECK(bind(c));
   if (!name) { set_error("null option name"); return MVICP_ERR_ARG; }
   if (std::strcmp(name, "nn_tree_only") == 0) { c->nn_tree_only = value != 0.0; return MVICP_OK; }
+  if (std::strcmp(name, "nn_census") == 0) { c->nn_census = value != 0.0; return MVICP_OK; }
+  if (std::strcmp(name, "nn_skip_far") == 0) { c->nn_skip_far = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "grid_target") == 0) {
     if (!(value >= 0.5 && value <= 64.0)) { set_error("grid_target out of range"); return MVICP_ERR_ARG; }
     c->grid_target = value;

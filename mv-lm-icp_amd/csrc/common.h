@@ -47,6 +47,13 @@ struct GridDev {
   unsigned int table_mask = 0; int table_shift = 0;
   float* bvh = nullptr;        // implicit complete AABB tree, 6 floats per node (outward rounded)
   int depth = 0;
+  // 64-wide box hierarchy over the same sorted array (nn_tile.hip): level 0 = boxes of 64-point leaves,
+  // level l+1 = boxes of 64 consecutive level-l boxes; SoA per level: 6 arrays of `wide_cnt[l]` floats.
+  float* wide = nullptr;
+  double maxabs = 0.0;         // largest |coordinate|
+  int wide_levels = 0;
+  int wide_cnt[6] = {0, 0, 0, 0, 0, 0};
+  long long wide_off[6] = {0, 0, 0, 0, 0, 0};
   double struct_bytes = 0.0;
 };
 
@@ -128,6 +135,9 @@ struct mvicp_ctx {
 
   // options / NN census (profiling only)
   bool nn_tree_only = false;
+  bool nn_census = false;          // count candidates / tree nodes per launch while profiling (small extra cost)
+  void* d_census = nullptr; size_t census_bytes = 0;
+  bool nn_skip_far = false;        // PROFILING ONLY: leave unresolved queries unresolved (wrong results)
   double grid_target = 6.0;        // points per occupied cell the cell-edge heuristic aims at
   double nn_candidates = 0, nn_nodes = 0, nn_far = 0, nn_queries = 0;
 
@@ -142,6 +152,8 @@ namespace mvicp {
 int launch_nn_brute_edges(mvicp_ctx* c);                                             // nn_brute.hip
 int launch_nn_brute_queries(mvicp_ctx* c, const FrameDev& f, const double* d_q, int n, int* d_idx, double* d_d2);
 int launch_nn_grid_edges(mvicp_ctx* c, double d2_bound);                              // nn_grid.hip
+int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound);                              // nn_tile.hip
+int build_wide(FrameDev& f, const double* sorted_pts);                                 // nn_tile.hip (host, called by build_grid)
 int launch_nn_grid_queries(mvicp_ctx* c, const FrameDev& f, const double* d_q, int n, int* d_idx, double* d_d2);
 int build_grid(mvicp_ctx* c, FrameDev& f, const double* h_xyz);
 void free_grid(GridDev& g);

@@ -101,8 +101,24 @@ __device__ __forceinline__ void scan_range(const GridView& g, int lo, int hi, do
   }
 }
 
+// sum over the ACTIVE lanes of the wave (lanes may have exited early)
+__device__ __forceinline__ unsigned long long __reduce_add_u64(unsigned long long v) {
+  unsigned long long total = 0;
+  unsigned long long mask = __ballot(1);
+  while (mask) {
+    const int l = __ffsll((long long)mask) - 1;
+    total += __shfl(v, l, 64);
+    mask &= mask - 1;
+  }
+  return total;
+}
+__device__ __forceinline__ bool __lane0() {
+  const unsigned long long mask = __ballot(1);
+  return (int)(threadIdx.x & 63) == __ffsll((long long)mask) - 1;
+}
+
 template <bool TREE_ONLY>
-__global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__ jobs, double bound, unsigned long long* __restrict__ stats) {
+__global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__ jobs, double bound, unsigned long long* __restrict__ stats, int skip_far) {
   __shared__ int s_stack[MAXD + 1][NT];
   __shared__ double sxf[kEdgeXf];
   const GridJob& job = jobs[blockIdx.y];
@@ -158,7 +174,7 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
     resolved = (m > 0.0) && (best < m * m) && (bi != 0x7fffffff);
   }
 
-  if (!resolved) {
+  if (!resolved && !skip_far) {
     // ---- (2) exact branch-and-bound over the implicit AABB tree, seeded with the current best
     const int D = g.depth;
     int sp = 0;
@@ -194,11 +210,26 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
   job.out_idx[out] = bi;
   job.out_d2[out] = best;
   if (stats) {
-    // candidate / node census for the algorithmic-byte model; wave-aggregated atomics
+    // candidate / node census for the algorithmic-byte model: one slot per wave, no atomics
+    // (hot-address atomics would throttle the kernel being measured); summed by census_sum_kernel.
+    // NOTE: lanes that returned early (i >= n) never get here; their slot share stays zero.
     unsigned long long c = n_cand, nd = n_nodes, far = resolved ? 0 : 1;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { c += __shfl_xor(c, d, 64); nd += __shfl_xor(nd, d, 64); far += __shfl_xor(far, d, 64); }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[0], c); atomicAdd(&stats[1], nd); atomicAdd(&stats[2], far); }
+    c = __reduce_add_u64(c); nd = __reduce_add_u64(nd); far = __reduce_add_u64(far);
+    const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + (threadIdx.x >> 6);
+    if (__lane0()) { stats[3 * slot] = c; stats[3 * slot + 1] = nd; stats[3 * slot + 2] = far; }
+  }
+}
+
+__global__ __launch_bounds__(256) void census_sum_kernel(const unsigned long long* __restrict__ stats, size_t slots, unsigned long long* __restrict__ out3) {
+  __shared__ unsigned long long sh[3][256];
+  unsigned long long a = 0, b = 0, c = 0;
+  for (size_t i = threadIdx.x; i < slots; i += 256) { a += stats[3 * i]; b += stats[3 * i + 1]; c += stats[3 * i + 2]; }
+  sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = b; sh[2][threadIdx.x] = c;
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    unsigned long long s = 0;
+    for (int i = 0; i < 256; ++i) s += sh[threadIdx.x][i];
+    out3[threadIdx.x] = s;
   }
 }
 
@@ -354,6 +385,7 @@ int build_grid(mvicp_ctx* c, FrameDev& f, const double* xyz) {
   MV_HIP(hipMemcpy(G.table, table.data(), sizeof(HashEntry) * (size_t)tsize, hipMemcpyHostToDevice));
   MV_HIP(hipMemcpy(G.bvh, bvh.data(), sizeof(float) * 6 * nodes, hipMemcpyHostToDevice));
   G.struct_bytes = sizeof(HashEntry) * (double)tsize + sizeof(float) * 6.0 * nodes;
+  MV_CHECK(build_wide(f, spts.data()));
   f.has_grid = true;
   return MVICP_OK;
 }
@@ -363,6 +395,7 @@ void free_grid(GridDev& g) {
   if (g.sidx) (void)hipFree(g.sidx);
   if (g.table) (void)hipFree(g.table);
   if (g.bvh) (void)hipFree(g.bvh);
+  if (g.wide) (void)hipFree(g.wide);
   g = GridDev();
 }
 
@@ -388,21 +421,29 @@ int run(mvicp_ctx* c, const std::vector<GridJob>& jobs, double bound) {
   scratch_reset(c);
   MV_CHECK(scratch_upload(c, jobs.data(), sizeof(GridJob) * jobs.size(), (void**)&d_jobs));
   unsigned long long* d_stats = nullptr;
-  if (c->profile) {
-    const unsigned long long z[3] = {0, 0, 0};
-    MV_CHECK(scratch_upload(c, z, sizeof(z), (void**)&d_stats));
+  const size_t slots = (size_t)((max_n + NT - 1) / NT) * jobs.size() * (NT / 64);
+  if (c->profile && c->nn_census) {
+    const size_t need = sizeof(unsigned long long) * 3 * (slots + 1);
+    if (need > c->census_bytes) {
+      if (c->d_census) MV_HIP(hipFree(c->d_census));
+      MV_HIP(hipMalloc((void**)&c->d_census, need));
+      c->census_bytes = need;
+    }
+    d_stats = (unsigned long long*)c->d_census;
+    MV_HIP(hipMemsetAsync(d_stats, 0, need, c->stream));
   }
   {
     ProfScope ps(c, "nn", (36.0 + (c->nn_tree_only ? 0.0 : 128.0)) * nq);  // query 24 B + result 12 B + 8 hash slots x 16 B; candidate bytes come from the census below
     if (c->nn_tree_only)
-      hipLaunchKernelGGL((nn_grid_kernel<true>), dim3((max_n + NT - 1) / NT, (unsigned)jobs.size()), dim3(NT), 0, c->stream, d_jobs, bound, d_stats);
+      hipLaunchKernelGGL((nn_grid_kernel<true>), dim3((max_n + NT - 1) / NT, (unsigned)jobs.size()), dim3(NT), 0, c->stream, d_jobs, bound, d_stats, 0);
     else
-      hipLaunchKernelGGL((nn_grid_kernel<false>), dim3((max_n + NT - 1) / NT, (unsigned)jobs.size()), dim3(NT), 0, c->stream, d_jobs, bound, d_stats);
+      hipLaunchKernelGGL((nn_grid_kernel<false>), dim3((max_n + NT - 1) / NT, (unsigned)jobs.size()), dim3(NT), 0, c->stream, d_jobs, bound, d_stats, c->nn_skip_far ? 1 : 0);
   }
   MV_HIP(hipGetLastError());
   if (d_stats) {
     unsigned long long st[3];
-    MV_HIP(hipMemcpyAsync(st, d_stats, sizeof(st), hipMemcpyDeviceToHost, c->stream));
+    hipLaunchKernelGGL(census_sum_kernel, dim3(1), dim3(256), 0, c->stream, d_stats, slots, d_stats + 3 * slots);
+    MV_HIP(hipMemcpyAsync(st, d_stats + 3 * slots, sizeof(st), hipMemcpyDeviceToHost, c->stream));
     MV_HIP(hipStreamSynchronize(c->stream));
     ProfEntry& pe = c->prof["nn"];
     pe.bytes += 28.0 * (double)st[0] + 24.0 * (double)st[1];  // candidates: 24 B xyz + 4 B index; tree nodes: 24 B AABB

@@ -1,0 +1,369 @@
+// K2t — wave-cooperative exact 1-NN: pruned brute force over LDS-staged target tiles.
+//
+// Same contract as K1/K2 (bit-exact indices and squared distances of the reference's
+// Frame::getClosestPoint, src/internal/frame.cpp:187-206, metric include/frame.h:70-76, query transform
+// frame.cpp:117-118,131,136; lowest original index wins exact ties).
+//
+// Both clouds are stored sorted by the Morton code of their grid cell (nn_grid.hip).  A WAVE owns 64
+// consecutive sorted source points — a compact surface patch — and answers all 64 queries together:
+//   * the target cloud is cut into leaves of 64 consecutive sorted points; leaf boxes, boxes of 64 leaves,
+//     boxes of 64 of those ... form a 64-wide hierarchy (float AABBs rounded outward, SoA per level) so one
+//     coalesced load hands every lane ONE child box of the current node;
+//   * a child is opened iff at least one lane still needs it: coarse cull = child box vs the patch's own
+//     AABB inflated by the largest running best (all children tested in parallel, one per lane), then an
+//     exact per-lane test `lb(q_lane, box) <= best_lane` (ballot).  lb uses the same rounded operations as the
+//     point distance, every rounding is monotone, hence lb <= d2 for every point inside: pruning is exact;
+//   * an opened leaf is staged once into LDS (coalesced) and every lane scans its 64 points from LDS
+//     (broadcast reads, conflict-free) keeping its running (d2, index) minimum — the K1 inner loop on a
+//     culled candidate set.  Children are opened nearest-first (wave arg-min by shuffles) so the running
+//     minima tighten before the siblings are tested.
+// No per-lane pointer chasing, no divergence between "near" and "far" queries: the round-1 regime
+// (centimetre misalignment) and the converged regime run the same code, the former just opens more leaves.
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <vector>
+
+#include "common.h"
+
+namespace mvicp {
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int LEAF = 32;   // points per leaf tile
+constexpr int FAN = 64;    // children per node = one box per lane
+
+struct TileView {
+  const double* spts; const int* sidx; int n;
+  const float* wide; int levels;  // number of box levels (>= 1)
+  int cnt[6]; long long off[6];
+  double maxabs;                  // largest |coordinate| in the cloud
+};
+
+struct TileJob {
+  TileView dst;
+  const double* q; const int* qidx; const double* xf; int n;
+  int* out_idx; double* out_d2;
+};
+
+__device__ __forceinline__ void xf_point(const double* __restrict__ x, double p0, double p1, double p2, double& q0, double& q1, double& q2) {
+  double g[3], u[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    g[i] = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(x[i], p0), __dmul_rn(x[i + 3], p1)), __dmul_rn(x[i + 6], p2)), x[9 + i]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) u[i] = __dsub_rn(g[i], x[21 + i]);
+  q0 = __dadd_rn(__dadd_rn(__dmul_rn(x[12 + 0], u[0]), __dmul_rn(x[12 + 3], u[1])), __dmul_rn(x[12 + 6], u[2]));
+  q1 = __dadd_rn(__dadd_rn(__dmul_rn(x[12 + 1], u[0]), __dmul_rn(x[12 + 4], u[1])), __dmul_rn(x[12 + 7], u[2]));
+  q2 = __dadd_rn(__dadd_rn(__dmul_rn(x[12 + 2], u[0]), __dmul_rn(x[12 + 5], u[1])), __dmul_rn(x[12 + 8], u[2]));
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fmax(v, __shfl_xor(v, d, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fmin(v, __shfl_xor(v, d, 64));
+  return v;
+}
+__device__ __forceinline__ float bcast(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+struct Lane {          // per-lane query state
+  double qx, qy, qz, best;
+  int bi;
+  bool active;
+};
+struct Group {         // wave-uniform patch description
+  double lo[3], hi[3], c[3];
+  float slack;         // fp32 screening guard band (metres)
+};
+
+// exact-order lower bound of the reference distance from q to any point in the box
+__device__ __forceinline__ double box_lb(const Lane& L, float b0, float b1, float b2, float b3, float b4, float b5) {
+  const double g0 = fmax(fmax(__dsub_rn((double)b0, L.qx), __dsub_rn(L.qx, (double)b3)), 0.0);
+  const double g1 = fmax(fmax(__dsub_rn((double)b1, L.qy), __dsub_rn(L.qy, (double)b4)), 0.0);
+  const double g2 = fmax(fmax(__dsub_rn((double)b2, L.qz), __dsub_rn(L.qz, (double)b5)), 0.0);
+  return __dadd_rn(__dadd_rn(__dmul_rn(g0, g0), __dmul_rn(g1, g1)), __dmul_rn(g2, g2));
+}
+
+// Scan one leaf tile for the whole wave.  The tile is staged once in LDS as fp64 (exact evaluation) AND fp32
+// (screening): a candidate is evaluated in the reference's fp64 arithmetic only if its fp32 distance is within
+// a rigorous guard band of the lane's running best — |sqrt(d32) - sqrt(d)| <= slack, where `slack` bounds the two
+// float conversions (2^-24 |coord| each, per axis) plus the fp32 rounding of the sum (relative 2^-22).  Everything
+// the screen rejects is provably farther than `best`, so the result is unchanged bit for bit.
+__device__ __forceinline__ void leaf_scan(const TileView& g, int leaf, Lane& L, float slack, double* __restrict__ sx, double* __restrict__ sy,
+                                          double* __restrict__ sz, float4* __restrict__ sf, unsigned long long* n_cand) {
+  const int lane = threadIdx.x & 63;
+  const int lo = leaf * LEAF;
+  const int cnt = min(LEAF, g.n - lo);
+  __builtin_amdgcn_wave_barrier();
+  if (lane < cnt) {
+    const double* p = g.spts + 3 * (size_t)(lo + lane);
+    const double x = p[0], y = p[1], z = p[2];
+    sx[lane] = x; sy[lane] = y; sz[lane] = z;
+    sf[lane] = make_float4((float)x, (float)y, (float)z, __int_as_float(g.sidx[lo + lane]));
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const float qx = (float)L.qx, qy = (float)L.qy, qz = (float)L.qz;
+  // screen threshold: (sqrt(best) + slack)^2 with 2^-20 relative head-room, recomputed when best improves
+  auto thr_of = [&](double best) {
+    const float rb = (float)sqrt(best) * 1.000001f + slack;
+    return rb * rb * 1.000002f;
+  };
+  float thr = thr_of(L.best);
+#pragma unroll 4
+  for (int k = 0; k < cnt; ++k) {
+    const float4 pf = sf[k];
+    const float e0 = qx - pf.x, e1 = qy - pf.y, e2 = qz - pf.z;
+    const float d32 = e0 * e0 + e1 * e1 + e2 * e2;
+    if (d32 <= thr) {
+      const double d0 = __dsub_rn(L.qx, sx[k]), d1 = __dsub_rn(L.qy, sy[k]), d2 = __dsub_rn(L.qz, sz[k]);
+      const double d = __dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2));
+      if (d <= L.best) {
+        const int oi = __float_as_int(pf.w);
+        if (d < L.best || oi < L.bi) { L.best = d; L.bi = oi; thr = thr_of(d); }
+      }
+    }
+  }
+  *n_cand += (unsigned)cnt;
+}
+
+// Test the `nchild` boxes [first, first + nchild) of level LEVEL (one per lane) and open what is needed.
+template <int LEVEL>
+__device__ void visit(const TileView& g, int first, int nchild, Lane& L, const Group& G, double* sx, double* sy, double* sz, float4* si,
+                      unsigned long long* n_cand, unsigned long long* n_box) {
+  const int lane = threadIdx.x & 63;
+  const float inf = __int_as_float(0x7f800000);
+  float b0 = inf, b1 = inf, b2 = inf, b3 = -inf, b4 = -inf, b5 = -inf;
+  if (lane < nchild) {
+    const float* base = g.wide + g.off[LEVEL] + first + lane;
+    const long long st = g.cnt[LEVEL];
+    b0 = base[0]; b1 = base[st]; b2 = base[2 * st]; b3 = base[3 * st]; b4 = base[4 * st]; b5 = base[5 * st];
+  }
+  // coarse cull: child box vs the patch AABB; valid for every lane because lb_lane >= box-box distance
+  double dd, key;
+  {
+    const double e0 = fmax(fmax((double)b0 - G.hi[0], G.lo[0] - (double)b3), 0.0);
+    const double e1 = fmax(fmax((double)b1 - G.hi[1], G.lo[1] - (double)b4), 0.0);
+    const double e2 = fmax(fmax((double)b2 - G.hi[2], G.lo[2] - (double)b5), 0.0);
+    dd = (e0 * e0 + e1 * e1 + e2 * e2) * (1.0 - 1e-12);
+    const double k0 = fmax(fmax((double)b0 - G.c[0], G.c[0] - (double)b3), 0.0);
+    const double k1 = fmax(fmax((double)b1 - G.c[1], G.c[1] - (double)b4), 0.0);
+    const double k2 = fmax(fmax((double)b2 - G.c[2], G.c[2] - (double)b5), 0.0);
+    key = k0 * k0 + k1 * k1 + k2 * k2;   // visiting order only
+  }
+  *n_box += (unsigned)nchild;
+  bool pend = lane < nchild;
+  while (true) {
+    const double gmax = wave_max(L.active ? L.best : -1.0);
+    pend = pend && dd <= gmax;
+    const unsigned long long mask = __ballot(pend);
+    if (mask == 0ull) break;
+    const double kmin = wave_min(pend ? key : 1.7976931348623157e308);
+    const unsigned long long pick = __ballot(pend && key == kmin);
+    const int c = __builtin_amdgcn_readfirstlane(__ffsll((long long)pick) - 1);
+    if (lane == c) pend = false;
+    const float c0 = bcast(b0, c), c1 = bcast(b1, c), c2 = bcast(b2, c), c3 = bcast(b3, c), c4 = bcast(b4, c), c5 = bcast(b5, c);
+    const double lb = box_lb(L, c0, c1, c2, c3, c4, c5);
+    if (__ballot(L.active && lb <= L.best) == 0ull) continue;
+    const int child = first + c;
+    if (LEVEL == 0) {
+      leaf_scan(g, child, L, G.slack, sx, sy, sz, si, n_cand);
+    } else {
+      const int cf = child * FAN;
+      visit<(LEVEL > 0 ? LEVEL - 1 : 0)>(g, cf, min(FAN, g.cnt[LEVEL > 0 ? LEVEL - 1 : 0] - cf), L, G, sx, sy, sz, si, n_cand, n_box);
+    }
+  }
+}
+
+__global__ __launch_bounds__(NT, 6) void nn_tile_kernel(const TileJob* __restrict__ jobs, double bound, unsigned long long* __restrict__ stats) {
+  __shared__ double s_x[NT / 64][LEAF], s_y[NT / 64][LEAF], s_z[NT / 64][LEAF];
+  __shared__ float4 s_i[NT / 64][LEAF];
+  __shared__ double sxf[kEdgeXf];
+  const TileJob& job = jobs[blockIdx.y];
+  if (blockIdx.x * NT >= job.n) return;
+  const bool has_xf = job.xf != nullptr;
+  if (has_xf && threadIdx.x < kEdgeXf) sxf[threadIdx.x] = job.xf[threadIdx.x];
+  __syncthreads();
+  const int wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * NT + threadIdx.x;
+  if ((i & ~63) >= job.n) return;  // whole wave beyond the end
+  const TileView& g = job.dst;
+
+  Lane L;
+  L.active = i < job.n;
+  L.best = bound; L.bi = 0x7fffffff;
+  L.qx = L.qy = L.qz = 0.0;
+  if (L.active) {
+    const double p0 = job.q[3 * (size_t)i], p1 = job.q[3 * (size_t)i + 1], p2 = job.q[3 * (size_t)i + 2];
+    if (has_xf) xf_point(sxf, p0, p1, p2, L.qx, L.qy, L.qz);
+    else { L.qx = p0; L.qy = p1; L.qz = p2; }
+  }
+  Group G;
+  {
+    const double big = 1.7976931348623157e308;
+    G.lo[0] = wave_min(L.active ? L.qx : big); G.hi[0] = wave_max(L.active ? L.qx : -big);
+    G.lo[1] = wave_min(L.active ? L.qy : big); G.hi[1] = wave_max(L.active ? L.qy : -big);
+    G.lo[2] = wave_min(L.active ? L.qz : big); G.hi[2] = wave_max(L.active ? L.qz : -big);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) G.c[a] = 0.5 * (G.lo[a] + G.hi[a]);
+    // largest coordinate magnitude either operand of a difference can have: the patch and the cloud's bounding box
+    double m = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) m = fmax(m, fmax(fmax(fabs(G.lo[a]), fabs(G.hi[a])), g.maxabs));
+    // per axis: |fl32(q) - q| + |fl32(p) - p| + rounding of the fp32 subtraction <= 3 * 2^-24 * m; x sqrt(3) axes, x2 safety
+    G.slack = (float)(m * (3.0 * 1.7320508 * 2.0 / 16777216.0)) + 1e-30f;
+  }
+  unsigned long long n_cand = 0, n_box = 0;
+  const int top = g.levels - 1;
+  double* sx = s_x[wave]; double* sy = s_y[wave]; double* sz = s_z[wave]; float4* si = s_i[wave];
+  switch (top) {
+    case 0: visit<0>(g, 0, g.cnt[0], L, G, sx, sy, sz, si, &n_cand, &n_box); break;
+    case 1: visit<1>(g, 0, g.cnt[1], L, G, sx, sy, sz, si, &n_cand, &n_box); break;
+    case 2: visit<2>(g, 0, g.cnt[2], L, G, sx, sy, sz, si, &n_cand, &n_box); break;
+    case 3: visit<3>(g, 0, g.cnt[3], L, G, sx, sy, sz, si, &n_cand, &n_box); break;
+    default: visit<4>(g, 0, g.cnt[4], L, G, sx, sy, sz, si, &n_cand, &n_box); break;
+  }
+  if (L.active) {
+    const int out = job.qidx ? job.qidx[i] : i;
+    job.out_idx[out] = L.bi == 0x7fffffff ? -1 : L.bi;
+    job.out_d2[out] = L.best;
+  }
+  if (stats && (threadIdx.x & 63) == 0) {
+    // wave-uniform counters: candidates examined PER LANE x active lanes, boxes tested per wave
+    const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + wave;
+    const unsigned long long act = (unsigned long long)min(64, job.n - (i & ~63));
+    stats[3 * slot] = n_cand; stats[3 * slot + 1] = n_box; stats[3 * slot + 2] = n_cand * act;
+  }
+}
+
+__global__ __launch_bounds__(256) void census_sum_kernel(const unsigned long long* __restrict__ stats, size_t slots, unsigned long long* __restrict__ out3) {
+  __shared__ unsigned long long sh[3][256];
+  unsigned long long a = 0, b = 0, c = 0;
+  for (size_t i = threadIdx.x; i < slots; i += 256) { a += stats[3 * i]; b += stats[3 * i + 1]; c += stats[3 * i + 2]; }
+  sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = b; sh[2][threadIdx.x] = c;
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    unsigned long long s = 0;
+    for (int i = 0; i < 256; ++i) s += sh[threadIdx.x][i];
+    out3[threadIdx.x] = s;
+  }
+}
+
+TileView view_of(const FrameDev& f) {
+  TileView v;
+  v.spts = f.grid.spts; v.sidx = f.grid.sidx; v.n = f.n;
+  v.wide = f.grid.wide; v.levels = f.grid.wide_levels;
+  for (int l = 0; l < 6; ++l) { v.cnt[l] = f.grid.wide_cnt[l]; v.off[l] = f.grid.wide_off[l]; }
+  v.maxabs = f.grid.maxabs;
+  return v;
+}
+
+}  // namespace
+
+int build_wide(FrameDev& f, const double* spts) {
+  GridDev& G = f.grid;
+  const int n = f.n;
+  const float finf = std::numeric_limits<float>::infinity();
+  auto down = [](double v) { float x = (float)v; if ((double)x > v) x = std::nextafterf(x, -std::numeric_limits<float>::infinity()); return x; };
+  auto up = [](double v) { float x = (float)v; if ((double)x < v) x = std::nextafterf(x, std::numeric_limits<float>::infinity()); return x; };
+  std::vector<std::vector<float>> lv;  // per level: 6 x cnt SoA
+  std::vector<int> cnts;
+  int cnt = (n + LEAF - 1) / LEAF;
+  {
+    std::vector<float> b(6 * (size_t)cnt);
+    for (int j = 0; j < cnt; ++j) {
+      float lo[3] = {finf, finf, finf}, hi[3] = {-finf, -finf, -finf};
+      for (int k = j * LEAF; k < std::min(n, (j + 1) * LEAF); ++k)
+        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], down(spts[3 * (size_t)k + a])); hi[a] = std::max(hi[a], up(spts[3 * (size_t)k + a])); }
+      for (int a = 0; a < 3; ++a) { b[(size_t)a * cnt + j] = lo[a]; b[(size_t)(3 + a) * cnt + j] = hi[a]; }
+    }
+    lv.push_back(b); cnts.push_back(cnt);
+  }
+  double maxabs = 0.0;
+  for (size_t k = 0; k < 3 * (size_t)n; ++k) maxabs = std::max(maxabs, std::fabs(spts[k]));
+  G.maxabs = maxabs;
+  while (cnt > FAN) {
+    const int pc = cnt;
+    cnt = (pc + FAN - 1) / FAN;
+    if (lv.size() >= 5) { set_error("cloud too large for the 64-wide hierarchy"); return MVICP_ERR_ARG; }
+    const std::vector<float>& p = lv.back();
+    std::vector<float> b(6 * (size_t)cnt);
+    for (int j = 0; j < cnt; ++j) {
+      float lo[3] = {finf, finf, finf}, hi[3] = {-finf, -finf, -finf};
+      for (int k = j * FAN; k < std::min(pc, (j + 1) * FAN); ++k)
+        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], p[(size_t)a * pc + k]); hi[a] = std::max(hi[a], p[(size_t)(3 + a) * pc + k]); }
+      for (int a = 0; a < 3; ++a) { b[(size_t)a * cnt + j] = lo[a]; b[(size_t)(3 + a) * cnt + j] = hi[a]; }
+    }
+    lv.push_back(b); cnts.push_back(cnt);
+  }
+  size_t total = 0;
+  for (size_t l = 0; l < lv.size(); ++l) { G.wide_off[l] = (long long)total; G.wide_cnt[l] = cnts[l]; total += lv[l].size(); }
+  G.wide_levels = (int)lv.size();
+  std::vector<float> flat(total);
+  for (size_t l = 0; l < lv.size(); ++l) std::copy(lv[l].begin(), lv[l].end(), flat.begin() + G.wide_off[l]);
+  MV_HIP(hipMalloc((void**)&G.wide, sizeof(float) * std::max<size_t>(total, 1)));
+  MV_HIP(hipMemcpy(G.wide, flat.data(), sizeof(float) * total, hipMemcpyHostToDevice));
+  return MVICP_OK;
+}
+
+int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound) {
+  std::vector<TileJob> jobs;
+  int max_n = 0;
+  double nq = 0;
+  for (int e = 0; e < c->E; ++e) {
+    if (!c->active[e]) continue;
+    const FrameDev& s = c->frames[c->esrc[e]];
+    const FrameDev& d = c->frames[c->edst[e]];
+    if (!s.has_grid || !d.has_grid) { set_error("tile NN needs the per-cloud structure on frames %d and %d", c->esrc[e], c->edst[e]); return MVICP_ERR_STATE; }
+    TileJob j;
+    j.dst = view_of(d);
+    j.q = s.grid.spts; j.qidx = s.grid.sidx; j.xf = c->d_xf + (size_t)e * kEdgeXf; j.n = s.n;
+    j.out_idx = c->d_nn_idx + c->cap_off[e]; j.out_d2 = c->d_nn_d2 + c->cap_off[e];
+    jobs.push_back(j);
+    max_n = std::max(max_n, s.n);
+    nq += s.n;
+  }
+  if (jobs.empty() || max_n == 0) return MVICP_OK;
+  TileJob* d_jobs = nullptr;
+  scratch_reset(c);
+  MV_CHECK(scratch_upload(c, jobs.data(), sizeof(TileJob) * jobs.size(), (void**)&d_jobs));
+  unsigned long long* d_stats = nullptr;
+  const size_t slots = (size_t)((max_n + NT - 1) / NT) * jobs.size() * (NT / 64);
+  if (c->profile && c->nn_census) {
+    const size_t need = sizeof(unsigned long long) * 3 * (slots + 1);
+    if (need > c->census_bytes) {
+      if (c->d_census) MV_HIP(hipFree(c->d_census));
+      MV_HIP(hipMalloc((void**)&c->d_census, need));
+      c->census_bytes = need;
+    }
+    d_stats = (unsigned long long*)c->d_census;
+    MV_HIP(hipMemsetAsync(d_stats, 0, need, c->stream));
+  }
+  {
+    ProfScope ps(c, "nn", 36.0 * nq);  // query read 24 B + result write 12 B; candidate / box bytes come from the census
+    hipLaunchKernelGGL(nn_tile_kernel, dim3((max_n + NT - 1) / NT, (unsigned)jobs.size()), dim3(NT), 0, c->stream, d_jobs, d2_bound, d_stats);
+  }
+  MV_HIP(hipGetLastError());
+  if (d_stats) {
+    unsigned long long st[3];
+    hipLaunchKernelGGL(census_sum_kernel, dim3(1), dim3(256), 0, c->stream, d_stats, slots, d_stats + 3 * slots);
+    MV_HIP(hipMemcpyAsync(st, d_stats + 3 * slots, sizeof(st), hipMemcpyDeviceToHost, c->stream));
+    MV_HIP(hipStreamSynchronize(c->stream));
+    ProfEntry& pe = c->prof["nn"];
+    // memory-side algorithmic bytes: every opened tile is loaded ONCE per wave (24 B xyz + 4 B index per point) and
+    // every tested box once per wave (24 B); the per-lane distance evaluations (st[2]) are served from LDS.
+    pe.bytes += 28.0 * (double)st[0] + 24.0 * (double)st[1];
+    c->nn_candidates += (double)st[2]; c->nn_nodes += (double)st[1]; c->nn_queries += nq;
+  }
+  return MVICP_OK;
+}
+
+}  // namespace mvicp

@@ -92,28 +92,38 @@ struct Assembler {
   }
 };
 
-bool cholesky_solve(std::vector<double>& A, int n, const double* b, double* y) {
-  for (int j = 0; j < n; ++j) {
-    double d = A[(size_t)j * n + j];
-    for (int k = 0; k < j; ++k) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
-    if (!(d > 0.0) || !std::isfinite(d)) return false;
-    d = std::sqrt(d);
-    A[(size_t)j * n + j] = d;
-    for (int i = j + 1; i < n; ++i) {
-      double v = A[(size_t)i * n + j];
-      for (int k = 0; k < j; ++k) v -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
-      A[(size_t)i * n + j] = v / d;
+// Envelope (skyline) Cholesky: row i of the lower triangle is only touched from its first structural non-zero
+// column env[i]; fill-in stays inside the envelope.  The pose graph of a turntable sequence (knn ring neighbours,
+// frame 0 eliminated) is block-banded, so the factorisation costs O(n b^2) instead of O(n^3 / 3); for an arbitrary
+// graph the envelope degenerates to the dense triangle and this is plain dense Cholesky.  (The reference hands the
+// same system to Ceres' SPARSE_NORMAL_CHOLESKY, icp-ceres.cpp:76.)
+bool cholesky_solve(std::vector<double>& A, int n, const int* env, const double* b, double* y) {
+  for (int i = 0; i < n; ++i) {
+    double* Ai = &A[(size_t)i * n];
+    for (int j = env[i]; j <= i; ++j) {
+      const double* Aj = &A[(size_t)j * n];
+      const int k0 = std::max(env[i], env[j]);
+      double v = Ai[j];
+      for (int k = k0; k < j; ++k) v -= Ai[k] * Aj[k];
+      if (j < i) {
+        Ai[j] = v / Aj[j];
+      } else {
+        if (!(v > 0.0) || !std::isfinite(v)) return false;
+        Ai[i] = std::sqrt(v);
+      }
     }
   }
   for (int i = 0; i < n; ++i) {
+    const double* Ai = &A[(size_t)i * n];
     double v = b[i];
-    for (int k = 0; k < i; ++k) v -= A[(size_t)i * n + k] * y[k];
-    y[i] = v / A[(size_t)i * n + i];
+    for (int k = env[i]; k < i; ++k) v -= Ai[k] * y[k];
+    y[i] = v / Ai[i];
   }
   for (int i = n - 1; i >= 0; --i) {
-    double v = y[i];
-    for (int k = i + 1; k < n; ++k) v -= A[(size_t)k * n + i] * y[k];
-    y[i] = v / A[(size_t)i * n + i];
+    y[i] /= A[(size_t)i * n + i];
+    const double yi = y[i];
+    const double* Ai = &A[(size_t)i * n];
+    for (int k = env[i]; k < i; ++k) y[k] -= Ai[k] * yi;
   }
   for (int i = 0; i < n; ++i) if (!std::isfinite(y[i])) return false;
   return true;
@@ -143,6 +153,18 @@ int lm_solve(int K, int E, const int* src, const int* dst, double* poses, unsign
   auto xnorm = [&](const std::vector<double>& v) { double s = 0; for (int i = 0; i < K; ++i) if (!fixed[i]) for (int a = 0; a < A; ++a) s += v[i * A + a] * v[i * A + a]; return std::sqrt(s); };
 
   std::vector<double> H((size_t)n * n), g(n), Hn((size_t)n * n), gn(n), scale(n), Hs((size_t)n * n), gs(n), diag(n), Aw, step(n), delta(n);
+  // structural envelope of the normal matrix from the pose graph: block row b starts at its lowest-numbered neighbour
+  std::vector<int> env(n);
+  {
+    std::vector<int> first(as.nfree);
+    for (int b = 0; b < as.nfree; ++b) first[b] = b;
+    for (int e = 0; e < E; ++e) {
+      const int a = as.fidx[src[e]], b = as.fidx[dst[e]];
+      if (a < 0 || b < 0) continue;
+      first[std::max(a, b)] = std::min(first[std::max(a, b)], std::min(a, b));
+    }
+    for (int b = 0; b < as.nfree; ++b) for (int l = 0; l < 6; ++l) env[b * 6 + l] = first[b] * 6;
+  }
   poses_of(x, pc.data());
   MV_CHECK(eval(user, pc.data(), blocks.data()));
   sm->evaluations = 1;
@@ -167,7 +189,7 @@ int lm_solve(int K, int E, const int* src, const int* dst, double* poses, unsign
     if (!reuse_diagonal) for (int i = 0; i < n; ++i) diag[i] = std::min(std::max(Hs[(size_t)i * n + i], min_diag), max_diag);
     Aw = Hs;
     for (int i = 0; i < n; ++i) Aw[(size_t)i * n + i] += diag[i] / radius;
-    bool valid = cholesky_solve(Aw, n, gs.data(), step.data());
+    bool valid = cholesky_solve(Aw, n, env.data(), gs.data(), step.data());
     reuse_diagonal = true;
     double model_cost_change = 0.0;
     if (valid) {

@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libmvicp_hip.so")
 
 PARAM_EIGEN_QUATERNION, PARAM_ANGLE_AXIS, PARAM_SOPHUS_SE3 = 0, 1, 2
-NN_AUTO, NN_BRUTE, NN_GRID = 0, 1, 2
+NN_AUTO, NN_BRUTE, NN_GRID, NN_TILE = 0, 1, 2, 3
 EDGE_BLOCK = 91
 
 SYMBOLS = [

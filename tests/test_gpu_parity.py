@@ -14,7 +14,7 @@ from mvicp import synth
 pytestmark = pytest.mark.gpu
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "bunny_nn.npz"))
 TREE = 102  # NN_GRID with the hash fast path disabled: every query takes the exact AABB-tree descent
-METHODS = [L.NN_BRUTE, L.NN_GRID, TREE]
+METHODS = [L.NN_BRUTE, L.NN_GRID, TREE, L.NN_TILE]
 
 
 class _Eng(mvicp.Engine):
@@ -132,6 +132,7 @@ def test_correspond_ragged_sizes_and_fixed_sources(eng, orc):
     check_correspond(eng, orc, pts, nor, pb["init"], [1, 0, 0], src, dst, 0.05, L.NN_BRUTE)
     check_correspond(eng, orc, pts, nor, pb["init"], [1, 0, 1], src, dst, 0.05, L.NN_GRID)
     check_correspond(eng, orc, pts, nor, pb["init"], [1, 0, 0], src, dst, 0.05, TREE)
+    check_correspond(eng, orc, pts, nor, pb["init"], [1, 0, 0], src, dst, 0.05, L.NN_TILE)
 
 
 def test_grid_far_queries_and_clustered_clouds(eng, orc):
@@ -283,7 +284,7 @@ def test_full_size_properties_cfg2(eng):
         assert np.array_equal(idx, np.arange(20000)) and np.all(d2 == 0)
     c1, w1 = eng.correspond(pb["init"], pb["fixed"], 0.05, L.NN_BRUTE)
     a = eng.get_correspondences(0)
-    for m in (L.NN_GRID, TREE):
+    for m in (L.NN_GRID, TREE, L.NN_TILE):
         c2, w2 = eng.correspond(pb["init"], pb["fixed"], 0.05, m)
         b = eng.get_correspondences(0)
         assert c1[0] == c2[0] and w1[0] == w2[0] and all(np.array_equal(x, y) for x, y in zip(a, b)), m

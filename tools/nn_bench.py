@@ -17,14 +17,19 @@ for tgt in targets:
     eng.set_graph(pb["src"], pb["dst"])
     eng.profile(True)
     for name, poses in (("init", pb["init"]), ("gt", pb["gt"])):
-        for mode in ("grid", "tree"):
-            eng.set_option("nn_tree_only", 1 if mode == "tree" else 0)
-            eng.correspond(poses, pb["fixed"], 0.05, L.NN_GRID)
+        for mode in ("grid", "tile"):
+            M = L.NN_TILE if mode == "tile" else L.NN_GRID
+            eng.set_option("nn_census", 1)
+            eng.profile_reset()
+            eng.correspond(poses, pb["fixed"], 0.05, M)
+            _, _, b1 = eng.profile_get("nn")
+            c = eng.nn_census()
+            eng.set_option("nn_census", 0)
             eng.profile_reset()
             for _ in range(3):
-                eng.correspond(poses, pb["fixed"], 0.05, L.NN_GRID)
+                eng.correspond(poses, pb["fixed"], 0.05, M)
             ms, n, b = eng.profile_get("nn")
-            c = eng.nn_census()
-            q = c["queries"] / 3
-            print(f"target {tgt:4.1f} {name:4s} {mode:4s}: {ms/n:8.3f} ms  {q/(ms/n)/1e6:8.1f} Mq/s  cand/q {c['candidates']/c['queries']:6.1f} nodes/q {c['nodes']/c['queries']:6.1f} far {c['far']/c['queries']:.3f}  alg {b/n/(ms/n)/1e6:8.1f} GB/s")
+            b = b1 * n
+            q = c["queries"]
+            print(f"target {tgt:4.1f} {name:4s} {mode:4s}: {ms/n:8.3f} ms  {q/(ms/n)/1e3:8.1f} Mq/s  cand/q {c['candidates']/c['queries']:6.1f} nodes/q {c['nodes']/c['queries']:6.1f} far {c['far']/c['queries']:.3f}  alg {b/n/(ms/n)/1e6:8.1f} GB/s")
     eng.close()
