@@ -295,3 +295,50 @@ def test_full_size_properties_cfg2(eng):
     blk2 = eng.linearize(moved, 1, 1)
     scale = np.abs(blk[0, :78]).max()
     assert np.allclose(blk, blk2, rtol=1e-9, atol=1e-12 * scale)
+
+
+# ---------------------------------------------------------------- multi-GPU plumbing that a 1-GPU box can exercise
+def test_rccl_communicator_single_rank(orc):
+    """RCCL path with world = 1: the all-reduce of the per-edge blocks and of the counts/medians must be an exact
+    identity (the real N > 1 exchange is covered by tests/test_gloo_shard.py on CPU and by the driver's 8-GPU run)."""
+    import torch
+    rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    rccl = rccl if os.path.exists(rccl) else None
+    pb = synth.make_problem(3, 3000)
+    a = mvicp.Engine(0)
+    a.set_frames(pb["pts"], pb["nor"]); a.set_graph(pb["src"], pb["dst"])
+    ca, wa = a.correspond(pb["init"], pb["fixed"], 0.05)
+    ba = a.linearize(pb["init"], 1, 1)
+    b = mvicp.Engine(0, rank=0, world=1)
+    b.set_frames(pb["pts"], pb["nor"]); b.set_graph(pb["src"], pb["dst"])
+    b.comm_init(mvicp.Engine.comm_unique_id(rccl), rccl)
+    cb, wb = b.correspond(pb["init"], pb["fixed"], 0.05)
+    bb = b.linearize(pb["init"], 1, 1)
+    assert np.array_equal(ca, cb) and np.array_equal(wa, wb) and np.array_equal(ba, bb)
+    Pa, _ = a.optimize(pb["init"], pb["fixed"]); Pb, _ = b.optimize(pb["init"], pb["fixed"])
+    assert np.array_equal(Pa, Pb)
+    a.close(); b.close()
+
+
+def test_sharded_contexts_sum_to_the_unsharded_blocks():
+    """Two contexts on one GPU playing rank 0 and rank 1 of a 2-way shard: each fills only its owned edge slots
+    (zeros elsewhere); their sum equals the single-context blocks BIT FOR BIT — the property that makes the RCCL
+    sum exact and the poses independent of the GPU count."""
+    pb = synth.make_problem(5, 5000)
+    full = mvicp.Engine(0)
+    full.set_frames(pb["pts"], pb["nor"]); full.set_graph(pb["src"], pb["dst"])
+    cf, wf = full.correspond(pb["init"], pb["fixed"], 0.05)
+    bf = full.linearize(pb["init"], 1, 1)
+    parts, counts = [], []
+    for r in range(2):
+        e = mvicp.Engine(0, rank=r, world=2)
+        e.set_frames(pb["pts"], pb["nor"]); e.set_graph(pb["src"], pb["dst"])
+        c, w = e.correspond(pb["init"], pb["fixed"], 0.05)
+        parts.append(e.linearize(pb["init"], 1, 1)); counts.append(c)
+        e.close()
+    own = L.edge_owner([len(pb["pts"][s]) for s in pb["src"]], 2)
+    for e in range(len(own)):
+        assert np.all(parts[1 - own[e]][e] == 0)
+    assert np.array_equal(parts[0] + parts[1], bf)
+    assert np.array_equal(counts[0] + counts[1], cf)
+    full.close()
