@@ -166,8 +166,34 @@ def main():
         elapsed = float(tt.item())
 
     prof = {k: eng.profile_get(k) for k in ("nn", "compact", "gather", "select", "linearize", "reduce")}
+    # NN candidate census: ONE extra correspondence pass at the final poses, outside the timed region (the counters
+    # cost a little, so they are off while timing).  Its per-query byte figure prices every timed launch.
+    eng.set_option("nn_census", 1)
+    eng.profile_reset()
+    eng.correspond(poses, pb["fixed"], 0.05, method)
+    _, _, nn_bytes_census = eng.profile_get("nn")
     census = eng.nn_census()
+    eng.set_option("nn_census", 0)
     eng.profile(False)
+    if prof["nn"][1]:
+        prof["nn"] = (prof["nn"][0], prof["nn"][1], nn_bytes_census * prof["nn"][1])
+
+    def pmc_traffic(name):
+        """HBM bytes per launch from the committed rocprofv3 PMC passes of THIS workload (tools/profile.sh): separate
+        --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled for the 16-B/lane coalesced linearize stream as
+        MI355X_MICROARCH.md §HBM prescribes for gfx950; other access patterns are uncalibrated and reported raw."""
+        path = os.path.join(ROOT, "profiles", f"r01_{args.workload}_{'grid' if args.nn in ('auto', 'grid') else args.nn}_kernels.json")
+        if world != 1 or not os.path.exists(path):
+            return None
+        try:
+            kern = json.load(open(path))["kernels"]
+            key = {"linearize": "linearize_kernel<true, true>" if plane else "linearize_kernel<false, true>",
+                   "nn": {"grid": "nn_grid_kernel<false>", "auto": "nn_grid_kernel<false>", "tile": "nn_tile_kernel", "brute": "nn_brute_kernel"}[args.nn]}[name]
+            k = kern[key]
+            fetch = k["FETCH_SIZE_KiB"] * (2.0 if name == "linearize" else 1.0)
+            return (fetch + k["WRITE_SIZE_KiB"]) * 1024.0
+        except Exception:
+            return None
 
     def roof(name):
         ms, n, b = prof[name]
@@ -175,7 +201,7 @@ def main():
             return None
         ach = (b / n) / (ms / n * 1e-3) / 1e9
         return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": None, "launches": n, "avg_us": ms / n * 1e3, "alg_bytes_per_launch": b / n}
+                "traffic": pmc_traffic(name), "launches": n, "avg_us": ms / n * 1e3, "alg_bytes_per_launch": b / n}
 
     dominant = max(("nn", "linearize"), key=lambda k: prof[k][0])
     err_t = max(synth.pose_diff(poses[k], pb["gt"][k])[0] for k in range(K))
