@@ -372,7 +372,19 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
 
   const double bound = sqrt_bound((double)thresh);
   int method = nn_method;
-  if (method == MVICP_NN_AUTO) method = MVICP_NN_GRID;
+  if (method == MVICP_NN_AUTO) {
+    // Per-lane hash lookups win once the clouds are aligned to within a fraction of a hash cell; while the typical
+    // NN distance is still comparable to the cell edge (first rounds) nearly every query falls through to the tree
+    // and the wave-cooperative tile kernel is several times faster.  Signal: last round's median distances.
+    method = MVICP_NN_TILE;
+    if (c->have_corr) {
+      double dist = 0.0, cell = 0.0;
+      int m = 0;
+      for (int e = 0; e < E; ++e)
+        if (c->h_count[e] > 0) { dist += c->h_weight[e] / 1.5; cell += c->frames[c->edst[e]].grid.cell; ++m; }
+      if (m > 0 && dist < 0.5 * cell) method = MVICP_NN_GRID;
+    }
+  }
   if (method == MVICP_NN_GRID || method == MVICP_NN_TILE) {
     for (int e = 0; e < E; ++e)
       if (c->active[e] && (!c->frames[c->edst[e]].has_grid || !c->frames[c->esrc[e]].has_grid)) method = MVICP_NN_BRUTE;

@@ -43,6 +43,7 @@ struct GridDev {
   int n_cells = 0;             // occupied cells
   double* spts = nullptr;      // n x 3 sorted by Morton(cell)
   int* sidx = nullptr;         // n: original index of sorted point
+  void* srec = nullptr;        // n x 32 B {x, y, z, idx}: the same, packed for the per-lane candidate scans
   void* table = nullptr;       // open-addressing hash: cell -> (start, count), 16-B entries
   unsigned int table_mask = 0; int table_shift = 0;
   float* bvh = nullptr;        // implicit complete AABB tree, 6 floats per node (outward rounded)

@@ -42,8 +42,10 @@ constexpr unsigned long long EMPTY = ~0ull;
 
 struct HashEntry { unsigned long long key; unsigned int start, count; };
 
+struct PointRec { double x, y, z; long long idx; };  // 32-B aligned sorted point + original index
+
 struct GridView {  // device view of one cloud's structure
-  const double* spts; const int* sidx; int n;
+  const double* spts; const int* sidx; const PointRec* srec; int n;
   const HashEntry* table; unsigned int mask; int shift;
   double ox, oy, oz, h, inv_h;
   int dx, dy, dz;
@@ -91,11 +93,13 @@ __device__ __forceinline__ double box_lb(double qx, double qy, double qz, const 
 }
 
 __device__ __forceinline__ void scan_range(const GridView& g, int lo, int hi, double qx, double qy, double qz, double& best, int& bi) {
+#pragma unroll 2
   for (int j = lo; j < hi; ++j) {
-    const double* p = g.spts + 3 * (size_t)j;
-    const double d = dist2(qx, qy, qz, p[0], p[1], p[2]);
+    const double2* p = reinterpret_cast<const double2*>(g.srec + j);  // two 16-B loads per candidate
+    const double2 a = p[0], b = p[1];
+    const double d = dist2(qx, qy, qz, a.x, a.y, b.x);
     if (d <= best) {
-      const int oi = g.sidx[j];
+      const int oi = (int)__double_as_longlong(b.y);
       if (d < best || oi < bi) { best = d; bi = oi; }
     }
   }
@@ -149,22 +153,34 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
     // queries far outside the grid cannot be resolved by the block test; clamp so the int conversion is safe
     const double lim = 2.0e6;
     const int bx = (int)floor(fmin(fmax(cx, -lim), lim)), by = (int)floor(fmin(fmax(cy, -lim), lim)), bz = (int)floor(fmin(fmax(cz, -lim), lim));
+    // all 8 first probes are issued together (independent 16-B loads), collisions are resolved afterwards
+    unsigned long long key[8];
+    unsigned int slot[8];
+    HashEntry ent[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const int ix = bx + (c & 1), iy = by + ((c >> 1) & 1), iz = bz + (c >> 2);
-      if (ix < 0 || iy < 0 || iz < 0 || ix >= g.dx || iy >= g.dy || iz >= g.dz) continue;
-      const unsigned long long key = cell_key(ix, iy, iz);
-      unsigned int slot = hash_slot(key, g.shift);
-      while (true) {
-        const HashEntry e = g.table[slot];
-        if (e.key == key) {
-          scan_range(g, (int)e.start, (int)(e.start + e.count), qx, qy, qz, best, bi);
-          n_cand += e.count;
-          break;
-        }
-        if (e.key == EMPTY) break;
-        slot = (slot + 1) & g.mask;
+      const bool in = !(ix < 0 || iy < 0 || iz < 0 || ix >= g.dx || iy >= g.dy || iz >= g.dz);
+      key[c] = in ? cell_key(ix, iy, iz) : EMPTY;
+      slot[c] = hash_slot(key[c], g.shift) & g.mask;
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      ent[c].key = EMPTY; ent[c].start = 0; ent[c].count = 0;
+      if (key[c] != EMPTY) ent[c] = g.table[slot[c]];
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      while (ent[c].key != key[c] && ent[c].key != EMPTY) {
+        slot[c] = (slot[c] + 1) & g.mask;
+        ent[c] = g.table[slot[c]];
       }
+      if (ent[c].key == EMPTY) ent[c].count = 0;
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      scan_range(g, (int)ent[c].start, (int)(ent[c].start + ent[c].count), qx, qy, qz, best, bi);
+      n_cand += ent[c].count;
     }
     // every point outside the block differs from q by at least `m` along some axis (cells are assigned with
     // the same rounded expression; 0.1 % slack dwarfs any rounding in it)
@@ -376,6 +392,12 @@ int build_grid(mvicp_ctx* c, FrameDev& f, const double* xyz) {
   G.cell = g.h; G.inv_cell = g.inv_h;
   G.n_cells = (int)runs.size();
   G.table_mask = mask; G.table_shift = shift; G.depth = D;
+  {
+    std::vector<PointRec> rec(n);
+    for (int i = 0; i < n; ++i) { rec[i].x = spts[3 * (size_t)i]; rec[i].y = spts[3 * (size_t)i + 1]; rec[i].z = spts[3 * (size_t)i + 2]; rec[i].idx = order[i]; }
+    MV_HIP(hipMalloc((void**)&G.srec, sizeof(PointRec) * (size_t)std::max(n, 1)));
+    MV_HIP(hipMemcpy(G.srec, rec.data(), sizeof(PointRec) * (size_t)n, hipMemcpyHostToDevice));
+  }
   MV_HIP(hipMalloc((void**)&G.spts, sizeof(double) * 3 * (size_t)n));
   MV_HIP(hipMalloc((void**)&G.sidx, sizeof(int) * (size_t)n));
   MV_HIP(hipMalloc((void**)&G.table, sizeof(HashEntry) * (size_t)tsize));
@@ -393,6 +415,7 @@ int build_grid(mvicp_ctx* c, FrameDev& f, const double* xyz) {
 void free_grid(GridDev& g) {
   if (g.spts) (void)hipFree(g.spts);
   if (g.sidx) (void)hipFree(g.sidx);
+  if (g.srec) (void)hipFree(g.srec);
   if (g.table) (void)hipFree(g.table);
   if (g.bvh) (void)hipFree(g.bvh);
   if (g.wide) (void)hipFree(g.wide);
@@ -403,7 +426,7 @@ namespace {
 GridView view_of(const FrameDev& f) {
   GridView v;
   const GridDev& g = f.grid;
-  v.spts = g.spts; v.sidx = g.sidx; v.n = f.n;
+  v.spts = g.spts; v.sidx = g.sidx; v.srec = (const PointRec*)g.srec; v.n = f.n;
   v.table = (const HashEntry*)g.table; v.mask = g.table_mask; v.shift = g.table_shift;
   v.ox = g.origin[0]; v.oy = g.origin[1]; v.oz = g.origin[2]; v.h = g.cell; v.inv_h = g.inv_cell;
   v.dx = g.dims[0]; v.dy = g.dims[1]; v.dz = g.dims[2];
