@@ -1,0 +1,110 @@
+// The reference's harness utilities the headless drivers need (include/common.h): on-disk formats, pose noise,
+// pose comparison, directory listing.  Own code; semantics cited per function.
+#pragma once
+#include <dirent.h>
+
+#include <algorithm>
+#include <cmath>
+#include <fstream>
+#include <iostream>
+#include <random>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "linalg.h"
+#include "se3.h"
+
+namespace mvicp {
+
+// common.h:224-239: `x y z nx ny nz` per row.  The reference's read loop pushes one extra element after the last
+// row (the stream only fails on the NEXT extraction); keep_phantom reproduces that element with the C++11 stream
+// semantics (first field zeroed, the others keep the previous row's values), default drops it.
+inline bool loadXYZ(const std::string& filename, std::vector<Vector3d>& pts, std::vector<Vector3d>& nor, bool keep_phantom = false) {
+  std::ifstream file(filename.c_str());
+  if (file.fail()) { std::cerr << filename << " could not be opened" << std::endl; return false; }
+  double a[6] = {0, 0, 0, 0, 0, 0};
+  while (true) {
+    double b[6];
+    bool ok = true;
+    for (int i = 0; i < 6 && ok; ++i) ok = static_cast<bool>(file >> b[i]);
+    if (!ok) break;
+    std::copy(b, b + 6, a);
+    pts.push_back(Vector3d(a[0], a[1], a[2]));
+    nor.push_back(Vector3d(a[3], a[4], a[5]));
+  }
+  if (keep_phantom && !pts.empty()) { pts.push_back(Vector3d(0.0, a[1], a[2])); nor.push_back(Vector3d(a[3], a[4], a[5])); }
+  return true;
+}
+
+// common.h:172-187: up to 16 numbers, row-major 4x4; missing entries keep [..0, 1].
+inline Isometry3d loadMatrix4d(const std::string& filename) {
+  Isometry3d P;
+  std::ifstream file(filename.c_str());
+  if (file.fail()) { std::cerr << filename << " could not be opened" << std::endl; for (double& v : P.m) v = 0.0; return P; }
+  double a[16] = {0};
+  a[15] = 1;
+  int i = 0;
+  while (i < 16 && (file >> a[i])) ++i;
+  for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) P(r, c) = a[4 * r + c];
+  return P;
+}
+inline void saveMatrix4d(const std::string& filename, const Isometry3d& P) {
+  std::ofstream f(filename.c_str());
+  f.precision(17);
+  for (int r = 0; r < 4; ++r) { for (int c = 0; c < 4; ++c) f << (c ? " " : "") << P(r, c); f << "\n"; }
+}
+
+// common.h:36-67: file-scope default-seeded std::mt19937 + std::normal_distribution<double>(0,1); draw order w then t;
+// noisyPose = pose * Exp(sigma w) (rotation appended on the right), translation += sigmat t.
+inline std::mt19937& noiseGenerator() { static std::mt19937 g; return g; }
+inline Isometry3d addNoise(const Isometry3d& pose, double sigma, double sigmat) {
+  std::normal_distribution<double> normal(0.0, 1.0);
+  std::mt19937& gen = noiseGenerator();
+  double w[3] = {normal(gen), normal(gen), normal(gen)};
+  for (double& x : w) x *= sigma;
+  double Rw[9];
+  se3::aa_to_R(w, Rw);  // SO3::exp(w)
+  Isometry3d out = pose;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) out(i, j) = pose(i, 0) * Rw[0 + 3 * j] + pose(i, 1) * Rw[1 + 3 * j] + pose(i, 2) * Rw[2 + 3 * j];
+  double t[3] = {normal(gen), normal(gen), normal(gen)};
+  for (int i = 0; i < 3; ++i) out.m[12 + i] = pose.m[12 + i] + t[i] * sigmat;
+  return out;
+}
+
+// common.h:259-282: translation distance and acos(2 <q1,q2>^2 - 1) in degrees.
+inline void poseDiffValues(const Isometry3d& P1, const Isometry3d& P2, double* diff_tra, double* diff_rot_degrees) {
+  double R1[9], R2[9], q1[4], q2[4];
+  se3::pose_R(P1.data(), R1); se3::pose_R(P2.data(), R2);
+  se3::R_to_quat(R1, q1); se3::R_to_quat(R2, q2);
+  *diff_tra = (P1.translation() - P2.translation()).norm();
+  const double d = q1[0] * q2[0] + q1[1] * q2[1] + q1[2] * q2[2] + q1[3] * q2[3];
+  double val = 2 * d * d - 1;
+  val = std::min(1.0, std::max(-1.0, val));
+  *diff_rot_degrees = std::acos(val) * 180.0 / M_PI;
+}
+inline std::string poseDiff(const Isometry3d& P1, const Isometry3d& P2) {
+  double a, b;
+  poseDiffValues(P1, P2, &a, &b);
+  std::stringstream ss;
+  ss << "\t diff_tra:" << a << "\t diff_rot_degrees:" << b << std::endl;
+  return ss.str();
+}
+
+// common.h:119-170: files starting with `prefix` and ending in .txt/.xyz, sorted by length then lexicographically.
+inline std::vector<std::string> getAllTextFilesFromFolder(const std::string& dirStr, const std::string& prefix) {
+  std::vector<std::string> out;
+  DIR* dir = opendir(dirStr.c_str());
+  if (!dir) { std::cerr << "Could not open directory " << dirStr << std::endl; return out; }
+  while (dirent* entry = readdir(dir)) {
+    const std::string name(entry->d_name);
+    auto ends = [&](const char* suf) { const std::string s(suf); return name.size() >= s.size() && name.compare(name.size() - s.size(), s.size(), s) == 0; };
+    if (name.compare(0, prefix.size(), prefix) == 0 && (ends(".txt") || ends(".xyz"))) out.push_back(dirStr + "/" + name);
+  }
+  closedir(dir);
+  std::sort(out.begin(), out.end(), [](const std::string& l, const std::string& r) { return l.size() != r.size() ? l.size() < r.size() : l < r; });
+  return out;
+}
+
+}  // namespace mvicp

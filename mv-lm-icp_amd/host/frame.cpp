@@ -1,0 +1,184 @@
+// Implementation of the Frame / ICP_Ceres mirror (host/frame.h) over the C ABI.
+#include "frame.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <stdexcept>
+
+namespace mvicp {
+
+static void check(int st) {
+  if (st < 0) throw std::runtime_error(std::string("mvicp: ") + mvicp_last_error());
+}
+
+Session& Session::get() {
+  static Session s;
+  return s;
+}
+
+void Session::reset() {
+  if (ctx) mvicp_destroy(ctx);
+  ctx = nullptr;
+  frames_key = nullptr;
+  last_poses.clear();
+}
+
+void Session::bind(std::vector<std::shared_ptr<Frame>>& frames) {
+  // graph in the reference's loop order: src ascending, neighbour order (main_multiview.cpp:119-127)
+  std::vector<int> s, d;
+  for (size_t i = 0; i < frames.size(); ++i)
+    for (const OutgoingEdge& e : frames[i]->neighbours) { s.push_back((int)i); d.push_back(e.neighbourIdx); }
+  if (ctx && frames_key == (const void*)&frames && s == esrc && d == edst) return;
+  if (!ctx) check(mvicp_create(device, &ctx));
+  check(mvicp_set_num_frames(ctx, (int)frames.size()));
+  for (size_t i = 0; i < frames.size(); ++i) {
+    Frame& f = *frames[i];
+    const double* nrm = f.nor.size() == f.pts.size() && !f.nor.empty() ? f.nor[0].data() : nullptr;
+    check(mvicp_set_frame(ctx, (int)i, f.pts.empty() ? nullptr : f.pts[0].data(), nrm, (int)f.pts.size()));
+  }
+  check(mvicp_set_graph(ctx, (int)s.size(), s.data(), d.data()));
+  esrc = s; edst = d;
+  frames_key = (const void*)&frames;
+  last_poses.clear();
+}
+
+void Session::correspond(std::vector<std::shared_ptr<Frame>>& frames, float thresh) {
+  bind(frames);
+  std::vector<double> P(16 * frames.size());
+  std::vector<unsigned char> fx(frames.size());
+  for (size_t i = 0; i < frames.size(); ++i) { std::memcpy(&P[16 * i], frames[i]->pose.data(), 128); fx[i] = frames[i]->fixed; }
+  if (P == last_poses && thresh == last_thresh) return;  // same round: the batched result is still valid
+  counts.assign(esrc.size(), 0);
+  weights.assign(esrc.size(), 0.f);
+  check(mvicp_correspond(ctx, P.data(), fx.data(), thresh, nn_method, counts.data(), weights.data()));
+  last_poses = P;
+  last_thresh = thresh;
+}
+
+void Session::optimize(std::vector<std::shared_ptr<Frame>>& frames, int param, bool pointToPlane, bool robust, mvicp_summary* out) {
+  bind(frames);
+  std::vector<double> P(16 * frames.size());
+  std::vector<unsigned char> fx(frames.size());
+  for (size_t i = 0; i < frames.size(); ++i) { std::memcpy(&P[16 * i], frames[i]->pose.data(), 128); fx[i] = frames[i]->fixed; }
+  mvicp_summary sm;
+  check(mvicp_optimize(ctx, P.data(), fx.data(), param, pointToPlane, robust, 50 /* icp-ceres.cpp:81 */, &sm));
+  if (!frames.empty()) frames[0]->fixed = true;  // icp-ceres.cpp:244,341,417
+  for (size_t i = 0; i < frames.size(); ++i) std::memcpy(frames[i]->pose.data(), &P[16 * i], 128);
+  if (out) *out = sm;
+}
+
+void Frame::computePoseNeighboursKnn(std::vector<std::shared_ptr<Frame>>* frames, int i, int k) {
+  neighbours.clear();
+  const Vector3d t1 = pose.translation();
+  for (int j = 0; j < (int)frames->size(); ++j) {
+    if (i == j) continue;
+    const float diff_tra = (float)(t1 - (*frames)[j]->pose.translation()).norm();
+    neighbours.push_back(OutgoingEdge{j, diff_tra, {}});
+  }
+  auto less = [](const OutgoingEdge& a, const OutgoingEdge& b) { return a.weight < b.weight; };
+  if ((int)neighbours.size() < k) {
+    std::sort(neighbours.begin(), neighbours.end(), less);
+  } else {
+    std::partial_sort(neighbours.begin(), neighbours.begin() + k, neighbours.end(), less);
+    neighbours.resize(k);
+  }
+}
+
+void Frame::computeClosestPointsToNeighbours(std::vector<std::shared_ptr<Frame>>* frames, float thresh) {
+  if (fixed) return;  // frame.cpp:93
+  Session& S = Session::get();
+  S.correspond(*frames, thresh);
+  size_t e = 0;
+  for (size_t i = 0; i < frames->size(); ++i) {
+    Frame& f = *(*frames)[i];
+    if (&f != this) { e += f.neighbours.size(); continue; }
+    for (OutgoingEdge& edge : f.neighbours) {
+      edge.weight = S.weights[e];
+      edge.correspondances.clear();
+      if (S.copy_back && S.counts[e] > 0) {
+        const int n = S.counts[e];
+        std::vector<int> a(n), b(n);
+        std::vector<double> d(n);
+        check(mvicp_get_correspondences(S.ctx, (int)e, n, a.data(), b.data(), d.data()));
+        edge.correspondances.resize(n);
+        for (int k = 0; k < n; ++k) edge.correspondances[k] = Correspondance{a[k], b[k], d[k]};
+      }
+      ++e;
+    }
+    break;
+  }
+}
+
+double Frame::getClosestPoint(const Vector3d& q, size_t& ret_index) {
+  Session& S = Session::get();
+  if (!S.ctx) throw std::runtime_error("mvicp: bind the frames first (computeClosestPointsToNeighbours / ceresOptimizer*)");
+  // locate this frame in the session by pointer scan is not possible without the vector; single-cloud fallback:
+  // callers use the batched API; this entry serves one-off queries through a private context.
+  static mvicp_ctx* own = nullptr;
+  static const Frame* owner = nullptr;
+  if (owner != this) {
+    if (own) mvicp_destroy(own);
+    check(mvicp_create(S.device, &own));
+    check(mvicp_set_num_frames(own, 1));
+    check(mvicp_set_frame(own, 0, pts[0].data(), nullptr, (int)pts.size()));
+    owner = this;
+  }
+  int idx = -1;
+  double d2 = 0.0;
+  check(mvicp_nn_query(own, 0, q.data(), 1, MVICP_NN_AUTO, &idx, &d2));
+  ret_index = (size_t)idx;
+  return d2;
+}
+
+}  // namespace mvicp
+
+namespace ICP_Ceres {
+
+void ceresOptimizer(std::vector<std::shared_ptr<Frame>>& frames, bool pointToPlane, bool robust) {
+  mvicp::Session::get().optimize(frames, MVICP_PARAM_EIGEN_QUATERNION, pointToPlane, robust);
+}
+void ceresOptimizer_ceresAngleAxis(std::vector<std::shared_ptr<Frame>>& frames, bool pointToPlane, bool robust) {
+  mvicp::Session::get().optimize(frames, MVICP_PARAM_ANGLE_AXIS, pointToPlane, robust);
+}
+void ceresOptimizer_sophusSE3(std::vector<std::shared_ptr<Frame>>& frames, bool pointToPlane, bool robust, bool) {
+  mvicp::Session::get().optimize(frames, MVICP_PARAM_SOPHUS_SE3, pointToPlane, robust);
+}
+
+// icp-ceres.cpp:137-218,525-565: one residual block per index-aligned pair (dst[i], src[i]), single free pose from identity,
+// no loss function.  Frame 0 = dst (fixed, identity), frame 1 = src.
+static Isometry3d pairwise(std::vector<Vector3d>& src, std::vector<Vector3d>& dst, std::vector<Vector3d>* nor, int param) {
+  auto check = [](int st) { if (st < 0) throw std::runtime_error(std::string("mvicp: ") + mvicp_last_error()); };
+  if (src.size() != dst.size() || src.empty()) throw std::runtime_error("mvicp: pairwise needs equally sized, non-empty clouds");
+  mvicp_ctx* c = nullptr;
+  check(mvicp_create(mvicp::Session::get().device, &c));
+  check(mvicp_set_num_frames(c, 2));
+  check(mvicp_set_frame(c, 0, dst[0].data(), nor ? (*nor)[0].data() : nullptr, (int)dst.size()));
+  check(mvicp_set_frame(c, 1, src[0].data(), nullptr, (int)src.size()));
+  const int s = 1, d = 0;
+  check(mvicp_set_graph(c, 1, &s, &d));
+  std::vector<int> id(src.size());
+  std::iota(id.begin(), id.end(), 0);
+  check(mvicp_set_correspondences(c, 0, (int)id.size(), id.data(), id.data(), 0.f));
+  double P[32];
+  Isometry3d I;
+  std::memcpy(P, I.data(), 128);
+  std::memcpy(P + 16, I.data(), 128);
+  unsigned char fixed[2] = {1, 0};
+  mvicp_summary sm;
+  const int st = mvicp_optimize(c, P, fixed, param, nor != nullptr, 0, 50, &sm);
+  Isometry3d out;
+  std::memcpy(out.data(), P + 16, 128);
+  mvicp_destroy(c);
+  check(st);
+  return out;
+}
+Isometry3d pointToPoint_EigenQuaternion(std::vector<Vector3d>& s, std::vector<Vector3d>& d) { return pairwise(s, d, nullptr, MVICP_PARAM_EIGEN_QUATERNION); }
+Isometry3d pointToPoint_CeresAngleAxis(std::vector<Vector3d>& s, std::vector<Vector3d>& d) { return pairwise(s, d, nullptr, MVICP_PARAM_ANGLE_AXIS); }
+Isometry3d pointToPoint_SophusSE3(std::vector<Vector3d>& s, std::vector<Vector3d>& d, bool) { return pairwise(s, d, nullptr, MVICP_PARAM_SOPHUS_SE3); }
+Isometry3d pointToPlane_EigenQuaternion(std::vector<Vector3d>& s, std::vector<Vector3d>& d, std::vector<Vector3d>& n) { return pairwise(s, d, &n, MVICP_PARAM_EIGEN_QUATERNION); }
+Isometry3d pointToPlane_CeresAngleAxis(std::vector<Vector3d>& s, std::vector<Vector3d>& d, std::vector<Vector3d>& n) { return pairwise(s, d, &n, MVICP_PARAM_ANGLE_AXIS); }
+Isometry3d pointToPlane_SophusSE3(std::vector<Vector3d>& s, std::vector<Vector3d>& d, std::vector<Vector3d>& n, bool) { return pairwise(s, d, &n, MVICP_PARAM_SOPHUS_SE3); }
+
+}  // namespace ICP_Ceres

@@ -1,0 +1,83 @@
+// Host-side mirror of the reference's Frame / ICP_Ceres interface on top of the C ABI (include/mvicp.h).
+// Same member names, argument meaning and call order as the reference, so a driver written against
+// include/frame.h + include/icp-ceres.h of adrelino/mv-lm-icp reads the same here:
+//   struct Correspondance / OutgoingEdge            include/frame.h:18-29
+//   class Frame                                     include/frame.h:31-102
+//   ICP_Ceres::ceresOptimizer*, pointToPoint/Plane_* include/icp-ceres.h:29-42
+// Differences forced by the boundary: errors are thrown as std::runtime_error carrying mvicp_last_error() (the
+// reference has nothing to propagate); OutgoingEdge::P_relative (never used, frame.h:28) is dropped; draw()/GL
+// members are out of scope.
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/mvicp.h"
+#include "linalg.h"
+
+namespace mvicp {
+
+struct Correspondance { int first; int second; double dist; };
+
+struct OutgoingEdge {
+  int neighbourIdx;
+  float weight;  // pose distance at graph build, then 1.5 x median correspondence distance (frame.cpp:176)
+  std::vector<Correspondance> correspondances;
+};
+
+class Frame {
+ public:
+  std::vector<Vector3d> pts;
+  std::vector<Vector3d> nor;
+  bool fixed = false;
+  Isometry3d pose;
+  Isometry3d poseGroundTruth;
+  std::vector<OutgoingEdge> neighbours;
+
+  // frame.cpp:67-89 (host; tiny)
+  void computePoseNeighboursKnn(std::vector<std::shared_ptr<Frame>>* frames, int i, int k);
+  // frame.cpp:91-185.  The first call after any pose change runs the batched device search for ALL frames; this
+  // frame's edges are then filled from it (later calls for the other frames in the same round are copies only).
+  void computeClosestPointsToNeighbours(std::vector<std::shared_ptr<Frame>>* frames, float thresh);
+  // frame.cpp:187-206: query in this frame's local coordinates -> squared distance, index
+  double getClosestPoint(const Vector3d& query_pt, size_t& ret_index);
+};
+
+// Process-wide device session behind the Frame / ICP_Ceres calls: uploads the (static) clouds once, mirrors the
+// pose graph, caches the batched correspondence search of the current poses.
+struct Session {
+  static Session& get();
+  mvicp_ctx* ctx = nullptr;
+  int device = 0;
+  bool copy_back = true;  // fill Frame::neighbours[].correspondances after the search (off: device-only, faster)
+  int nn_method = MVICP_NN_AUTO;
+  const void* frames_key = nullptr;
+  std::vector<int> esrc, edst;
+  std::vector<double> last_poses;
+  float last_thresh = -1.f;
+  std::vector<int> counts;
+  std::vector<float> weights;
+  void bind(std::vector<std::shared_ptr<Frame>>& frames);      // upload + graph (idempotent)
+  void correspond(std::vector<std::shared_ptr<Frame>>& frames, float thresh);
+  void optimize(std::vector<std::shared_ptr<Frame>>& frames, int param, bool pointToPlane, bool robust, mvicp_summary* sm = nullptr);
+  void reset();
+};
+
+}  // namespace mvicp
+
+namespace ICP_Ceres {
+using mvicp::Frame;
+using mvicp::Isometry3d;
+using mvicp::Vector3d;
+// multiview (icp-ceres.h:40-42)
+void ceresOptimizer(std::vector<std::shared_ptr<Frame>>& frames, bool pointToPlane, bool robust);
+void ceresOptimizer_ceresAngleAxis(std::vector<std::shared_ptr<Frame>>& frames, bool pointToPlane, bool robust);
+void ceresOptimizer_sophusSE3(std::vector<std::shared_ptr<Frame>>& frames, bool pointToPlane, bool robust, bool automaticDiffLocalParam = true);
+// pairwise (icp-ceres.h:30-36): returns the src -> dst transform, starting from identity
+Isometry3d pointToPoint_EigenQuaternion(std::vector<Vector3d>& src, std::vector<Vector3d>& dst);
+Isometry3d pointToPoint_CeresAngleAxis(std::vector<Vector3d>& src, std::vector<Vector3d>& dst);
+Isometry3d pointToPoint_SophusSE3(std::vector<Vector3d>& src, std::vector<Vector3d>& dst, bool automaticDiffLocalParam = true);
+Isometry3d pointToPlane_EigenQuaternion(std::vector<Vector3d>& src, std::vector<Vector3d>& dst, std::vector<Vector3d>& nor);
+Isometry3d pointToPlane_CeresAngleAxis(std::vector<Vector3d>& src, std::vector<Vector3d>& dst, std::vector<Vector3d>& nor);
+Isometry3d pointToPlane_SophusSE3(std::vector<Vector3d>& src, std::vector<Vector3d>& dst, std::vector<Vector3d>& nor, bool automaticDiffLocalParam = true);
+}  // namespace ICP_Ceres

@@ -1,0 +1,85 @@
+// Headless counterpart of the reference's src/main_multiview.cpp (same flags, same loop, no viewer):
+//   loadFrames (:53-100) -> frames[0]->fixed = true (:141) -> computePoseNeighbours (:104-117, once) ->
+//   20 x { computeClosestPoints (:119-127) ; ceresOptimizer* (:158-161) }
+// Extra flags: --rounds (20), --out DIR (write final poses as pose_<i>.txt, 4x4 row-major), --device, --copyback,
+// --keep_phantom_row (reproduce the reference's loadXYZ trailing element), --quiet.
+#include <chrono>
+#include <iomanip>
+#include <iostream>
+
+#include "common_io.h"
+#include "flags.h"
+#include "frame.h"
+
+using namespace mvicp;
+
+static void loadFrames(const Flags& F, std::vector<std::shared_ptr<Frame>>& frames, const std::string& dir) {
+  const std::vector<std::string> clouds = getAllTextFilesFromFolder(dir, "cloud");
+  const std::vector<std::string> poses = getAllTextFilesFromFolder(dir, "pose");
+  const std::vector<std::string> groundtruth = getAllTextFilesFromFolder(dir, "groundtruth");
+  if (clouds.size() != poses.size()) std::cout << "unequal size" << std::endl;
+  const int limit = F.i("limit", 40), step = F.i("step", 2);
+  const double sigma = F.f("sigma", 0.02), sigmat = F.f("sigmat", 0.01);
+  for (int i = 0; i < (int)clouds.size() && i < limit * step; i += step) {
+    std::shared_ptr<Frame> f(new Frame());
+    const int j = F.b("fake", false) ? 0 : i;
+    loadXYZ(clouds[j], f->pts, f->nor, F.b("keep_phantom_row", false));
+    if (groundtruth.size() == clouds.size()) {
+      f->pose = loadMatrix4d(poses[i]);
+      f->poseGroundTruth = loadMatrix4d(groundtruth[i]);
+    } else {
+      f->poseGroundTruth = loadMatrix4d(poses[i]);
+      f->pose = (i == 0) ? f->poseGroundTruth : addNoise(f->poseGroundTruth, sigma, sigmat);
+    }
+    frames.push_back(f);
+  }
+}
+
+int main(int argc, char** argv) {
+  Flags F(argc, argv);
+  const bool pointToPlane = F.b("pointToPlane", true), sophusSE3 = F.b("sophusSE3", true), angleAxis = F.b("angleAxis", false);
+  const bool robust = F.b("robust", true), quiet = F.b("quiet", false);
+  const float cutoff = (float)F.f("cutoff", 0.05);
+  const int knn = F.i("knn", 2), rounds = F.i("rounds", 20);
+  const std::string dir = F.s("dir", "../samples/Bunny_RealData"), out = F.s("out", "");
+  Session::get().device = F.i("device", 0);
+  Session::get().copy_back = F.b("copyback", true);
+
+  std::vector<std::shared_ptr<Frame>> frames;
+  loadFrames(F, frames, dir);
+  if (frames.empty()) { std::cerr << "no frames loaded from " << dir << std::endl; return 1; }
+  frames[0]->fixed = true;
+  for (int i = 0; i < (int)frames.size(); ++i) frames[i]->computePoseNeighboursKnn(&frames, i, knn);
+  if (!quiet) {
+    std::cout << "graph adjacency matrix == block structure" << std::endl;
+    for (size_t i = 0; i < frames.size(); ++i) {
+      std::vector<int> row(frames.size(), 0);
+      for (const OutgoingEdge& e : frames[i]->neighbours) row[e.neighbourIdx] = 1;
+      for (int v : row) std::cout << v << " ";
+      std::cout << std::endl;
+    }
+  }
+  try {
+    for (int r = 0; r < rounds; ++r) {
+      const auto t0 = std::chrono::steady_clock::now();
+      for (auto& f : frames) f->computeClosestPointsToNeighbours(&frames, cutoff);
+      const auto t1 = std::chrono::steady_clock::now();
+      if (sophusSE3) ICP_Ceres::ceresOptimizer_sophusSE3(frames, pointToPlane, robust);
+      else if (angleAxis) ICP_Ceres::ceresOptimizer_ceresAngleAxis(frames, pointToPlane, robust);
+      else ICP_Ceres::ceresOptimizer(frames, pointToPlane, robust);
+      const auto t2 = std::chrono::steady_clock::now();
+      if (!quiet)
+        std::cout << "round: " << r << "  closest pts " << std::chrono::duration<double, std::milli>(t1 - t0).count() << " ms  global "
+                  << std::chrono::duration<double, std::milli>(t2 - t1).count() << " ms" << std::endl;
+    }
+  } catch (const std::exception& ex) {
+    std::cerr << ex.what() << std::endl;
+    return 2;
+  }
+  for (size_t i = 0; i < frames.size(); ++i) {
+    if (!quiet) std::cout << "frame " << i << poseDiff(frames[i]->pose, frames[i]->poseGroundTruth);
+    if (!out.empty()) saveMatrix4d(out + "/pose_" + std::to_string(i) + ".txt", frames[i]->pose);
+  }
+  Session::get().reset();
+  return 0;
+}
