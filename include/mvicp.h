@@ -64,6 +64,12 @@ int mvicp_destroy(mvicp_ctx* ctx);
 int mvicp_set_num_frames(mvicp_ctx* ctx, int n_frames);
 int mvicp_set_frame(mvicp_ctx* ctx, int frame, const double* xyz, const double* nrm, int n);
 
+/* Replaces Frame::recomputeNormals() (include/frame.h:49, src/internal/frame.cpp:244-255; on by default in the reference,
+ * main_multiview.cpp:49,68-70): normal of every point = eigenvector of the smallest eigenvalue of the covariance of its
+ * k nearest points INCLUDING itself (reference k = 10), flipped so n_z <= 0 (include/common.h:331-346).  Overwrites the
+ * frame's device normals; nrm_out (n x 3) and knn_out (n x k original indices, nearest first) may be NULL. */
+int mvicp_recompute_normals(mvicp_ctx* ctx, int frame, int k, double* nrm_out, int* knn_out);
+
 /* Pose graph = all Frame::neighbours[j].neighbourIdx (frame.cpp:67-89 builds it; main_multiview.cpp:
  * 104-117).  Edge order is the reference's loop order: src ascending, then neighbour order. */
 int mvicp_set_graph(mvicp_ctx* ctx, int n_edges, const int* src, const int* dst);

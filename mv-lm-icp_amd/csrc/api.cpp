@@ -246,6 +246,26 @@ int mvicp_set_frame(mvicp_ctx* c, int frame, const double* xyz, const double* nr
   return MVICP_OK;
 }
 
+int mvicp_recompute_normals(mvicp_ctx* c, int frame, int k, double* nrm_out, int* knn_out) {
+  MV_CHECK(bind(c));
+  if (frame < 0 || frame >= c->n_frames) { set_error("frame %d out of range", frame); return MVICP_ERR_ARG; }
+  FrameDev& f = c->frames[frame];
+  if (f.n < k) { set_error("frame %d has %d points < k = %d (common.h:333 asserts >= 3)", frame, f.n, k); return MVICP_ERR_STATE; }
+  if (!f.nor) MV_CHECK(dev_alloc(&f.nor, 3 * (size_t)f.n));
+  int* d_knn = nullptr;
+  if (knn_out) MV_CHECK(dev_alloc(&d_knn, (size_t)f.n * k));
+  int st = launch_normals(c, f, k, d_knn);
+  if (st == MVICP_OK) {
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && nrm_out) e = hipMemcpy(nrm_out, f.nor, sizeof(double) * 3 * (size_t)f.n, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && knn_out) e = hipMemcpy(knn_out, d_knn, sizeof(int) * (size_t)f.n * k, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { set_error("recompute_normals: %s", hipGetErrorString(e)); st = MVICP_ERR_HIP; }
+  }
+  dev_free(d_knn);
+  if (c->profile) prof_collect(c);
+  return st;
+}
+
 int mvicp_set_shard(mvicp_ctx* c, int rank, int world) {
   MV_CHECK(bind(c));
   if (world < 1 || rank < 0 || rank >= world) { set_error("bad shard %d/%d", rank, world); return MVICP_ERR_ARG; }

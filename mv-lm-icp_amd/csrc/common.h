@@ -162,6 +162,7 @@ int launch_compact(mvicp_ctx* c, double d2_bound);                              
 int launch_gather_stream(mvicp_ctx* c);
 int launch_select_median(mvicp_ctx* c);
 int launch_linearize(mvicp_ctx* c, int plane, int robust);                            // linearize.hip
+int launch_normals(mvicp_ctx* c, FrameDev& f, int k, int* d_knn);                      // normals.hip
 
 // small host->device table uploads through a persistent bump-allocated scratch buffer; the copy is a
 // synchronous hipMemcpy (tables are tiny) so the pageable source may die right after the call.

@@ -111,6 +111,18 @@ void Frame::computeClosestPointsToNeighbours(std::vector<std::shared_ptr<Frame>>
   }
 }
 
+void Frame::recomputeNormals() {
+  if (pts.size() < 10) throw std::runtime_error("mvicp: recomputeNormals needs >= 10 points");
+  mvicp_ctx* c = nullptr;
+  check(mvicp_create(Session::get().device, &c));
+  nor.resize(pts.size());
+  int st = mvicp_set_num_frames(c, 1);
+  if (st == MVICP_OK) st = mvicp_set_frame(c, 0, pts[0].data(), nullptr, (int)pts.size());
+  if (st == MVICP_OK) st = mvicp_recompute_normals(c, 0, 10, nor[0].data(), nullptr);
+  mvicp_destroy(c);
+  check(st);
+}
+
 double Frame::getClosestPoint(const Vector3d& q, size_t& ret_index) {
   Session& S = Session::get();
   if (!S.ctx) throw std::runtime_error("mvicp: bind the frames first (computeClosestPointsToNeighbours / ceresOptimizer*)");

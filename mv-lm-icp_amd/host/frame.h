@@ -41,6 +41,8 @@ class Frame {
   void computeClosestPointsToNeighbours(std::vector<std::shared_ptr<Frame>>* frames, float thresh);
   // frame.cpp:187-206: query in this frame's local coordinates -> squared distance, index
   double getClosestPoint(const Vector3d& query_pt, size_t& ret_index);
+  // frame.cpp:244-255: PCA normals from the 10 nearest points (self included), n_z <= 0; overwrites `nor`
+  void recomputeNormals();
 };
 
 // Process-wide device session behind the Frame / ICP_Ceres calls: uploads the (static) clouds once, mirrors the

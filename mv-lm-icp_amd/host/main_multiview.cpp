@@ -24,6 +24,7 @@ static void loadFrames(const Flags& F, std::vector<std::shared_ptr<Frame>>& fram
     std::shared_ptr<Frame> f(new Frame());
     const int j = F.b("fake", false) ? 0 : i;
     loadXYZ(clouds[j], f->pts, f->nor, F.b("keep_phantom_row", false));
+    if (F.b("recomputeNormals", true)) f->recomputeNormals();  // main_multiview.cpp:49,68-70 (default on)
     if (groundtruth.size() == clouds.size()) {
       f->pose = loadMatrix4d(poses[i]);
       f->poseGroundTruth = loadMatrix4d(groundtruth[i]);

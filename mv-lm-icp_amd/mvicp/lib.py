@@ -13,7 +13,7 @@ EDGE_BLOCK = 91
 
 SYMBOLS = [
     "mvicp_last_error", "mvicp_version", "mvicp_create", "mvicp_destroy", "mvicp_set_num_frames", "mvicp_set_frame",
-    "mvicp_set_graph", "mvicp_set_shard", "mvicp_edge_owner", "mvicp_comm_unique_id", "mvicp_comm_init", "mvicp_correspond",
+    "mvicp_recompute_normals", "mvicp_set_graph", "mvicp_set_shard", "mvicp_edge_owner", "mvicp_comm_unique_id", "mvicp_comm_init", "mvicp_correspond",
     "mvicp_get_correspondences", "mvicp_set_correspondences", "mvicp_nn_query", "mvicp_linearize", "mvicp_optimize",
     "mvicp_lm_solve", "mvicp_set_option", "mvicp_nn_census", "mvicp_profile_enable", "mvicp_profile_reset", "mvicp_profile_get", "mvicp_stream", "mvicp_sync",
 ]
@@ -52,6 +52,7 @@ def load_library(path=None):
     lib.mvicp_destroy.argtypes = [vp]
     lib.mvicp_set_num_frames.argtypes = [vp, C.c_int]
     lib.mvicp_set_frame.argtypes = [vp, C.c_int, dp, dp, C.c_int]
+    lib.mvicp_recompute_normals.argtypes = [vp, C.c_int, C.c_int, dp, ip]
     lib.mvicp_set_graph.argtypes = [vp, C.c_int, ip, ip]
     lib.mvicp_set_shard.argtypes = [vp, C.c_int, C.c_int]
     lib.mvicp_edge_owner.argtypes = [C.c_int, ip, C.c_int, ip]
@@ -173,6 +174,13 @@ class Engine:
             n = None if nor_list is None or nor_list[i] is None else np.ascontiguousarray(nor_list[i], dtype=np.float64)
             _check(self.lib, self.lib.mvicp_set_frame(self.h, i, _dp(p), _dp(n) if n is not None else None, len(p)))
             self.npts.append(len(p))
+
+    def recompute_normals(self, frame, k=10, want_knn=False):
+        n = self.npts[frame]
+        nrm = np.zeros((n, 3), dtype=np.float64)
+        knn = np.zeros((n, k), dtype=np.int32) if want_knn else None
+        _check(self.lib, self.lib.mvicp_recompute_normals(self.h, frame, k, _dp(nrm), _ip(knn) if want_knn else None))
+        return (nrm, knn) if want_knn else nrm
 
     def set_graph(self, src, dst):
         self.src = np.ascontiguousarray(src, dtype=np.int32)

@@ -30,7 +30,7 @@ def test_multiview_driver_matches_engine_loop(tmp_path, flags, param, plane):
     d = tmp_path / "data"; o = tmp_path / "out"
     d.mkdir(); o.mkdir()
     write_dataset(str(d), pb)
-    cmd = [os.path.join(BIN, "multiview"), "--dir", str(d), "--out", str(o), "--step", "1", "--limit", "40", "--rounds", "4", "--quiet"] + flags
+    cmd = [os.path.join(BIN, "multiview"), "--dir", str(d), "--out", str(o), "--step", "1", "--limit", "40", "--rounds", "4", "--quiet", "--norecomputeNormals"] + flags
     subprocess.check_call(cmd)
     got = np.array([np.loadtxt(os.path.join(str(o), f"pose_{i}.txt")) for i in range(5)])
     # same loop through the Python binding; the driver's graph includes the fixed frame's own (inactive) edges
@@ -53,6 +53,27 @@ def test_correspondence_copy_back_through_frame_api(tmp_path):
     write_dataset(str(d), pb)
     subprocess.check_call([os.path.join(BIN, "multiview"), "--dir", str(d), "--out", str(o), "--step", "1", "--rounds", "1", "--quiet", "--copyback"])
     assert os.path.exists(os.path.join(str(o), "pose_2.txt"))
+
+
+def test_multiview_driver_default_flags_recompute_normals(tmp_path):
+    """Reference defaults (recomputeNormals on): the driver's PCA normals + loop equal the engine's."""
+    pb = synth.make_problem(4, 3000)
+    d = tmp_path / "data"; o = tmp_path / "out"
+    d.mkdir(); o.mkdir()
+    write_dataset(str(d), pb)
+    subprocess.check_call([os.path.join(BIN, "multiview"), "--dir", str(d), "--out", str(o), "--step", "1", "--rounds", "3", "--quiet"])
+    got = np.array([np.loadtxt(os.path.join(str(o), f"pose_{i}.txt")) for i in range(4)])
+    src, dst = synth.pose_graph_knn(pb["init"], 2, skip_fixed0=False)
+    eng = mvicp.Engine(0)
+    eng.set_frames(pb["pts"], None)
+    nor = [eng.recompute_normals(i, 10) for i in range(4)]
+    eng.set_frames(pb["pts"], nor); eng.set_graph(src, dst)
+    poses = pb["init"].copy()
+    for _ in range(3):
+        eng.correspond(poses, pb["fixed"], 0.05)
+        poses, sm = eng.optimize(poses, pb["fixed"], L.PARAM_SOPHUS_SE3, 1, True, 50)
+    eng.close()
+    assert np.allclose(got, poses, rtol=0, atol=1e-13), np.abs(got - poses).max()
 
 
 def test_pairwise_driver_recovers_known_transform(tmp_path):

@@ -342,3 +342,68 @@ def test_sharded_contexts_sum_to_the_unsharded_blocks():
     assert np.array_equal(parts[0] + parts[1], bf)
     assert np.array_equal(counts[0] + counts[1], cf)
     full.close()
+
+
+# ---------------------------------------------------------------- f1: Frame::recomputeNormals
+def test_recompute_normals_matches_nanoflann_knn_and_pca(eng):
+    """frame.cpp:244-255 + common.h:331-346: 10-NN (self included) from the REAL nanoflann (golden bunny_knn.npz), PCA in
+    numpy.  k-NN index sets must be identical; normals agree to 1e-9 (iterative eigen-solvers differ in rounding only)."""
+    K = np.load(os.path.join(os.path.dirname(__file__), "golden", "bunny_knn.npz"))
+    pts, gi, gd = K["pts"], K["knn_idx"], K["knn_d2"]
+    eng.set_frames([pts], None)
+    nrm, knn = eng.recompute_normals(0, 10, want_knn=True)
+    # the Bunny clouds are range-image lattices: exact distance ties are common, and on a tie at the k-th place nanoflann
+    # keeps whichever leaf it visited first (nanoflann.hpp:111-115) while this kernel keeps the lowest index.  What is
+    # unique is the multiset of the k smallest squared distances: bit-equal.  Index sets are compared where no tie decides.
+    e = pts[:, None, :] - pts[knn]
+    myd = (e[:, :, 0] * e[:, :, 0] + e[:, :, 1] * e[:, :, 1]) + e[:, :, 2] * e[:, :, 2]
+    assert np.array_equal(np.sort(myd, axis=1), np.sort(gd, axis=1))
+    assert np.all(knn[:, 0] == np.arange(len(pts)))  # self first (distance 0)
+    same = np.all(np.sort(knn, axis=1) == np.sort(gi, axis=1), axis=1)
+    assert same.mean() > 0.5
+    nb = pts[gi]                                   # (n, 10, 3)
+    c = nb - nb.mean(axis=1, keepdims=True)
+    cov = np.einsum("nki,nkj->nij", c, c)
+    w, v = np.linalg.eigh(cov)
+    ref = v[:, :, 0]
+    ref = np.where(ref[:, 2:3] > 0, -ref, ref)
+    well = same & ((w[:, 1] - w[:, 0]) > 1e-6 * w[:, 2])    # same neighbour set, and skip (near-)degenerate smallest eigenvalues
+    dots = np.abs(np.sum(nrm * ref, axis=1))
+    assert np.all(dots[well] > 1 - 1e-9), dots[well].min()
+    assert np.all(nrm[:, 2] <= 0) and np.allclose(np.linalg.norm(nrm, axis=1), 1, atol=1e-12)
+    sure = well & (np.abs(ref[:, 2]) > 1e-6)
+    assert np.all(np.sum(nrm * ref, axis=1)[sure] > 0)
+
+
+def test_recomputed_normals_feed_point_to_plane(eng, orc):
+    """The ICP path uses the device normals written by mvicp_recompute_normals (reference default, main_multiview.cpp:49)."""
+    pb = synth.make_problem(3, 4000)
+    eng.set_frames(pb["pts"], None)
+    nor = [eng.recompute_normals(i, 10) for i in range(3)]
+    eng.set_graph(pb["src"], pb["dst"])
+    counts, weights = eng.correspond(pb["init"], pb["fixed"], 0.05)
+    corr = [eng.get_correspondences(e)[:2] for e in range(eng.E)]
+    got = eng.linearize(pb["init"], 1, 1)
+    want = orc.edge_blocks(pb["pts"], nor, pb["src"], pb["dst"], corr, weights, pb["init"], 1, 1)
+    scale = np.abs(want[:, :78]).max()
+    assert np.allclose(got, want, rtol=1e-9, atol=1e-11 * scale)
+    # synthetic analytic normals vs PCA normals: same surface, so they agree up to sign / sampling noise
+    ang = np.abs(np.sum(nor[1] * pb["nor"][1], axis=1))
+    assert np.median(ang) > 0.99
+
+
+def test_linearised_point_to_plane_matches_closed_form(eng):
+    """icp-closedform.cpp:30-54 builds the 6x6 linearised point-to-plane normal equations C x = d at identity; they are exactly
+    the source block of K5's output at identity poses without the robust loss: H_ss = sum [n; p x n][n; p x n]^T."""
+    rng = np.random.default_rng(2)
+    n = 5000
+    src = rng.normal(0, 0.1, (n, 3)); dst = src + rng.normal(0, 0.002, (n, 3))
+    nor = rng.normal(0, 1, (n, 3)); nor /= np.linalg.norm(nor, axis=1, keepdims=True)
+    eng.set_frames([dst, src], [nor, nor]); eng.set_graph([1], [0])
+    ids = np.arange(n, dtype=np.int32)
+    eng.set_correspondences(0, ids, ids, 0.0)
+    H, g, cost = L.unpack_block(eng.linearize(np.array([np.eye(4), np.eye(4)]), 1, 0)[0])
+    u = np.hstack([nor, np.cross(src, nor)])
+    r = np.sum((src - dst) * nor, axis=1)
+    assert np.allclose(H[:6, :6], u.T @ u, rtol=1e-11) and np.allclose(g[:6], u.T @ r, rtol=1e-9, atol=1e-15)
+    assert np.isclose(cost, 0.5 * np.sum(r * r), rtol=1e-12)
