@@ -208,6 +208,8 @@ int mvicp_destroy(mvicp_ctx* c) {
   for (FrameDev& f : c->frames) { dev_free(f.pts); dev_free(f.nor); free_grid(f.grid); }
   dev_free(c->d_split_idx); dev_free(c->d_split_d2); dev_free(c->d_scratch);
   if (c->d_census) (void)hipFree(c->d_census);
+  if (c->d_far_list) (void)hipFree(c->d_far_list);
+  if (c->d_far_count) (void)hipFree(c->d_far_count);
   for (auto& kv : c->prof) {
     for (auto& pr : kv.second.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (hipEvent_t ev : kv.second.pool) (void)hipEventDestroy(ev);

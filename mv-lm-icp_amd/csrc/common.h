@@ -48,6 +48,8 @@ struct GridDev {
   unsigned int table_mask = 0; int table_shift = 0;
   float* bvh = nullptr;        // implicit complete AABB tree, 6 floats per node (outward rounded)
   int depth = 0;
+  float* oct = nullptr;        // implicit complete 8-ary box tree, 8 floats per node {lo.xyz, hi.xyz, pad2}
+  int oct_depth = 0; long long oct_first_leaf = 0;
   // 64-wide box hierarchy over the same sorted array (nn_tile.hip): level 0 = boxes of 64-point leaves,
   // level l+1 = boxes of 64 consecutive level-l boxes; SoA per level: 6 arrays of `wide_cnt[l]` floats.
   float* wide = nullptr;
@@ -138,6 +140,7 @@ struct mvicp_ctx {
   bool nn_tree_only = false;
   bool nn_census = false;          // count candidates / tree nodes per launch while profiling (small extra cost)
   void* d_census = nullptr; size_t census_bytes = 0;
+  void* d_far_list = nullptr; size_t far_cap = 0; unsigned int* d_far_count = nullptr;  // nn_grid far-query list
   bool nn_skip_far = false;        // PROFILING ONLY: leave unresolved queries unresolved (wrong results)
   double grid_target = 6.0;        // points per occupied cell the cell-edge heuristic aims at
   double nn_candidates = 0, nn_nodes = 0, nn_far = 0, nn_queries = 0;

@@ -50,6 +50,7 @@ struct GridView {  // device view of one cloud's structure
   double ox, oy, oz, h, inv_h;
   int dx, dy, dz;
   const float* bvh; int depth;
+  const float* oct; int oct_depth; long long oct_first_leaf;   // implicit 8-ary box tree (32-B boxes), phase 2
 };
 
 struct GridJob {
@@ -121,9 +122,10 @@ __device__ __forceinline__ bool __lane0() {
   return (int)(threadIdx.x & 63) == __ffsll((long long)mask) - 1;
 }
 
+// ---- phase 1: spatial-hash block lookup for every query; queries it cannot prove optimal go to the far list ----
 template <bool TREE_ONLY>
-__global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__ jobs, double bound, unsigned long long* __restrict__ stats, int skip_far) {
-  __shared__ int s_stack[MAXD + 1][NT];
+__global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__ jobs, double bound, unsigned long long* __restrict__ stats, int skip_far,
+                                                     int2* __restrict__ far_list, unsigned int* __restrict__ far_count) {
   __shared__ double sxf[kEdgeXf];
   const GridJob& job = jobs[blockIdx.y];
   const int i = blockIdx.x * NT + threadIdx.x;
@@ -145,10 +147,10 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
   double best = bound;      // nothing at or beyond the cutoff bound needs resolving (frame.cpp:156)
   int bi = 0x7fffffff;
   bool resolved = false;
-  unsigned int n_cand = 0, n_nodes = 0;
+  unsigned int n_cand = 0;
 
   if (!TREE_ONLY) {
-    // ---- (1) 2x2x2 block of cells nearest to the query, through the spatial hash
+    // 2x2x2 block of cells nearest to the query, through the spatial hash
     const double cx = (qx - g.ox) * g.inv_h - 0.5, cy = (qy - g.oy) * g.inv_h - 0.5, cz = (qz - g.oz) * g.inv_h - 0.5;
     // queries far outside the grid cannot be resolved by the block test; clamp so the int conversion is safe
     const double lim = 2.0e6;
@@ -189,50 +191,138 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
     m *= 0.999;
     resolved = (m > 0.0) && (best < m * m) && (bi != 0x7fffffff);
   }
-
+  // provisional (or final) result; phase 2 re-reads it as the seed of the tree descent
+  job.out_idx[out] = bi == 0x7fffffff ? -1 : bi;
+  job.out_d2[out] = best;
   if (!resolved && !skip_far) {
-    // ---- (2) exact branch-and-bound over the implicit AABB tree, seeded with the current best
-    const int D = g.depth;
+    // wave-aggregated append: one atomic per wave
+    const unsigned long long mask = __ballot(1);
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;
+    const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+    unsigned int base = 0;
+    if (lane == leader) base = atomicAdd(far_count, (unsigned int)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    far_list[base + rank] = make_int2((int)blockIdx.y, i);
+  }
+  if (stats) {
+    // candidate census for the algorithmic-byte model: one slot per wave, no atomics
+    // (hot-address atomics would throttle the kernel being measured); summed by census_sum_kernel.
+    unsigned long long c = n_cand, far = resolved ? 0 : 1;
+    c = __reduce_add_u64(c); far = __reduce_add_u64(far);
+    const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + (threadIdx.x >> 6);
+    if (__lane0()) { stats[3 * slot] = c; stats[3 * slot + 2] = far; }
+  }
+}
+
+// ---- phase 2: exact branch-and-bound for the compacted far list, EIGHT LANES PER QUERY over an implicit 8-ary
+// box tree (children of heap node id are 8 id + 1 .. 8 id + 8; leaf j = sorted points [j n / 8^D, (j+1) n / 8^D)).
+// A lane octet loads the 8 child boxes of a node in one coalesced 256-B access (one 32-B box per lane), ranks them by
+// lower bound with shuffles and pushes the survivors nearest-on-top onto the octet's LDS stack; leaves are scanned 8
+// points at a time with an octet arg-min.  Compared with one lane per query this divides the number of dependent
+// memory round trips per query by ~3 (8-ary instead of binary), keeps the loads of an octet contiguous, and only the 8
+// octets of a wave can diverge from each other.  Persistent grid-stride launch: the far count lives on the device.
+constexpr int OCT_STACK = 56;  // >= 7 * max depth (depth <= 8 for n < 2^27)
+
+__device__ __forceinline__ double oct_box_lb(double qx, double qy, double qz, const float4 a, const float4 b) {
+  // box = {lo.xyz = a.xyz, hi.xyz = (a.w, b.x, b.y)}
+  const double g0 = fmax(fmax(__dsub_rn((double)a.x, qx), __dsub_rn(qx, (double)a.w)), 0.0);
+  const double g1 = fmax(fmax(__dsub_rn((double)a.y, qy), __dsub_rn(qy, (double)b.x)), 0.0);
+  const double g2 = fmax(fmax(__dsub_rn((double)a.z, qz), __dsub_rn(qz, (double)b.y)), 0.0);
+  return __dadd_rn(__dadd_rn(__dmul_rn(g0, g0), __dmul_rn(g1, g1)), __dmul_rn(g2, g2));
+}
+
+__global__ __launch_bounds__(NT) void nn_far_kernel(const GridJob* __restrict__ jobs, const int2* __restrict__ far_list,
+                                                    const unsigned int* __restrict__ far_count, unsigned long long* __restrict__ stats, size_t stats_slots) {
+  __shared__ int s_id[NT / 8][OCT_STACK];
+  __shared__ double s_lb[NT / 8][OCT_STACK];
+  const unsigned int nfar = *far_count;
+  const int oct = threadIdx.x >> 3, l = threadIdx.x & 7;
+  const int lane = threadIdx.x & 63, obase = lane & ~7;
+  unsigned long long n_cand = 0, n_nodes = 0;
+  for (unsigned int f = blockIdx.x * (NT / 8) + oct; f < ((nfar + (NT / 8) - 1) / (NT / 8)) * (NT / 8); f += gridDim.x * (NT / 8)) {
+    const bool live = f < nfar;   // whole octet live or not (f is octet-uniform)
+    if (!live) continue;
+    const int2 item = far_list[f];
+    const GridJob& job = jobs[item.x];
+    const GridView& g = job.dst;
+    const int i = item.y;
+    double qx, qy, qz;
+    {
+      const double p0 = job.q[3 * (size_t)i], p1 = job.q[3 * (size_t)i + 1], p2 = job.q[3 * (size_t)i + 2];
+      if (job.xf != nullptr) xf_point(job.xf, p0, p1, p2, qx, qy, qz);  // same rounded operations as phase 1
+      else { qx = p0; qy = p1; qz = p2; }
+    }
+    const int out = job.qidx ? job.qidx[i] : i;
+    double best = job.out_d2[out];
+    int bi = job.out_idx[out];
+    if (bi < 0) bi = 0x7fffffff;
+    const long long first_leaf = g.oct_first_leaf;
+    const int sh = 3 * g.oct_depth;
     int sp = 0;
-    s_stack[sp++][threadIdx.x] = 0;
+    if (l == 0) { s_id[oct][0] = 0; s_lb[oct][0] = 0.0; }
+    sp = 1;
     while (sp > 0) {
-      int id = s_stack[--sp][threadIdx.x];
-      double lb = box_lb(qx, qy, qz, g.bvh + 6 * (size_t)id);
-      ++n_nodes;
-      if (lb > best) continue;
-      while (true) {
-        const int level = 31 - __clz(id + 1);
-        if (level == D) {
-          const long long j = (long long)id - ((1ll << D) - 1);
-          const int lo = (int)((j * g.n) >> D), hi = (int)(((j + 1) * g.n) >> D);
-          scan_range(g, lo, hi, qx, qy, qz, best, bi);
-          n_cand += (unsigned)(hi - lo);
-          break;
+      --sp;
+      const int id = s_id[oct][sp];
+      const double lbp = s_lb[oct][sp];
+      if (lbp > best) continue;
+      if (id >= first_leaf) {
+        const long long j = (long long)id - first_leaf;
+        const int lo = (int)((j * g.n) >> sh), hi = (int)(((j + 1) * g.n) >> sh);
+        double d = 1.7976931348623157e308;
+        int oi = 0x7fffffff;
+        for (int k = lo + l; k < hi; k += 8) {
+          const double2* p = reinterpret_cast<const double2*>(g.srec + k);
+          const double2 a = p[0], b = p[1];
+          const double dk = dist2(qx, qy, qz, a.x, a.y, b.x);
+          const int ok = (int)__double_as_longlong(b.y);
+          if (dk < d || (dk == d && ok < oi)) { d = dk; oi = ok; }
         }
-        const int c0 = 2 * id + 1, c1 = c0 + 1;
-        const double l0 = box_lb(qx, qy, qz, g.bvh + 6 * (size_t)c0);
-        const double l1 = box_lb(qx, qy, qz, g.bvh + 6 * (size_t)c1);
-        n_nodes += 2;
-        const bool first0 = l0 <= l1;
-        const int nearc = first0 ? c0 : c1, farc = first0 ? c1 : c0;
-        const double ln = first0 ? l0 : l1, lf = first0 ? l1 : l0;
-        if (lf <= best) s_stack[sp++][threadIdx.x] = farc;
-        if (ln > best) break;
-        id = nearc;
+        n_cand += (unsigned)(hi - lo);
+        // octet arg-min with the (d2, index) total order
+#pragma unroll
+        for (int m = 1; m < 8; m <<= 1) {
+          const double od = __shfl_xor(d, m, 64);
+          const int oo = __shfl_xor(oi, m, 64);
+          if (od < d || (od == d && oo < oi)) { d = od; oi = oo; }
+        }
+        if (d < best || (d == best && oi < bi)) { best = d; bi = oi; }
+        continue;
       }
+      // internal node: one child box per lane (32 B each, 256 B contiguous per octet)
+      const float4* bx = reinterpret_cast<const float4*>(g.oct + 8 * ((size_t)8 * id + 1 + l));
+      const float4 a = bx[0], b = bx[1];
+      const double lb = oct_box_lb(qx, qy, qz, a, b);
+      n_nodes += 8;
+      const bool pass = lb <= best;
+      // rank among the passing children by (lb, lane): nearest gets rank 0
+      int rank = 0, npass = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const double lj = __shfl(lb, obase + j, 64);
+        const bool pj = lj <= best;
+        npass += pj ? 1 : 0;
+        rank += (pj && (lj < lb || (lj == lb && j < l))) ? 1 : 0;
+      }
+      if (pass) {
+        const int pos = sp + (npass - 1 - rank);  // nearest on top
+        s_id[oct][pos] = 8 * id + 1 + l;
+        s_lb[oct][pos] = lb;
+      }
+      sp += npass;
+    }
+    if (l == 0) {
+      job.out_idx[out] = bi == 0x7fffffff ? -1 : bi;
+      job.out_d2[out] = best;
     }
   }
-  if (bi == 0x7fffffff) bi = -1;
-  job.out_idx[out] = bi;
-  job.out_d2[out] = best;
   if (stats) {
-    // candidate / node census for the algorithmic-byte model: one slot per wave, no atomics
-    // (hot-address atomics would throttle the kernel being measured); summed by census_sum_kernel.
-    // NOTE: lanes that returned early (i >= n) never get here; their slot share stays zero.
-    unsigned long long c = n_cand, nd = n_nodes, far = resolved ? 0 : 1;
-    c = __reduce_add_u64(c); nd = __reduce_add_u64(nd); far = __reduce_add_u64(far);
-    const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + (threadIdx.x >> 6);
-    if (__lane0()) { stats[3 * slot] = c; stats[3 * slot + 1] = nd; stats[3 * slot + 2] = far; }
+    // every lane of an octet counted the same work: keep one lane per octet
+    unsigned long long c = l == 0 ? n_cand : 0, nd = l == 0 ? n_nodes : 0;
+    c = __reduce_add_u64(c); nd = __reduce_add_u64(nd);
+    const size_t slot = ((size_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6)) % stats_slots;
+    if (__lane0()) { atomicAdd(&stats[3 * slot], c); atomicAdd(&stats[3 * slot + 1], nd); }
   }
 }
 
@@ -386,6 +476,32 @@ int build_grid(mvicp_ctx* c, FrameDev& f, const double* xyz) {
     for (int ax = 0; ax < 3; ++ax) { bx[ax] = std::min(l[ax], r[ax]); bx[3 + ax] = std::max(l[3 + ax], r[3 + ax]); }
   }
 
+  // implicit complete 8-ary box tree over the sorted array (phase 2 of the grid kernel): 32-B boxes {lo.xyz, hi.xyz, pad}
+  int D8 = 0;
+  while ((1ll << (3 * (D8 + 1))) <= (long long)n / 6) ++D8;
+  const long long leaves8 = 1ll << (3 * D8);
+  const long long first_leaf8 = (leaves8 - 1) / 7;
+  const long long nodes8 = first_leaf8 + leaves8;
+  std::vector<float> oct(8 * (size_t)nodes8, 0.f);
+  for (long long j = 0; j < leaves8; ++j) {
+    const int a = (int)((j * n) >> (3 * D8)), b = (int)(((j + 1) * n) >> (3 * D8));
+    float* bx = &oct[8 * (size_t)(first_leaf8 + j)];
+    bx[0] = bx[1] = bx[2] = finf; bx[3] = bx[4] = bx[5] = -finf;
+    for (int k = a; k < b; ++k)
+      for (int ax = 0; ax < 3; ++ax) { bx[ax] = std::min(bx[ax], down(spts[3 * (size_t)k + ax])); bx[3 + ax] = std::max(bx[3 + ax], up(spts[3 * (size_t)k + ax])); }
+  }
+  for (long long id = first_leaf8 - 1; id >= 0; --id) {
+    float* bx = &oct[8 * (size_t)id];
+    bx[0] = bx[1] = bx[2] = finf; bx[3] = bx[4] = bx[5] = -finf;
+    for (int ch = 1; ch <= 8; ++ch) {
+      const float* cb = &oct[8 * (size_t)(8 * id + ch)];
+      for (int ax = 0; ax < 3; ++ax) { bx[ax] = std::min(bx[ax], cb[ax]); bx[3 + ax] = std::max(bx[3 + ax], cb[3 + ax]); }
+    }
+  }
+  G.oct_depth = D8; G.oct_first_leaf = first_leaf8;
+  MV_HIP(hipMalloc((void**)&G.oct, sizeof(float) * oct.size()));
+  MV_HIP(hipMemcpy(G.oct, oct.data(), sizeof(float) * oct.size(), hipMemcpyHostToDevice));
+
   // upload
   G.dims[0] = g.d[0]; G.dims[1] = g.d[1]; G.dims[2] = g.d[2];
   G.origin[0] = g.o[0]; G.origin[1] = g.o[1]; G.origin[2] = g.o[2];
@@ -419,6 +535,7 @@ void free_grid(GridDev& g) {
   if (g.table) (void)hipFree(g.table);
   if (g.bvh) (void)hipFree(g.bvh);
   if (g.wide) (void)hipFree(g.wide);
+  if (g.oct) (void)hipFree(g.oct);
   g = GridDev();
 }
 
@@ -431,6 +548,7 @@ GridView view_of(const FrameDev& f) {
   v.ox = g.origin[0]; v.oy = g.origin[1]; v.oz = g.origin[2]; v.h = g.cell; v.inv_h = g.inv_cell;
   v.dx = g.dims[0]; v.dy = g.dims[1]; v.dz = g.dims[2];
   v.bvh = g.bvh; v.depth = g.depth;
+  v.oct = g.oct; v.oct_depth = g.oct_depth; v.oct_first_leaf = g.oct_first_leaf;
   return v;
 }
 
@@ -455,12 +573,25 @@ int run(mvicp_ctx* c, const std::vector<GridJob>& jobs, double bound) {
     d_stats = (unsigned long long*)c->d_census;
     MV_HIP(hipMemsetAsync(d_stats, 0, need, c->stream));
   }
+  // far list: (job, query) pairs, worst case every query
+  const size_t total_q = (size_t)nq;
+  if (total_q > c->far_cap) {
+    if (c->d_far_list) MV_HIP(hipFree(c->d_far_list));
+    MV_HIP(hipMalloc((void**)&c->d_far_list, sizeof(int2) * total_q));
+    c->far_cap = total_q;
+  }
+  if (!c->d_far_count) MV_HIP(hipMalloc((void**)&c->d_far_count, sizeof(unsigned int)));
+  MV_HIP(hipMemsetAsync(c->d_far_count, 0, sizeof(unsigned int), c->stream));
   {
     ProfScope ps(c, "nn", (36.0 + (c->nn_tree_only ? 0.0 : 128.0)) * nq);  // query 24 B + result 12 B + 8 hash slots x 16 B; candidate bytes come from the census below
+    const dim3 grid((max_n + NT - 1) / NT, (unsigned)jobs.size());
     if (c->nn_tree_only)
-      hipLaunchKernelGGL((nn_grid_kernel<true>), dim3((max_n + NT - 1) / NT, (unsigned)jobs.size()), dim3(NT), 0, c->stream, d_jobs, bound, d_stats, 0);
+      hipLaunchKernelGGL((nn_grid_kernel<true>), grid, dim3(NT), 0, c->stream, d_jobs, bound, d_stats, 0, (int2*)c->d_far_list, c->d_far_count);
     else
-      hipLaunchKernelGGL((nn_grid_kernel<false>), dim3((max_n + NT - 1) / NT, (unsigned)jobs.size()), dim3(NT), 0, c->stream, d_jobs, bound, d_stats, c->nn_skip_far ? 1 : 0);
+      hipLaunchKernelGGL((nn_grid_kernel<false>), grid, dim3(NT), 0, c->stream, d_jobs, bound, d_stats, c->nn_skip_far ? 1 : 0, (int2*)c->d_far_list, c->d_far_count);
+    // phase 2: persistent grid-stride launch (the far count is only known on the device)
+    const unsigned int far_blocks = (unsigned int)std::min<size_t>(256 * 8, (total_q * 8 + NT - 1) / NT);
+    hipLaunchKernelGGL(nn_far_kernel, dim3(far_blocks), dim3(NT), 0, c->stream, d_jobs, (const int2*)c->d_far_list, c->d_far_count, d_stats, slots);
   }
   MV_HIP(hipGetLastError());
   if (d_stats) {

@@ -17,8 +17,9 @@ for tgt in targets:
     eng.set_graph(pb["src"], pb["dst"])
     eng.profile(True)
     for name, poses in (("init", pb["init"]), ("gt", pb["gt"])):
-        for mode in ("grid", "tile"):
+        for mode in ("grid", "hash-only", "tile"):
             M = L.NN_TILE if mode == "tile" else L.NN_GRID
+            eng.set_option("nn_skip_far", 1 if mode == "hash-only" else 0)
             eng.set_option("nn_census", 1)
             eng.profile_reset()
             eng.correspond(poses, pb["fixed"], 0.05, M)
