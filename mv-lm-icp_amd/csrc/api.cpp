@@ -87,7 +87,7 @@ template <typename T> void dev_free(T*& p) {
 
 void free_graph(mvicp_ctx* c) {
   dev_free(c->d_esrc); dev_free(c->d_edst); dev_free(c->d_cap_off); dev_free(c->d_nsrc); dev_free(c->d_count); dev_free(c->d_a);
-  dev_free(c->d_xf); dev_free(c->d_rel); dev_free(c->d_nn_idx); dev_free(c->d_nn_d2); dev_free(c->d_first); dev_free(c->d_second);
+  dev_free(c->d_xf); dev_free(c->d_rel); dev_free(c->d_nn_idx); dev_free(c->d_nn_d2); dev_free(c->d_nn_lb); dev_free(c->d_first); dev_free(c->d_second);
   dev_free(c->d_cd2); dev_free(c->d_stream); dev_free(c->d_cblock_off); dev_free(c->d_cblock_cnt); dev_free(c->d_sel_prefix);
   dev_free(c->d_sel_k); dev_free(c->d_sel_hist); dev_free(c->d_median); dev_free(c->d_chunk_edge); dev_free(c->d_chunk_start);
   dev_free(c->d_chunk_first); dev_free(c->d_partials); dev_free(c->d_out);
@@ -244,6 +244,11 @@ int mvicp_set_frame(mvicp_ctx* c, int frame, const double* xyz, const double* nr
     MV_CHECK(dev_alloc(&f.nor, 3 * (size_t)n));
     if (n) MV_HIP(hipMemcpy(f.nor, nrm, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice));
   }
+  f.max_norm = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const double* p = xyz + 3 * (size_t)i;
+    f.max_norm = std::max(f.max_norm, std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]));
+  }
   if (n > 0) MV_CHECK(build_grid(c, f, xyz));
   return MVICP_OK;
 }
@@ -340,7 +345,8 @@ int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) {
   MV_CHECK(dev_alloc(&c->d_esrc, E)); MV_CHECK(dev_alloc(&c->d_edst, E)); MV_CHECK(dev_alloc(&c->d_cap_off, E + 1));
   MV_CHECK(dev_alloc(&c->d_nsrc, E)); MV_CHECK(dev_alloc(&c->d_count, E)); MV_CHECK(dev_alloc(&c->d_a, E));
   MV_CHECK(dev_alloc(&c->d_xf, (size_t)E * kEdgeXf)); MV_CHECK(dev_alloc(&c->d_rel, (size_t)E * kEdgeRel));
-  MV_CHECK(dev_alloc(&c->d_nn_idx, cap)); MV_CHECK(dev_alloc(&c->d_nn_d2, cap));
+  MV_CHECK(dev_alloc(&c->d_nn_idx, cap)); MV_CHECK(dev_alloc(&c->d_nn_d2, cap)); MV_CHECK(dev_alloc(&c->d_nn_lb, cap));
+  c->nn_cache_valid = false; c->prev_q.assign((size_t)E * 12, 0.0);
   MV_CHECK(dev_alloc(&c->d_first, cap)); MV_CHECK(dev_alloc(&c->d_second, cap)); MV_CHECK(dev_alloc(&c->d_cd2, cap));
   MV_CHECK(dev_alloc(&c->d_stream, 9 * cap));
   MV_CHECK(dev_alloc(&c->d_cblock_off, E + 1)); MV_CHECK(dev_alloc(&c->d_cblock_cnt, (size_t)c->n_cblocks));
@@ -386,6 +392,22 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
       for (int i = 0; i < 3; ++i) { x[i + 3 * j] = Ps[i + 4 * j]; Rd[i + 3 * j] = Pd[i + 4 * j]; }
     for (int i = 0; i < 3; ++i) { x[9 + i] = Ps[12 + i]; x[21 + i] = Pd[12 + i]; }
     inverse3(Rd, x + 12);
+    // temporal cache: q = M p + v with M = Rd^-1 Rs, v = Rd^-1 (ts - td).  Between two searches every query of the edge
+    // moves by at most ||dM||_F max|p| + |dv|  (+ a rounding allowance far above the 1e-16-relative error of the fp64 map).
+    double Mq[12];
+    for (int j = 0; j < 3; ++j)
+      for (int i = 0; i < 3; ++i) Mq[i + 3 * j] = x[12 + i] * x[0 + 3 * j] + x[12 + i + 3] * x[1 + 3 * j] + x[12 + i + 6] * x[2 + 3 * j];
+    const double dt[3] = {x[9] - x[21], x[10] - x[22], x[11] - x[23]};
+    for (int i = 0; i < 3; ++i) Mq[9 + i] = x[12 + i] * dt[0] + x[12 + i + 3] * dt[1] + x[12 + i + 6] * dt[2];
+    double* pq = &c->prev_q[(size_t)e * 12];
+    double dM = 0.0, dv = 0.0, scale = 0.0;
+    for (int k = 0; k < 9; ++k) dM += (Mq[k] - pq[k]) * (Mq[k] - pq[k]);
+    for (int k = 0; k < 3; ++k) { dv += (Mq[9 + k] - pq[9 + k]) * (Mq[9 + k] - pq[9 + k]); scale = std::max(scale, std::fabs(Mq[9 + k])); }
+    const double rmax = c->frames[c->esrc[e]].max_norm;
+    const double eps = std::sqrt(dM) * rmax + std::sqrt(dv) + 1e-12 * (rmax + scale + 1.0);
+    x[24] = (c->nn_cache_valid && c->nn_cache_enable && c->active[e] && (int)c->nn_cache_edge.size() == E && c->nn_cache_edge[e] && c->nn_cache_thresh == thresh) ? eps : -1.0;
+    x[25] = 0.0;
+    std::memcpy(pq, Mq, sizeof(Mq));
   }
   MV_HIP(hipMemcpyAsync(c->d_xf, hx, sizeof(double) * (size_t)E * kEdgeXf, hipMemcpyHostToDevice, c->stream));
   MV_HIP(hipStreamSynchronize(c->stream));
@@ -415,6 +437,10 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   else if (method == MVICP_NN_GRID) MV_CHECK(launch_nn_grid_edges(c, bound));
   else if (method == MVICP_NN_TILE) MV_CHECK(launch_nn_tile_edges(c, bound));
   else { set_error("unknown nn_method %d", nn_method); return MVICP_ERR_ARG; }
+  // only the grid kernel maintains the per-query lower bounds the temporal cache needs; the cutoff must not change either
+  c->nn_cache_valid = (method == MVICP_NN_GRID) && !c->nn_tree_only && !c->nn_skip_far;
+  c->nn_cache_thresh = thresh;
+  c->nn_cache_edge.assign(c->active.begin(), c->active.end());
 
   MV_CHECK(launch_compact(c, bound));
   MV_CHECK(launch_gather_stream(c));
@@ -529,6 +555,7 @@ int mvicp_set_option(mvicp_ctx* c, const char* name, double value) {
   MV_CHECK(bind(c));
   if (!name) { set_error("null option name"); return MVICP_ERR_ARG; }
   if (std::strcmp(name, "nn_tree_only") == 0) { c->nn_tree_only = value != 0.0; return MVICP_OK; }
+  if (std::strcmp(name, "nn_cache") == 0) { c->nn_cache_enable = value != 0.0; c->nn_cache_valid = false; return MVICP_OK; }
   if (std::strcmp(name, "nn_census") == 0) { c->nn_census = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "nn_skip_far") == 0) { c->nn_skip_far = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "grid_target") == 0) {

@@ -32,7 +32,8 @@ void set_error(const char* fmt, ...);
 constexpr int kLinPartial = 32;      // doubles per linearize workgroup partial (28 plane / 29 point, padded)
 constexpr int kLinThreads = 256;
 constexpr int kCompactBlock = 1024;  // queries per compaction workgroup
-constexpr int kEdgeXf = 24;          // Rs(9) ts(3) Rdinv(9) td(3), column-major
+constexpr int kEdgeXf = 26;          // Rs(9) ts(3) Rdinv(9) td(3), column-major; [24] = query displacement bound since the
+                                     // last search (metres, < 0: no temporal cache for this edge), [25] = spare
 constexpr int kEdgeRel = 12;         // R_ds(9, column-major) t_ds(3)
 
 // Uniform grid (spatial hash) over one cloud; see nn_grid.hip.
@@ -66,6 +67,7 @@ struct FrameDev {
   double* nor = nullptr;  // n x 3 or null
   GridDev grid;
   bool has_grid = false;
+  double max_norm = 0.0;   // max |p| over the cloud (bounds how far a pose change can move a query)
 };
 
 struct ProfEntry {
@@ -107,6 +109,10 @@ struct mvicp_ctx {
   double* d_rel = nullptr;          // E x kEdgeRel
   // per-query (total_cap)
   int* d_nn_idx = nullptr; double* d_nn_d2 = nullptr;
+  double* d_nn_lb = nullptr;        // lower bound on the DISTANCE from the query to every target other than nn_idx (temporal cache)
+  bool nn_cache_valid = false; bool nn_cache_enable = true; float nn_cache_thresh = -1.f;
+  std::vector<char> nn_cache_edge;  // edges searched (active) in the last grid search
+  std::vector<double> prev_q;       // E x 12: query map M = Rd^-1 Rs (9, col-major) and v = Rd^-1 (ts - td) of the last search
   // per-correspondence (total_cap)
   int* d_first = nullptr; int* d_second = nullptr; double* d_cd2 = nullptr;
   double* d_stream = nullptr;       // 9 x total_cap SoA: px py pz qx qy qz nx ny nz

@@ -59,6 +59,8 @@ struct GridJob {
   const double* xf;                  // kEdgeXf or null
   int n;
   int* out_idx; double* out_d2;
+  const double* tgt;   // target cloud in ORIGINAL order (n_dst x 3): re-evaluating a cached neighbour
+  double* out_lb;      // per query: lower bound on the distance to every target other than out_idx (null: no cache)
 };
 
 __host__ __device__ __forceinline__ unsigned long long cell_key(int ix, int iy, int iz) {
@@ -93,15 +95,19 @@ __device__ __forceinline__ double box_lb(double qx, double qy, double qz, const 
   return __dadd_rn(__dadd_rn(__dmul_rn(g0, g0), __dmul_rn(g1, g1)), __dmul_rn(g2, g2));
 }
 
-__device__ __forceinline__ void scan_range(const GridView& g, int lo, int hi, double qx, double qy, double qz, double& best, int& bi) {
+// keeps the running (d2, index) minimum AND `second` = the smallest d2 among all other scanned candidates
+__device__ __forceinline__ void scan_range(const GridView& g, int lo, int hi, double qx, double qy, double qz, double& best, int& bi, double& second) {
 #pragma unroll 2
   for (int j = lo; j < hi; ++j) {
     const double2* p = reinterpret_cast<const double2*>(g.srec + j);  // two 16-B loads per candidate
     const double2 a = p[0], b = p[1];
     const double d = dist2(qx, qy, qz, a.x, a.y, b.x);
-    if (d <= best) {
-      const int oi = (int)__double_as_longlong(b.y);
-      if (d < best || oi < bi) { best = d; bi = oi; }
+    const int oi = (int)__double_as_longlong(b.y);
+    if (d < best || (d == best && oi < bi)) {
+      if (bi != 0x7fffffff) second = fmin(second, best);
+      best = d; bi = oi;
+    } else {
+      second = fmin(second, d);
     }
   }
 }
@@ -148,7 +154,33 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
   int bi = 0x7fffffff;
   bool resolved = false;
   unsigned int n_cand = 0;
+  double second = 1.7976931348623157e308;
 
+  // ---- temporal cache.  Last search left, per query, its neighbour p1 and a lower bound L on the distance to every
+  // OTHER target.  Since then the query moved by at most eps (pose update), so every other target is still >= L - eps
+  // away; if the re-evaluated distance to p1 is strictly below that, p1 is still the unique nearest neighbour and its
+  // exact squared distance (reference arithmetic) is the answer — no search.  Relative 1e-12 slack covers sqrt rounding.
+  const double eps = has_xf ? sxf[24] : -1.0;
+  if (!TREE_ONLY && eps >= 0.0 && job.out_lb != nullptr) {
+    const int pi = job.out_idx[out];
+    if (pi >= 0) {
+      const double* tp = job.tgt + 3 * (size_t)pi;
+      const double d = dist2(qx, qy, qz, tp[0], tp[1], tp[2]);
+      const double nlb = job.out_lb[out] - eps;
+      if (sqrt(d) * (1.0 + 1e-12) < nlb) {
+        job.out_d2[out] = d;
+        job.out_lb[out] = nlb;
+        if (stats) {
+          unsigned long long c1 = __reduce_add_u64(1ull);
+          const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + (threadIdx.x >> 6);
+          if (__lane0()) atomicAdd(&stats[3 * slot], c1);
+        }
+        return;
+      }
+    }
+  }
+
+  double m2 = 0.0;
   if (!TREE_ONLY) {
     // 2x2x2 block of cells nearest to the query, through the spatial hash
     const double cx = (qx - g.ox) * g.inv_h - 0.5, cy = (qy - g.oy) * g.inv_h - 0.5, cz = (qz - g.oz) * g.inv_h - 0.5;
@@ -181,7 +213,7 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
     }
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      scan_range(g, (int)ent[c].start, (int)(ent[c].start + ent[c].count), qx, qy, qz, best, bi);
+      scan_range(g, (int)ent[c].start, (int)(ent[c].start + ent[c].count), qx, qy, qz, best, bi, second);
       n_cand += ent[c].count;
     }
     // every point outside the block differs from q by at least `m` along some axis (cells are assigned with
@@ -189,11 +221,14 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
     const double fx = g.ox + bx * g.h, fy = g.oy + by * g.h, fz = g.oz + bz * g.h;
     double m = fmin(fmin(qx - fx, fx + 2.0 * g.h - qx), fmin(fmin(qy - fy, fy + 2.0 * g.h - qy), fmin(qz - fz, fz + 2.0 * g.h - qz)));
     m *= 0.999;
-    resolved = (m > 0.0) && (best < m * m) && (bi != 0x7fffffff);
+    m2 = m > 0.0 ? m * m : 0.0;
+    resolved = (m > 0.0) && (best < m2) && (bi != 0x7fffffff);
   }
   // provisional (or final) result; phase 2 re-reads it as the seed of the tree descent
   job.out_idx[out] = bi == 0x7fffffff ? -1 : bi;
   job.out_d2[out] = best;
+  // every other target is either a scanned candidate (>= second) or outside the block (>= m)
+  if (job.out_lb != nullptr) job.out_lb[out] = resolved ? sqrt(fmin(second, m2)) * (1.0 - 1e-12) : 0.0;
   if (!resolved && !skip_far) {
     // wave-aggregated append: one atomic per wave
     const unsigned long long mask = __ballot(1);
@@ -211,7 +246,7 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
     unsigned long long c = n_cand, far = resolved ? 0 : 1;
     c = __reduce_add_u64(c); far = __reduce_add_u64(far);
     const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + (threadIdx.x >> 6);
-    if (__lane0()) { stats[3 * slot] = c; stats[3 * slot + 2] = far; }
+    if (__lane0()) { atomicAdd(&stats[3 * slot], c); atomicAdd(&stats[3 * slot + 2], far); }
   }
 }
 
@@ -257,6 +292,8 @@ __global__ __launch_bounds__(NT) void nn_far_kernel(const GridJob* __restrict__ 
     double best = job.out_d2[out];
     int bi = job.out_idx[out];
     if (bi < 0) bi = 0x7fffffff;
+    double second = 1.7976931348623157e308;   // smallest d2 among scanned targets other than the running best
+    double pruned = 1.7976931348623157e308;   // smallest lower bound among the boxes this lane skipped
     const long long first_leaf = g.oct_first_leaf;
     const int sh = 3 * g.oct_depth;
     int sp = 0;
@@ -266,28 +303,42 @@ __global__ __launch_bounds__(NT) void nn_far_kernel(const GridJob* __restrict__ 
       --sp;
       const int id = s_id[oct][sp];
       const double lbp = s_lb[oct][sp];
-      if (lbp > best) continue;
+      if (lbp > best) { pruned = fmin(pruned, lbp); continue; }
       if (id >= first_leaf) {
         const long long j = (long long)id - first_leaf;
         const int lo = (int)((j * g.n) >> sh), hi = (int)(((j + 1) * g.n) >> sh);
-        double d = 1.7976931348623157e308;
+        double d = 1.7976931348623157e308, ls = 1.7976931348623157e308;  // this lane's best and second best in the leaf
         int oi = 0x7fffffff;
         for (int k = lo + l; k < hi; k += 8) {
           const double2* p = reinterpret_cast<const double2*>(g.srec + k);
           const double2 a = p[0], b = p[1];
           const double dk = dist2(qx, qy, qz, a.x, a.y, b.x);
           const int ok = (int)__double_as_longlong(b.y);
-          if (dk < d || (dk == d && ok < oi)) { d = dk; oi = ok; }
+          if (dk < d || (dk == d && ok < oi)) { ls = fmin(ls, d); d = dk; oi = ok; }
+          else ls = fmin(ls, dk);
         }
         n_cand += (unsigned)(hi - lo);
         // octet arg-min with the (d2, index) total order
+        double D = d; int OI = oi;
 #pragma unroll
         for (int m = 1; m < 8; m <<= 1) {
-          const double od = __shfl_xor(d, m, 64);
-          const int oo = __shfl_xor(oi, m, 64);
-          if (od < d || (od == d && oo < oi)) { d = od; oi = oo; }
+          const double od = __shfl_xor(D, m, 64);
+          const int oo = __shfl_xor(OI, m, 64);
+          if (od < D || (od == D && oo < OI)) { D = od; OI = oo; }
         }
-        if (d < best || (d == best && oi < bi)) { best = d; bi = oi; }
+        // smallest d2 in the leaf among the points that are NOT the leaf winner
+        double other = (oi == OI) ? ls : d;
+#pragma unroll
+        for (int m = 1; m < 8; m <<= 1) other = fmin(other, __shfl_xor(other, m, 64));
+        if (OI == bi) {                      // the running best itself was rescanned (seed from phase 1)
+          second = fmin(second, other);
+        } else if (D < best || (D == best && OI < bi)) {
+          if (bi != 0x7fffffff) second = fmin(second, best);
+          second = fmin(second, other);
+          best = D; bi = OI;
+        } else {
+          second = fmin(second, D);
+        }
         continue;
       }
       // internal node: one child box per lane (32 B each, 256 B contiguous per octet)
@@ -296,6 +347,7 @@ __global__ __launch_bounds__(NT) void nn_far_kernel(const GridJob* __restrict__ 
       const double lb = oct_box_lb(qx, qy, qz, a, b);
       n_nodes += 8;
       const bool pass = lb <= best;
+      if (!pass) pruned = fmin(pruned, lb);
       // rank among the passing children by (lb, lane): nearest gets rank 0
       int rank = 0, npass = 0;
 #pragma unroll
@@ -312,9 +364,13 @@ __global__ __launch_bounds__(NT) void nn_far_kernel(const GridJob* __restrict__ 
       }
       sp += npass;
     }
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) pruned = fmin(pruned, __shfl_xor(pruned, m, 64));
     if (l == 0) {
       job.out_idx[out] = bi == 0x7fffffff ? -1 : bi;
       job.out_d2[out] = best;
+      // every other target was scanned (>= second) or sits in a skipped box (>= its lower bound)
+      if (job.out_lb != nullptr) job.out_lb[out] = bi == 0x7fffffff ? 0.0 : sqrt(fmin(second, pruned)) * (1.0 - 1e-12);
     }
   }
   if (stats) {
@@ -618,6 +674,7 @@ int launch_nn_grid_edges(mvicp_ctx* c, double d2_bound) {
     j.dst = view_of(d);
     j.q = s.grid.spts; j.qidx = s.grid.sidx; j.xf = c->d_xf + (size_t)e * kEdgeXf; j.n = s.n;
     j.out_idx = c->d_nn_idx + c->cap_off[e]; j.out_d2 = c->d_nn_d2 + c->cap_off[e];
+    j.tgt = d.pts; j.out_lb = c->d_nn_lb + c->cap_off[e];
     jobs.push_back(j);
   }
   return run(c, jobs, d2_bound);
@@ -629,6 +686,7 @@ int launch_nn_grid_queries(mvicp_ctx* c, const FrameDev& f, const double* d_q, i
   jobs[0].dst = view_of(f);
   jobs[0].q = d_q; jobs[0].qidx = nullptr; jobs[0].xf = nullptr; jobs[0].n = n;
   jobs[0].out_idx = d_idx; jobs[0].out_d2 = d_d2;
+  jobs[0].tgt = f.pts; jobs[0].out_lb = nullptr;
   return run(c, jobs, 1.7976931348623157e308);
 }
 

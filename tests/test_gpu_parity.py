@@ -407,3 +407,50 @@ def test_linearised_point_to_plane_matches_closed_form(eng):
     r = np.sum((src - dst) * nor, axis=1)
     assert np.allclose(H[:6, :6], u.T @ u, rtol=1e-11) and np.allclose(g[:6], u.T @ r, rtol=1e-9, atol=1e-15)
     assert np.isclose(cost, 0.5 * np.sum(r * r), rtol=1e-12)
+
+
+# ---------------------------------------------------------------- temporal NN cache
+def test_temporal_cache_is_bit_identical_to_full_search(orc):
+    """From the second grid search on, a query whose previous neighbour is provably still nearest (re-evaluated distance
+    below the stored lower bound on all other targets minus the pose-induced displacement) skips the search.  Every round
+    must give exactly the lists a fresh full search gives, and the oracle's."""
+    pb = synth.make_problem(4, 6000)
+    engs = []
+    for cache in (1, 0):
+        e = mvicp.Engine(0)
+        e.set_option("nn_cache", cache)
+        e.set_frames(pb["pts"], pb["nor"]); e.set_graph(pb["src"], pb["dst"])
+        e.profile(True); e.set_option("nn_census", 1)
+        engs.append(e)
+    poses = pb["init"].copy()
+    hits = []
+    for r in range(9):
+        res = []
+        for e in engs:
+            e.profile_reset()
+            c, w = e.correspond(poses, pb["fixed"], 0.05, L.NN_GRID)
+            res.append((c, w, [e.get_correspondences(k) for k in range(e.E)], e.nn_census()))
+        (c1, w1, l1, s1), (c0, w0, l0, s0) = res
+        assert np.array_equal(c1, c0) and np.array_equal(w1, w0), r
+        for a, b in zip(l1, l0):
+            assert all(np.array_equal(x, y) for x, y in zip(a, b)), r
+        hits.append(s1["candidates"] / s1["queries"])
+        if r in (0, 8):
+            for k, (s, d) in enumerate(zip(pb["src"], pb["dst"])):
+                f, sec, dist, wt, _, _ = orc.correspond_edge(pb["pts"][s], poses[s], pb["pts"][d], poses[d], 0.05)
+                assert np.array_equal(l1[k][0], f) and np.array_equal(l1[k][1], sec) and np.array_equal(l1[k][2], dist) and w1[k] == wt
+        poses, sm = engs[0].optimize(poses, pb["fixed"], L.PARAM_SOPHUS_SE3, 1, True, 50)
+    # the cache must actually engage once the poses settle (candidates examined per query collapse towards 1)
+    assert hits[-1] < 0.2 * hits[0], hits
+    # a changed cutoff or a perturbed pose must fall back to searching and stay exact
+    poses2 = poses.copy(); poses2[2][:3, 3] += [0.004, -0.003, 0.002]
+    for e in engs:
+        e.correspond(poses2, pb["fixed"], 0.05, L.NN_GRID)
+    for k in range(engs[0].E):
+        assert all(np.array_equal(x, y) for x, y in zip(engs[0].get_correspondences(k), engs[1].get_correspondences(k)))
+    for e in engs:
+        e.correspond(poses2, pb["fixed"], 0.01, L.NN_GRID)
+    for k in range(engs[0].E):
+        assert all(np.array_equal(x, y) for x, y in zip(engs[0].get_correspondences(k), engs[1].get_correspondences(k)))
+    for e in engs:
+        e.close()
