@@ -156,7 +156,7 @@ int evaluate_blocks(mvicp_ctx* c, const double* poses, int plane, int robust, do
   if (!c->have_corr) { set_error("no correspondences: call mvicp_correspond or mvicp_set_correspondences first"); return MVICP_ERR_STATE; }
   if (plane) {
     for (int e = 0; e < c->E; ++e)
-      if (c->owned[e] && c->h_count[e] > 0 && c->frames[c->edst[e]].nor == nullptr) {
+      if (c->owned[e] && c->h_count[e] > 0 && c->frames[c->edst[e]].grid.snor == nullptr) {
         set_error("point-to-plane needs normals on frame %d", c->edst[e]);
         return MVICP_ERR_STATE;
       }
@@ -250,6 +250,12 @@ int mvicp_set_frame(mvicp_ctx* c, int frame, const double* xyz, const double* nr
     f.max_norm = std::max(f.max_norm, std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]));
   }
   if (n > 0) MV_CHECK(build_grid(c, f, xyz));
+  if (n > 0 && nrm) {
+    std::vector<double> sn(3 * (size_t)n);
+    for (int i = 0; i < n; ++i) std::memcpy(&sn[3 * (size_t)i], nrm + 3 * (size_t)f.grid.h_order[i], 24);
+    MV_CHECK(dev_alloc(&f.grid.snor, 3 * (size_t)n));
+    MV_HIP(hipMemcpy(f.grid.snor, sn.data(), sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice));
+  }
   return MVICP_OK;
 }
 
@@ -259,6 +265,7 @@ int mvicp_recompute_normals(mvicp_ctx* c, int frame, int k, double* nrm_out, int
   FrameDev& f = c->frames[frame];
   if (f.n < k) { set_error("frame %d has %d points < k = %d (common.h:333 asserts >= 3)", frame, f.n, k); return MVICP_ERR_STATE; }
   if (!f.nor) MV_CHECK(dev_alloc(&f.nor, 3 * (size_t)f.n));
+  if (!f.grid.snor) MV_CHECK(dev_alloc(&f.grid.snor, 3 * (size_t)f.n));
   int* d_knn = nullptr;
   if (knn_out) MV_CHECK(dev_alloc(&d_knn, (size_t)f.n * k));
   int st = launch_normals(c, f, k, d_knn);
@@ -480,11 +487,25 @@ int mvicp_get_correspondences(mvicp_ctx* c, int edge, int cap, int* first, int* 
   if (cap < n) { set_error("capacity %d < count %d", cap, n); return MVICP_ERR_ARG; }
   const size_t off = (size_t)c->cap_off[edge];
   MV_HIP(hipStreamSynchronize(c->stream));
-  if (first) MV_HIP(hipMemcpy(first, c->d_first + off, sizeof(int) * n, hipMemcpyDeviceToHost));
-  if (second) MV_HIP(hipMemcpy(second, c->d_second + off, sizeof(int) * n, hipMemcpyDeviceToHost));
-  if (dist) {
-    MV_HIP(hipMemcpy(dist, c->d_cd2 + off, sizeof(double) * n, hipMemcpyDeviceToHost));
-    for (int i = 0; i < n; ++i) dist[i] = std::sqrt(dist[i]);  // frame.cpp:139 pointDist = sqrt(pointDistSquared), IEEE on the host
+  // the device lists hold SORTED positions (Morton order of each cloud) in the source's sorted order; hand them back as
+  // the reference builds them: original indices, ascending `first` (frame.cpp:129,158)
+  std::vector<int> a(n), b(n);
+  std::vector<double> d(n);
+  if (n) {
+    MV_HIP(hipMemcpy(a.data(), c->d_first + off, sizeof(int) * n, hipMemcpyDeviceToHost));
+    MV_HIP(hipMemcpy(b.data(), c->d_second + off, sizeof(int) * n, hipMemcpyDeviceToHost));
+    MV_HIP(hipMemcpy(d.data(), c->d_cd2 + off, sizeof(double) * n, hipMemcpyDeviceToHost));
+  }
+  const std::vector<int>& so = c->frames[c->esrc[edge]].grid.h_order;
+  const std::vector<int>& dorder = c->frames[c->edst[edge]].grid.h_order;
+  std::vector<int> perm(n);
+  for (int i = 0; i < n; ++i) { a[i] = so[a[i]]; b[i] = dorder[b[i]]; perm[i] = i; }
+  std::sort(perm.begin(), perm.end(), [&](int x, int y) { return a[x] < a[y]; });
+  for (int i = 0; i < n; ++i) {
+    const int k = perm[i];
+    if (first) first[i] = a[k];
+    if (second) second[i] = b[k];
+    if (dist) dist[i] = std::sqrt(d[k]);  // frame.cpp:139 pointDist = sqrt(pointDistSquared), IEEE on the host
   }
   return n;
 }
@@ -500,10 +521,16 @@ int mvicp_set_correspondences(mvicp_ctx* c, int edge, int n, const int* first, c
   const size_t off = (size_t)c->cap_off[edge];
   MV_HIP(hipStreamSynchronize(c->stream));
   if (n) {
-    MV_HIP(hipMemcpy(c->d_first + off, first, sizeof(int) * n, hipMemcpyHostToDevice));
-    MV_HIP(hipMemcpy(c->d_second + off, second, sizeof(int) * n, hipMemcpyHostToDevice));
+    // device lists are kept in sorted positions
+    const std::vector<int>& si = c->frames[c->esrc[edge]].grid.h_inv;
+    const std::vector<int>& di = c->frames[c->edst[edge]].grid.h_inv;
+    std::vector<int> a(n), b(n);
+    for (int i = 0; i < n; ++i) { a[i] = si[first[i]]; b[i] = di[second[i]]; }
+    MV_HIP(hipMemcpy(c->d_first + off, a.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+    MV_HIP(hipMemcpy(c->d_second + off, b.data(), sizeof(int) * n, hipMemcpyHostToDevice));
     MV_HIP(hipMemset(c->d_cd2 + off, 0, sizeof(double) * n));
   }
+  c->nn_cache_valid = false;
   const double a = (double)weight;
   MV_HIP(hipMemcpy(c->d_count + edge, &n, sizeof(int), hipMemcpyHostToDevice));
   MV_HIP(hipMemcpy(c->d_a + edge, &a, sizeof(double), hipMemcpyHostToDevice));

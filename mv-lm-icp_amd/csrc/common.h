@@ -45,6 +45,9 @@ struct GridDev {
   double* spts = nullptr;      // n x 3 sorted by Morton(cell)
   int* sidx = nullptr;         // n: original index of sorted point
   void* srec = nullptr;        // n x 32 B {x, y, z, idx}: the same, packed for the per-lane candidate scans
+  double* snor = nullptr;      // n x 3 normals in sorted order (null without normals)
+  int* inv = nullptr;          // n: original index -> sorted position
+  std::vector<int> h_order, h_inv;  // host copies: sorted -> original, original -> sorted
   void* table = nullptr;       // open-addressing hash: cell -> (start, count), 16-B entries
   unsigned int table_mask = 0; int table_shift = 0;
   float* bvh = nullptr;        // implicit complete AABB tree, 6 floats per node (outward rounded)
@@ -60,6 +63,8 @@ struct GridDev {
   long long wide_off[6] = {0, 0, 0, 0, 0, 0};
   double struct_bytes = 0.0;
 };
+
+struct PointRec { double x, y, z; long long idx; };  // 32-B aligned sorted point + original index
 
 struct FrameDev {
   int n = 0;

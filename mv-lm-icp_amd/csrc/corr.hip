@@ -134,8 +134,8 @@ __global__ __launch_bounds__(NT) void scatter_kernel(const int* __restrict__ cbl
 // packed operand stream for the LM evaluations
 __global__ __launch_bounds__(NT) void gather_kernel(const int* __restrict__ cblock_off, int E, const int* __restrict__ count,
                                                     const long long* __restrict__ cap_off, long long total_cap, const int* __restrict__ first,
-                                                    const int* __restrict__ second, const double* const* __restrict__ src_pts,
-                                                    const double* const* __restrict__ dst_pts, const double* const* __restrict__ dst_nor,
+                                                    const int* __restrict__ second, const PointRec* const* __restrict__ src_rec,
+                                                    const PointRec* const* __restrict__ dst_rec, const double* const* __restrict__ dst_nor,
                                                     double* __restrict__ stream) {
   const int b = blockIdx.x;
   const int e = find_edge(cblock_off, E, b);
@@ -143,20 +143,24 @@ __global__ __launch_bounds__(NT) void gather_kernel(const int* __restrict__ cblo
   const int cnt = count[e];
   if (lb * kCompactBlock >= cnt) return;
   const long long base = cap_off[e];
-  const double* __restrict__ sp = src_pts[e];
-  const double* __restrict__ dp = dst_pts[e];
+  const PointRec* __restrict__ sp = src_rec[e];   // first / second are SORTED positions: neighbouring correspondences
+  const PointRec* __restrict__ dp = dst_rec[e];   // read neighbouring records (coherent gathers)
   const double* __restrict__ dn = dst_nor[e];
   for (int i = 0; i < IPT; ++i) {
     const int pos = lb * kCompactBlock + i * NT + threadIdx.x;
     if (pos >= cnt) break;
     const size_t f = (size_t)first[base + pos], s = (size_t)second[base + pos];
     const size_t o = (size_t)(base + pos);
-    stream[0 * total_cap + o] = sp[3 * f];
-    stream[1 * total_cap + o] = sp[3 * f + 1];
-    stream[2 * total_cap + o] = sp[3 * f + 2];
-    stream[3 * total_cap + o] = dp[3 * s];
-    stream[4 * total_cap + o] = dp[3 * s + 1];
-    stream[5 * total_cap + o] = dp[3 * s + 2];
+    const double2* pa = reinterpret_cast<const double2*>(sp + f);
+    const double2 a0 = pa[0], a1 = pa[1];
+    const double2* pb = reinterpret_cast<const double2*>(dp + s);
+    const double2 b0 = pb[0], b1 = pb[1];
+    stream[0 * total_cap + o] = a0.x;
+    stream[1 * total_cap + o] = a0.y;
+    stream[2 * total_cap + o] = a1.x;
+    stream[3 * total_cap + o] = b0.x;
+    stream[4 * total_cap + o] = b0.y;
+    stream[5 * total_cap + o] = b1.x;
     if (dn != nullptr) {
       stream[6 * total_cap + o] = dn[3 * s];
       stream[7 * total_cap + o] = dn[3 * s + 1];
@@ -245,19 +249,19 @@ int launch_compact(mvicp_ctx* c, double d2_bound) {
 int launch_gather_stream(mvicp_ctx* c) {
   if (c->n_cblocks == 0) return MVICP_OK;
   // per-edge base pointers (device table lives in the pinned staging area's device twin: small, rebuilt per call)
-  std::vector<const double*> tab(3 * (size_t)c->E, nullptr);
+  std::vector<const void*> tab(3 * (size_t)c->E, nullptr);
   for (int e = 0; e < c->E; ++e) {
-    tab[e] = c->frames[c->esrc[e]].pts;
-    tab[c->E + e] = c->frames[c->edst[e]].pts;
-    tab[2 * c->E + e] = c->frames[c->edst[e]].nor;
+    tab[e] = c->frames[c->esrc[e]].grid.srec;
+    tab[c->E + e] = c->frames[c->edst[e]].grid.srec;
+    tab[2 * c->E + e] = c->frames[c->edst[e]].grid.snor;
   }
-  const double** d_tab = nullptr;
+  const void** d_tab = nullptr;
   scratch_reset(c);
-  MV_CHECK(scratch_upload(c, tab.data(), sizeof(double*) * tab.size(), (void**)&d_tab));
+  MV_CHECK(scratch_upload(c, tab.data(), sizeof(void*) * tab.size(), (void**)&d_tab));
   {
     ProfScope ps(c, "gather", 0.0);
     hipLaunchKernelGGL(gather_kernel, dim3(c->n_cblocks), dim3(NT), 0, c->stream, c->d_cblock_off, c->E, c->d_count, c->d_cap_off, c->total_cap,
-                       c->d_first, c->d_second, d_tab, d_tab + c->E, d_tab + 2 * c->E, c->d_stream);
+                       c->d_first, c->d_second, (const PointRec* const*)d_tab, (const PointRec* const*)(d_tab + c->E), (const double* const*)(d_tab + 2 * c->E), c->d_stream);
   }
   MV_HIP(hipGetLastError());
   return MVICP_OK;

@@ -28,6 +28,7 @@ struct BruteJob {
   const double* tgt;    // m x 3
   int n, m;
   int* out_idx; double* out_d2;  // final outputs (n)
+  const int* inv;                // target original index -> sorted position (null: emit original indices)
 };
 
 __device__ __forceinline__ void xf_point(const double* __restrict__ x, double p0, double p1, double p2, double& q0, double& q1, double& q2) {
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(NT) void nn_brute_kernel(const BruteJob* __restrict
     const int k = qbase + i * NT + tid;
     if (k >= job.n) continue;
     if (n_splits == 1) {
-      job.out_idx[k] = bi[i];
+      job.out_idx[k] = (bi[i] >= 0 && job.inv) ? job.inv[bi[i]] : bi[i];
       job.out_d2[k] = best[i];
     } else {
       const size_t o = (size_t)split_off[blockIdx.z] + (size_t)blockIdx.y * job.n + k;
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(NT) void nn_brute_merge_kernel(const BruteJob* __re
     const int i = split_idx[o];
     if (i >= 0 && d < best) { best = d; bi = i; }
   }
-  job.out_idx[k] = bi;
+  job.out_idx[k] = (bi >= 0 && job.inv) ? job.inv[bi] : bi;
   job.out_d2[k] = best;
 }
 
@@ -179,7 +180,9 @@ int launch_nn_brute_edges(mvicp_ctx* c) {
     const FrameDev& s = c->frames[c->esrc[e]];
     const FrameDev& d = c->frames[c->edst[e]];
     BruteJob j;
-    j.q = s.pts; j.xf = c->d_xf + (size_t)e * kEdgeXf; j.tgt = d.pts; j.n = s.n; j.m = d.n;
+    // queries in the source's SORTED order (the pipeline's order), targets scanned in original order (lowest original index wins ties)
+    j.q = s.grid.spts; j.xf = c->d_xf + (size_t)e * kEdgeXf; j.tgt = d.pts; j.n = s.n; j.m = d.n;
+    j.inv = d.grid.inv;
     j.out_idx = c->d_nn_idx + c->cap_off[e]; j.out_d2 = c->d_nn_d2 + c->cap_off[e];
     jobs.push_back(j);
   }
@@ -189,7 +192,7 @@ int launch_nn_brute_edges(mvicp_ctx* c) {
 int launch_nn_brute_queries(mvicp_ctx* c, const FrameDev& f, const double* d_q, int n, int* d_idx, double* d_d2) {
   std::vector<BruteJob> jobs(1);
   jobs[0].q = d_q; jobs[0].xf = nullptr; jobs[0].tgt = f.pts; jobs[0].n = n; jobs[0].m = f.n;
-  jobs[0].out_idx = d_idx; jobs[0].out_d2 = d_d2;
+  jobs[0].out_idx = d_idx; jobs[0].out_d2 = d_d2; jobs[0].inv = nullptr;
   return run_jobs(c, jobs, nullptr);
 }
 

@@ -42,8 +42,6 @@ constexpr unsigned long long EMPTY = ~0ull;
 
 struct HashEntry { unsigned long long key; unsigned int start, count; };
 
-struct PointRec { double x, y, z; long long idx; };  // 32-B aligned sorted point + original index
-
 struct GridView {  // device view of one cloud's structure
   const double* spts; const int* sidx; const PointRec* srec; int n;
   const HashEntry* table; unsigned int mask; int shift;
@@ -59,7 +57,7 @@ struct GridJob {
   const double* xf;                  // kEdgeXf or null
   int n;
   int* out_idx; double* out_d2;
-  const double* tgt;   // target cloud in ORIGINAL order (n_dst x 3): re-evaluating a cached neighbour
+  const int* inv;      // target original index -> sorted position (null: emit original indices, raw-query API)
   double* out_lb;      // per query: lower bound on the distance to every target other than out_idx (null: no cache)
 };
 
@@ -148,7 +146,7 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
     if (has_xf) xf_point(sxf, p0, p1, p2, qx, qy, qz);
     else { qx = p0; qy = p1; qz = p2; }
   }
-  const int out = job.qidx ? job.qidx[i] : i;
+  const int out = i;   // results live in the SORTED order of the source cloud (coalesced; the pipeline stays in that order)
 
   double best = bound;      // nothing at or beyond the cutoff bound needs resolving (frame.cpp:156)
   int bi = 0x7fffffff;
@@ -162,10 +160,11 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
   // exact squared distance (reference arithmetic) is the answer — no search.  Relative 1e-12 slack covers sqrt rounding.
   const double eps = has_xf ? sxf[24] : -1.0;
   if (!TREE_ONLY && eps >= 0.0 && job.out_lb != nullptr) {
-    const int pi = job.out_idx[out];
+    const int pi = job.out_idx[out];   // sorted position of last round's neighbour
     if (pi >= 0) {
-      const double* tp = job.tgt + 3 * (size_t)pi;
-      const double d = dist2(qx, qy, qz, tp[0], tp[1], tp[2]);
+      const double2* tp = reinterpret_cast<const double2*>(g.srec + pi);
+      const double2 ta = tp[0], tb = tp[1];
+      const double d = dist2(qx, qy, qz, ta.x, ta.y, tb.x);
       const double nlb = job.out_lb[out] - eps;
       if (sqrt(d) * (1.0 + 1e-12) < nlb) {
         job.out_d2[out] = d;
@@ -225,7 +224,7 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
     resolved = (m > 0.0) && (best < m2) && (bi != 0x7fffffff);
   }
   // provisional (or final) result; phase 2 re-reads it as the seed of the tree descent
-  job.out_idx[out] = bi == 0x7fffffff ? -1 : bi;
+  job.out_idx[out] = bi == 0x7fffffff ? -1 : (job.inv ? job.inv[bi] : bi);
   job.out_d2[out] = best;
   // every other target is either a scanned candidate (>= second) or outside the block (>= m)
   if (job.out_lb != nullptr) job.out_lb[out] = resolved ? sqrt(fmin(second, m2)) * (1.0 - 1e-12) : 0.0;
@@ -288,10 +287,11 @@ __global__ __launch_bounds__(NT) void nn_far_kernel(const GridJob* __restrict__ 
       if (job.xf != nullptr) xf_point(job.xf, p0, p1, p2, qx, qy, qz);  // same rounded operations as phase 1
       else { qx = p0; qy = p1; qz = p2; }
     }
-    const int out = job.qidx ? job.qidx[i] : i;
+    const int out = i;
     double best = job.out_d2[out];
-    int bi = job.out_idx[out];
+    int bi = job.out_idx[out];         // seed from phase 1: sorted position (or original index for raw queries)
     if (bi < 0) bi = 0x7fffffff;
+    else if (job.inv) bi = (int)g.srec[bi].idx;
     double second = 1.7976931348623157e308;   // smallest d2 among scanned targets other than the running best
     double pruned = 1.7976931348623157e308;   // smallest lower bound among the boxes this lane skipped
     const long long first_leaf = g.oct_first_leaf;
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(NT) void nn_far_kernel(const GridJob* __restrict__ 
 #pragma unroll
     for (int m = 1; m < 8; m <<= 1) pruned = fmin(pruned, __shfl_xor(pruned, m, 64));
     if (l == 0) {
-      job.out_idx[out] = bi == 0x7fffffff ? -1 : bi;
+      job.out_idx[out] = bi == 0x7fffffff ? -1 : (job.inv ? job.inv[bi] : bi);
       job.out_d2[out] = best;
       // every other target was scanned (>= second) or sits in a skipped box (>= its lower bound)
       if (job.out_lb != nullptr) job.out_lb[out] = bi == 0x7fffffff ? 0.0 : sqrt(fmin(second, pruned)) * (1.0 - 1e-12);
@@ -576,6 +576,11 @@ int build_grid(mvicp_ctx* c, FrameDev& f, const double* xyz) {
   MV_HIP(hipMalloc((void**)&G.bvh, sizeof(float) * 6 * nodes));
   MV_HIP(hipMemcpy(G.spts, spts.data(), sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice));
   MV_HIP(hipMemcpy(G.sidx, order.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+  G.h_order = order;
+  G.h_inv.assign(n, 0);
+  for (int i = 0; i < n; ++i) G.h_inv[order[i]] = i;
+  MV_HIP(hipMalloc((void**)&G.inv, sizeof(int) * (size_t)std::max(n, 1)));
+  MV_HIP(hipMemcpy(G.inv, G.h_inv.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
   MV_HIP(hipMemcpy(G.table, table.data(), sizeof(HashEntry) * (size_t)tsize, hipMemcpyHostToDevice));
   MV_HIP(hipMemcpy(G.bvh, bvh.data(), sizeof(float) * 6 * nodes, hipMemcpyHostToDevice));
   G.struct_bytes = sizeof(HashEntry) * (double)tsize + sizeof(float) * 6.0 * nodes;
@@ -588,6 +593,8 @@ void free_grid(GridDev& g) {
   if (g.spts) (void)hipFree(g.spts);
   if (g.sidx) (void)hipFree(g.sidx);
   if (g.srec) (void)hipFree(g.srec);
+  if (g.snor) (void)hipFree(g.snor);
+  if (g.inv) (void)hipFree(g.inv);
   if (g.table) (void)hipFree(g.table);
   if (g.bvh) (void)hipFree(g.bvh);
   if (g.wide) (void)hipFree(g.wide);
@@ -672,9 +679,9 @@ int launch_nn_grid_edges(mvicp_ctx* c, double d2_bound) {
     if (!s.has_grid || !d.has_grid) { set_error("grid NN needs the per-cloud structure on frames %d and %d", c->esrc[e], c->edst[e]); return MVICP_ERR_STATE; }
     GridJob j;
     j.dst = view_of(d);
-    j.q = s.grid.spts; j.qidx = s.grid.sidx; j.xf = c->d_xf + (size_t)e * kEdgeXf; j.n = s.n;
+    j.q = s.grid.spts; j.qidx = nullptr; j.xf = c->d_xf + (size_t)e * kEdgeXf; j.n = s.n;
     j.out_idx = c->d_nn_idx + c->cap_off[e]; j.out_d2 = c->d_nn_d2 + c->cap_off[e];
-    j.tgt = d.pts; j.out_lb = c->d_nn_lb + c->cap_off[e];
+    j.inv = d.grid.inv; j.out_lb = c->d_nn_lb + c->cap_off[e];
     jobs.push_back(j);
   }
   return run(c, jobs, d2_bound);
@@ -686,7 +693,7 @@ int launch_nn_grid_queries(mvicp_ctx* c, const FrameDev& f, const double* d_q, i
   jobs[0].dst = view_of(f);
   jobs[0].q = d_q; jobs[0].qidx = nullptr; jobs[0].xf = nullptr; jobs[0].n = n;
   jobs[0].out_idx = d_idx; jobs[0].out_d2 = d_d2;
-  jobs[0].tgt = f.pts; jobs[0].out_lb = nullptr;
+  jobs[0].inv = nullptr; jobs[0].out_lb = nullptr;
   return run(c, jobs, 1.7976931348623157e308);
 }
 

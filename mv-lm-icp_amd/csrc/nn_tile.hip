@@ -45,6 +45,7 @@ struct TileJob {
   TileView dst;
   const double* q; const int* qidx; const double* xf; int n;
   int* out_idx; double* out_d2;
+  const int* inv;   // target original index -> sorted position
 };
 
 __device__ __forceinline__ void xf_point(const double* __restrict__ x, double p0, double p1, double p2, double& q0, double& q1, double& q2) {
@@ -232,8 +233,8 @@ __global__ __launch_bounds__(NT, 6) void nn_tile_kernel(const TileJob* __restric
     default: visit<4>(g, 0, g.cnt[4], L, G, sx, sy, sz, si, &n_cand, &n_box); break;
   }
   if (L.active) {
-    const int out = job.qidx ? job.qidx[i] : i;
-    job.out_idx[out] = L.bi == 0x7fffffff ? -1 : L.bi;
+    const int out = i;   // sorted order of the source cloud
+    job.out_idx[out] = L.bi == 0x7fffffff ? -1 : (job.inv ? job.inv[L.bi] : L.bi);
     job.out_d2[out] = L.best;
   }
   if (stats && (threadIdx.x & 63) == 0) {
@@ -325,8 +326,9 @@ int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound) {
     if (!s.has_grid || !d.has_grid) { set_error("tile NN needs the per-cloud structure on frames %d and %d", c->esrc[e], c->edst[e]); return MVICP_ERR_STATE; }
     TileJob j;
     j.dst = view_of(d);
-    j.q = s.grid.spts; j.qidx = s.grid.sidx; j.xf = c->d_xf + (size_t)e * kEdgeXf; j.n = s.n;
+    j.q = s.grid.spts; j.qidx = nullptr; j.xf = c->d_xf + (size_t)e * kEdgeXf; j.n = s.n;
     j.out_idx = c->d_nn_idx + c->cap_off[e]; j.out_d2 = c->d_nn_d2 + c->cap_off[e];
+    j.inv = d.grid.inv;
     jobs.push_back(j);
     max_n = std::max(max_n, s.n);
     nq += s.n;

@@ -20,7 +20,6 @@ constexpr int KMAX = 16;
 constexpr unsigned long long EMPTY = ~0ull;
 
 struct HashEntry { unsigned long long key; unsigned int start, count; };
-struct PointRec { double x, y, z; long long idx; };
 
 __device__ __forceinline__ unsigned long long cell_key(int ix, int iy, int iz) {
   return (unsigned long long)ix | ((unsigned long long)iy << 21) | ((unsigned long long)iz << 42);
@@ -34,6 +33,7 @@ struct NormJob {
   int dx, dy, dz;
   int k;
   double* nor_out;   // n x 3, original order
+  double* snor_out;  // n x 3, sorted order (what the gather kernel reads)
   int* knn_out;      // n x k original indices (optional, for tests), sorted by (d2, index)
 };
 
@@ -147,6 +147,8 @@ __global__ __launch_bounds__(NT) void normals_kernel(NormJob job) {
   jacobi_min_eigvec(c00, c01, c02, c11, c12, c22, nv);
   double* o = job.nor_out + 3 * (size_t)me.idx;
   o[0] = nv[0]; o[1] = nv[1]; o[2] = nv[2];
+  double* os = job.snor_out + 3 * (size_t)i;
+  os[0] = nv[0]; os[1] = nv[1]; os[2] = nv[2];
   if (job.knn_out) {
 #pragma unroll
     for (int t = 0; t < KMAX; ++t)
@@ -165,7 +167,7 @@ int launch_normals(mvicp_ctx* c, FrameDev& f, int k, int* d_knn) {
   j.table = (const HashEntry*)g.table; j.mask = g.table_mask; j.shift = g.table_shift;
   j.ox = g.origin[0]; j.oy = g.origin[1]; j.oz = g.origin[2]; j.h = g.cell; j.inv_h = g.inv_cell;
   j.dx = g.dims[0]; j.dy = g.dims[1]; j.dz = g.dims[2];
-  j.k = k; j.nor_out = f.nor; j.knn_out = d_knn;
+  j.k = k; j.nor_out = f.nor; j.snor_out = f.grid.snor; j.knn_out = d_knn;
   ProfScope ps(c, "normals", 0.0);
   hipLaunchKernelGGL(normals_kernel, dim3((f.n + NT - 1) / NT), dim3(NT), 0, c->stream, j);
   MV_HIP(hipGetLastError());
