@@ -407,13 +407,14 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
     const double dt[3] = {x[9] - x[21], x[10] - x[22], x[11] - x[23]};
     for (int i = 0; i < 3; ++i) Mq[9 + i] = x[12 + i] * dt[0] + x[12 + i + 3] * dt[1] + x[12 + i + 6] * dt[2];
     double* pq = &c->prev_q[(size_t)e * 12];
-    double dM = 0.0, dv = 0.0, scale = 0.0;
-    for (int k = 0; k < 9; ++k) dM += (Mq[k] - pq[k]) * (Mq[k] - pq[k]);
-    for (int k = 0; k < 3; ++k) { dv += (Mq[9 + k] - pq[9 + k]) * (Mq[9 + k] - pq[9 + k]); scale = std::max(scale, std::fabs(Mq[9 + k])); }
+    double scale = 0.0;
+    for (int k = 0; k < 12; ++k) { x[25 + k] = Mq[k] - pq[k]; scale = std::max(scale, std::fabs(Mq[k])); }
     const double rmax = c->frames[c->esrc[e]].max_norm;
-    const double eps = std::sqrt(dM) * rmax + std::sqrt(dv) + 1e-12 * (rmax + scale + 1.0);
-    x[24] = (c->nn_cache_valid && c->nn_cache_enable && c->active[e] && (int)c->nn_cache_edge.size() == E && c->nn_cache_edge[e] && c->nn_cache_thresh == thresh) ? eps : -1.0;
-    x[25] = 0.0;
+    const bool cache_on = c->nn_cache_valid && c->nn_cache_enable && c->active[e] && (int)c->nn_cache_edge.size() == E && c->nn_cache_edge[e] &&
+                          c->nn_cache_thresh == thresh;
+    // allowance for the rounding of the fp64 query map itself (both evaluations): ~1e-16 (|M||p| + |v|), taken 1e4 times larger
+    x[24] = cache_on ? 1e-12 * (scale * (rmax + 1.0) + 1.0) : -1.0;
+    for (int k = 37; k < kEdgeXf; ++k) x[k] = 0.0;
     std::memcpy(pq, Mq, sizeof(Mq));
   }
   MV_HIP(hipMemcpyAsync(c->d_xf, hx, sizeof(double) * (size_t)E * kEdgeXf, hipMemcpyHostToDevice, c->stream));

@@ -32,8 +32,9 @@ void set_error(const char* fmt, ...);
 constexpr int kLinPartial = 32;      // doubles per linearize workgroup partial (28 plane / 29 point, padded)
 constexpr int kLinThreads = 256;
 constexpr int kCompactBlock = 1024;  // queries per compaction workgroup
-constexpr int kEdgeXf = 26;          // Rs(9) ts(3) Rdinv(9) td(3), column-major; [24] = query displacement bound since the
-                                     // last search (metres, < 0: no temporal cache for this edge), [25] = spare
+constexpr int kEdgeXf = 40;          // Rs(9) ts(3) Rdinv(9) td(3), column-major; [24] = temporal-cache switch (>= 0: on, value =
+                                     // rounding allowance in metres), [25..36] = dM (9, col-major) dv (3): change of the query map
+                                     // q = M p + v since the last search, so a query moved by exactly |dM p + dv|
 constexpr int kEdgeRel = 12;         // R_ds(9, column-major) t_ds(3)
 
 // Uniform grid (spatial hash) over one cloud; see nn_grid.hip.

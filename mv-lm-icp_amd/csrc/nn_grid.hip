@@ -158,8 +158,17 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
   // OTHER target.  Since then the query moved by at most eps (pose update), so every other target is still >= L - eps
   // away; if the re-evaluated distance to p1 is strictly below that, p1 is still the unique nearest neighbour and its
   // exact squared distance (reference arithmetic) is the answer — no search.  Relative 1e-12 slack covers sqrt rounding.
-  const double eps = has_xf ? sxf[24] : -1.0;
-  if (!TREE_ONLY && eps >= 0.0 && job.out_lb != nullptr) {
+  const double slack = has_xf ? sxf[24] : -1.0;
+  if (!TREE_ONLY && slack >= 0.0 && job.out_lb != nullptr) {
+    // how far THIS query moved since the last search: |dM p + dv| (exactly, up to the rounding allowance)
+    double eps;
+    {
+      const double p0 = job.q[3 * (size_t)i], p1 = job.q[3 * (size_t)i + 1], p2 = job.q[3 * (size_t)i + 2];
+      const double e0 = sxf[25] * p0 + sxf[28] * p1 + sxf[31] * p2 + sxf[34];
+      const double e1 = sxf[26] * p0 + sxf[29] * p1 + sxf[32] * p2 + sxf[35];
+      const double e2 = sxf[27] * p0 + sxf[30] * p1 + sxf[33] * p2 + sxf[36];
+      eps = sqrt(e0 * e0 + e1 * e1 + e2 * e2) * (1.0 + 1e-9) + slack;
+    }
     const int pi = job.out_idx[out];   // sorted position of last round's neighbour
     if (pi >= 0) {
       const double2* tp = reinterpret_cast<const double2*>(g.srec + pi);
