@@ -152,6 +152,7 @@ def main():
     for _ in range(args.warmup):
         step()
     eng.profile(True)
+    eng.set_option("nn_census", 1)  # per-launch candidate / box / cache-hit counts -> algorithmic bytes of every timed NN launch
     eng.profile_reset()
     log.clear()
     fence()
@@ -166,17 +167,11 @@ def main():
         elapsed = float(tt.item())
 
     prof = {k: eng.profile_get(k) for k in ("nn", "compact", "gather", "select", "linearize", "reduce")}
-    # NN candidate census: ONE extra correspondence pass at the final poses, outside the timed region (the counters
-    # cost a little, so they are off while timing).  Its per-query byte figure prices every timed launch.
-    eng.set_option("nn_census", 1)
-    eng.profile_reset()
-    eng.correspond(poses, pb["fixed"], 0.05, method)
-    _, _, nn_bytes_census = eng.profile_get("nn")
+    host = {k: eng.profile_get(k)[0] / args.steps for k in ("host.correspond", "host.corr.setup", "host.corr.nn_launch", "host.corr.post_launch", "host.corr.wait",
+                                                            "host.corr.finish", "host.optimize", "host.evaluate")}
     census = eng.nn_census()
     eng.set_option("nn_census", 0)
     eng.profile(False)
-    if prof["nn"][1]:
-        prof["nn"] = (prof["nn"][0], prof["nn"][1], nn_bytes_census * prof["nn"][1])
 
     def pmc_traffic(name):
         """HBM bytes per launch from the committed rocprofv3 PMC passes of THIS workload (tools/profile.sh): separate
@@ -219,8 +214,10 @@ def main():
                                   "lm_iterations": float(np.mean([l["lm_iters"] for l in log])), "device_evaluations": float(np.mean([l["evals"] for l in log])),
                                   "correspondences": float(np.mean([l["corr"] for l in log]))},
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
-            "nn_census_per_query": {"candidates": census["candidates"] / max(1.0, census["queries"]), "tree_nodes": census["nodes"] / max(1.0, census["queries"]),
-                                    "tree_fallback_fraction": census["far"] / max(1.0, census["queries"])},
+            "host_ms_per_step": host,
+            "nn_census_per_query": {"candidates": census["candidates"] / max(1.0, census["queries"]), "tree_boxes": census["nodes"] / max(1.0, census["queries"]),
+                                    "tree_fallback_fraction": census["far"] / max(1.0, census["queries"]),
+                                    "temporal_cache_hit_fraction": census["hits"] / max(1.0, census["queries"])},
             "pose_error_vs_gt": {"max_translation_m": err_t, "max_rotation_rad": err_r},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -135,11 +135,14 @@ int mvicp_lm_solve(int n_frames, int n_edges, const int* src, const int* dst, do
 
 /* Tuning / test switches.  "nn_tree_only" (0/1): skip the hash-grid fast path and answer every query with the
  * exact AABB-tree descent (same results; used by the parity tests to exercise the fallback on every query).
- * "grid_target" (points per occupied hash cell the cell-edge heuristic aims at; set before mvicp_set_frame). */
+ * "grid_target" (points per occupied hash cell the cell-edge heuristic aims at; set before mvicp_set_frame).
+ * "nn_cache" (0/1, default 1): temporal cache of the grid kernel — a query whose previous neighbour is provably still
+ * nearest after the pose update skips the search (results are bit-identical either way).
+ * "nn_census" (0/1): count candidates / boxes / cache hits per launch while profiling (feeds the algorithmic-byte model). */
 int mvicp_set_option(mvicp_ctx* ctx, const char* name, double value);
-/* NN census accumulated while profiling is enabled: out[0..3] = queries, candidate points examined,
- * tree nodes tested, queries that needed the tree fallback. */
-int mvicp_nn_census(mvicp_ctx* ctx, double* out4);
+/* NN census accumulated while profiling and the "nn_census" option are on: out[0..4] = queries, candidate points
+ * examined, tree boxes tested, queries that needed the tree fallback, queries answered by the temporal cache. */
+int mvicp_nn_census(mvicp_ctx* ctx, double* out5);
 
 /* ---- profiling (HIP events on the library's own stream) ------------------------------------------ */
 int mvicp_profile_enable(mvicp_ctx* ctx, int on);

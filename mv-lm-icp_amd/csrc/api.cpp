@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <ctime>
 
 #include "common.h"
 #include "comm.h"
@@ -59,6 +60,18 @@ ProfScope::~ProfScope() {
   if (b) (void)hipEventRecord(b, c->stream);
   if (a && b) c->prof[name].pending.push_back(std::make_pair(a, b));
 }
+static double now_ms() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+HostScope::HostScope(mvicp_ctx* ctx, const char* nm) : c(ctx), name(nm), t0(0.0), on(ctx->profile) { if (on) t0 = now_ms(); }
+HostScope::~HostScope() {
+  if (!on) return;
+  ProfEntry& pe = c->prof[name];
+  pe.ms += now_ms() - t0;
+  pe.launches += 1;
+}
 void prof_collect(mvicp_ctx* c) {
   for (auto& kv : c->prof) {
     ProfEntry& pe = kv.second;
@@ -88,7 +101,7 @@ template <typename T> void dev_free(T*& p) {
 void free_graph(mvicp_ctx* c) {
   dev_free(c->d_esrc); dev_free(c->d_edst); dev_free(c->d_cap_off); dev_free(c->d_nsrc); dev_free(c->d_count); dev_free(c->d_a);
   dev_free(c->d_xf); dev_free(c->d_rel); dev_free(c->d_nn_idx); dev_free(c->d_nn_d2); dev_free(c->d_nn_lb); dev_free(c->d_first); dev_free(c->d_second);
-  dev_free(c->d_cd2); dev_free(c->d_stream); dev_free(c->d_cblock_off); dev_free(c->d_cblock_cnt); dev_free(c->d_sel_prefix);
+  dev_free(c->d_cd2); dev_free(c->d_qpos); dev_free(c->d_dirty); dev_free(c->d_stream); dev_free(c->d_cblock_off); dev_free(c->d_cblock_cnt); dev_free(c->d_sel_prefix);
   dev_free(c->d_sel_k); dev_free(c->d_sel_hist); dev_free(c->d_median); dev_free(c->d_chunk_edge); dev_free(c->d_chunk_start);
   dev_free(c->d_chunk_first); dev_free(c->d_partials); dev_free(c->d_out);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
@@ -161,6 +174,7 @@ int evaluate_blocks(mvicp_ctx* c, const double* poses, int plane, int robust, do
         return MVICP_ERR_STATE;
       }
   }
+  HostScope hs(c, "host.evaluate");
   MV_CHECK(upload_rel(c, poses));
   MV_CHECK(launch_linearize(c, plane, robust));
   const size_t n = (size_t)c->E * MVICP_EDGE_BLOCK;
@@ -356,6 +370,9 @@ int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) {
   c->nn_cache_valid = false; c->prev_q.assign((size_t)E * 12, 0.0);
   MV_CHECK(dev_alloc(&c->d_first, cap)); MV_CHECK(dev_alloc(&c->d_second, cap)); MV_CHECK(dev_alloc(&c->d_cd2, cap));
   MV_CHECK(dev_alloc(&c->d_stream, 9 * cap));
+  MV_CHECK(dev_alloc(&c->d_qpos, cap)); MV_CHECK(dev_alloc(&c->d_dirty, (size_t)E));
+  MV_HIP(hipMemset(c->d_qpos, 0xff, sizeof(int) * std::max<size_t>(cap, 1)));
+  c->list_valid.assign(E, 0);
   MV_CHECK(dev_alloc(&c->d_cblock_off, E + 1)); MV_CHECK(dev_alloc(&c->d_cblock_cnt, (size_t)c->n_cblocks));
   MV_CHECK(dev_alloc(&c->d_sel_prefix, E)); MV_CHECK(dev_alloc(&c->d_sel_k, E)); MV_CHECK(dev_alloc(&c->d_sel_hist, (size_t)E * 256));
   MV_CHECK(dev_alloc(&c->d_median, E));
@@ -385,6 +402,7 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   if (!poses) { set_error("poses is null"); return MVICP_ERR_ARG; }
   if (c->E == 0) { set_error("no graph: call mvicp_set_graph first"); return MVICP_ERR_STATE; }
   const int E = c->E;
+  HostScope hs_all(c, "host.correspond");
   // per-edge query transforms (frame.cpp:117-118,131,136) + active mask (frame.cpp:93)
   std::vector<int> nsrc(E, 0);
   double* hx = c->h_pin;
@@ -423,6 +441,9 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   MV_HIP(hipMemcpyAsync(c->d_nsrc, hx, sizeof(int) * E, hipMemcpyHostToDevice, c->stream));
 
   const double bound = sqrt_bound((double)thresh);
+  double t_mark = now_ms();
+  auto mark = [&](const char* nm) { if (c->profile) { const double t = now_ms(); ProfEntry& pe = c->prof[nm]; pe.ms += t - t_mark; pe.launches += 1; t_mark = t; } };
+  mark("host.corr.setup");
   int method = nn_method;
   if (method == MVICP_NN_AUTO) {
     // Per-lane hash lookups win once the clouds are aligned to within a fraction of a hash cell; while the typical
@@ -441,6 +462,16 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
     for (int e = 0; e < E; ++e)
       if (c->active[e] && (!c->frames[c->edst[e]].has_grid || !c->frames[c->esrc[e]].has_grid)) method = MVICP_NN_BRUTE;
   }
+  {
+    // an edge may keep last round's compacted list only if the grid kernel (which checks every query) runs and the list
+    // on the device really is last round's result for this edge
+    std::vector<int> dirty(E, 1);
+    if (method == MVICP_NN_GRID && !c->nn_tree_only && !c->nn_skip_far && c->list_reuse)
+      for (int e = 0; e < E; ++e) if (c->active[e] && c->list_valid[e]) dirty[e] = 0;
+    int* hd = reinterpret_cast<int*>(c->h_pin + (size_t)E * kEdgeXf);
+    std::memcpy(hd, dirty.data(), sizeof(int) * E);
+    MV_HIP(hipMemcpyAsync(c->d_dirty, hd, sizeof(int) * E, hipMemcpyHostToDevice, c->stream));
+  }
   if (method == MVICP_NN_BRUTE) MV_CHECK(launch_nn_brute_edges(c));
   else if (method == MVICP_NN_GRID) MV_CHECK(launch_nn_grid_edges(c, bound));
   else if (method == MVICP_NN_TILE) MV_CHECK(launch_nn_tile_edges(c, bound));
@@ -449,16 +480,20 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   c->nn_cache_valid = (method == MVICP_NN_GRID) && !c->nn_tree_only && !c->nn_skip_far;
   c->nn_cache_thresh = thresh;
   c->nn_cache_edge.assign(c->active.begin(), c->active.end());
+  for (int e = 0; e < E; ++e) c->list_valid[e] = c->active[e];
 
+  mark("host.corr.nn_launch");
   MV_CHECK(launch_compact(c, bound));
   MV_CHECK(launch_gather_stream(c));
   MV_CHECK(launch_select_median(c));
+  mark("host.corr.post_launch");
   // counts + median d2 back; weight = (float)(1.5 * sqrt(median d2))  (frame.cpp:168-176)
   int* hc = reinterpret_cast<int*>(c->h_pin);
   double* hm = c->h_pin + E;  // leave room: E ints fit in E doubles
   MV_HIP(hipMemcpyAsync(hc, c->d_count, sizeof(int) * E, hipMemcpyDeviceToHost, c->stream));
   MV_HIP(hipMemcpyAsync(hm, c->d_median, sizeof(double) * E, hipMemcpyDeviceToHost, c->stream));
   MV_HIP(hipStreamSynchronize(c->stream));
+  mark("host.corr.wait");
   std::vector<double> pack(2 * (size_t)E, 0.0);
   for (int e = 0; e < E; ++e)
     if (c->owned[e]) { pack[2 * e] = c->active[e] ? hc[e] : 0; pack[2 * e + 1] = (c->active[e] && hc[e] > 0) ? hm[e] : 0.0; }
@@ -475,6 +510,7 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   MV_HIP(hipMemcpyAsync(c->d_a, ha, sizeof(double) * E, hipMemcpyHostToDevice, c->stream));
   MV_HIP(hipStreamSynchronize(c->stream));
   c->have_corr = true;
+  mark("host.corr.finish");
   if (c->profile) prof_collect(c);
   return MVICP_OK;
 }
@@ -532,12 +568,15 @@ int mvicp_set_correspondences(mvicp_ctx* c, int edge, int n, const int* first, c
     MV_HIP(hipMemset(c->d_cd2 + off, 0, sizeof(double) * n));
   }
   c->nn_cache_valid = false;
+  c->list_valid[edge] = 0;
   const double a = (double)weight;
   MV_HIP(hipMemcpy(c->d_count + edge, &n, sizeof(int), hipMemcpyHostToDevice));
   MV_HIP(hipMemcpy(c->d_a + edge, &a, sizeof(double), hipMemcpyHostToDevice));
   c->h_count[edge] = n;
   c->h_weight[edge] = weight;
   c->have_corr = true;
+  const int one = 1;
+  MV_HIP(hipMemcpy(c->d_dirty + edge, &one, sizeof(int), hipMemcpyHostToDevice));  // this edge's operands must be (re)gathered
   MV_CHECK(launch_gather_stream(c));
   MV_HIP(hipStreamSynchronize(c->stream));
   return MVICP_OK;
@@ -584,6 +623,7 @@ int mvicp_set_option(mvicp_ctx* c, const char* name, double value) {
   if (!name) { set_error("null option name"); return MVICP_ERR_ARG; }
   if (std::strcmp(name, "nn_tree_only") == 0) { c->nn_tree_only = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "nn_cache") == 0) { c->nn_cache_enable = value != 0.0; c->nn_cache_valid = false; return MVICP_OK; }
+  if (std::strcmp(name, "list_reuse") == 0) { c->list_reuse = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "nn_census") == 0) { c->nn_census = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "nn_skip_far") == 0) { c->nn_skip_far = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "grid_target") == 0) {
@@ -597,7 +637,7 @@ int mvicp_set_option(mvicp_ctx* c, const char* name, double value) {
 int mvicp_nn_census(mvicp_ctx* c, double* out4) {
   MV_CHECK(bind(c));
   if (!out4) { set_error("null output"); return MVICP_ERR_ARG; }
-  out4[0] = c->nn_queries; out4[1] = c->nn_candidates; out4[2] = c->nn_nodes; out4[3] = c->nn_far;
+  out4[0] = c->nn_queries; out4[1] = c->nn_candidates; out4[2] = c->nn_nodes; out4[3] = c->nn_far; out4[4] = c->nn_hits;
   return MVICP_OK;
 }
 
@@ -611,7 +651,7 @@ int mvicp_profile_reset(mvicp_ctx* c) {
   MV_HIP(hipStreamSynchronize(c->stream));
   prof_collect(c);
   for (auto& kv : c->prof) { kv.second.ms = 0; kv.second.launches = 0; kv.second.bytes = 0; }
-  c->nn_candidates = c->nn_nodes = c->nn_far = c->nn_queries = 0;
+  c->nn_candidates = c->nn_nodes = c->nn_far = c->nn_queries = c->nn_hits = 0;
   return MVICP_OK;
 }
 int mvicp_profile_get(mvicp_ctx* c, const char* kernel, double* total_ms, long long* launches, double* alg_bytes) {

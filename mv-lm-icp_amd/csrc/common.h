@@ -121,6 +121,9 @@ struct mvicp_ctx {
   std::vector<double> prev_q;       // E x 12: query map M = Rd^-1 Rs (9, col-major) and v = Rd^-1 (ts - td) of the last search
   // per-correspondence (total_cap)
   int* d_first = nullptr; int* d_second = nullptr; double* d_cd2 = nullptr;
+  int* d_qpos = nullptr;            // per query: its position in the edge's compacted list, or -1 (rejected by the cutoff)
+  int* d_dirty = nullptr;           // E: != 0 -> the edge's list (membership or a neighbour) changed this round: re-compact + re-gather
+  std::vector<char> list_valid;     // E: d_qpos / lists describe last round's result of this edge
   double* d_stream = nullptr;       // 9 x total_cap SoA: px py pz qx qy qz nx ny nz
   // compaction scratch
   int n_cblocks = 0;                // total compaction blocks over owned edges
@@ -149,13 +152,14 @@ struct mvicp_ctx {
   void* comm = nullptr;
 
   // options / NN census (profiling only)
+  bool list_reuse = true;          // skip compaction + gather for edges whose list did not change
   bool nn_tree_only = false;
   bool nn_census = false;          // count candidates / tree nodes per launch while profiling (small extra cost)
   void* d_census = nullptr; size_t census_bytes = 0;
   void* d_far_list = nullptr; size_t far_cap = 0; unsigned int* d_far_count = nullptr;  // nn_grid far-query list
   bool nn_skip_far = false;        // PROFILING ONLY: leave unresolved queries unresolved (wrong results)
   double grid_target = 6.0;        // points per occupied cell the cell-edge heuristic aims at
-  double nn_candidates = 0, nn_nodes = 0, nn_far = 0, nn_queries = 0;
+  double nn_candidates = 0, nn_nodes = 0, nn_far = 0, nn_queries = 0, nn_hits = 0;
 
   // profiling
   bool profile = false;
@@ -191,5 +195,11 @@ struct ProfScope {
   ~ProfScope();
 };
 void prof_collect(mvicp_ctx* c);
+// host wall-clock sections (same table, names prefixed "host."), only while profiling
+struct HostScope {
+  mvicp_ctx* c; const char* name; double t0; bool on;
+  HostScope(mvicp_ctx* c, const char* name);
+  ~HostScope();
+};
 
 }  // namespace mvicp

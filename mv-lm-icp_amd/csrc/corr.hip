@@ -53,10 +53,12 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* __restrict__ wav
 
 __global__ __launch_bounds__(NT) void count_kernel(const int* __restrict__ cblock_off, int E, const int* __restrict__ nsrc,
                                                    const long long* __restrict__ cap_off, const int* __restrict__ nn_idx,
-                                                   const double* __restrict__ nn_d2, double bound, int* __restrict__ cblock_cnt) {
+                                                   const double* __restrict__ nn_d2, double bound, int* __restrict__ cblock_cnt,
+                                                   const int* __restrict__ dirty) {
   __shared__ int wave_tot[NT / 64];
   const int b = blockIdx.x;
   const int e = find_edge(cblock_off, E, b);
+  if (dirty[e] == 0) return;  // list unchanged since last round
   const int lb = b - cblock_off[e];
   const int n = nsrc[e];
   const long long base = cap_off[e];
@@ -72,10 +74,12 @@ __global__ __launch_bounds__(NT) void count_kernel(const int* __restrict__ cbloc
 }
 
 // one workgroup per edge: exclusive scan of its block counts (<= ~1k blocks for 1M points), in place.
-__global__ __launch_bounds__(NT) void scan_kernel(const int* __restrict__ cblock_off, int* __restrict__ cblock_cnt, int* __restrict__ count) {
+__global__ __launch_bounds__(NT) void scan_kernel(const int* __restrict__ cblock_off, int* __restrict__ cblock_cnt, int* __restrict__ count,
+                                                  const int* __restrict__ dirty) {
   __shared__ int wave_tot[NT / 64];
   __shared__ int carry_s;
   const int e = blockIdx.x;
+  if (dirty[e] == 0) return;
   const int b0 = cblock_off[e], b1 = cblock_off[e + 1];
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
@@ -96,10 +100,12 @@ __global__ __launch_bounds__(NT) void scan_kernel(const int* __restrict__ cblock
 __global__ __launch_bounds__(NT) void scatter_kernel(const int* __restrict__ cblock_off, int E, const int* __restrict__ nsrc,
                                                      const long long* __restrict__ cap_off, const int* __restrict__ nn_idx,
                                                      const double* __restrict__ nn_d2, double bound, const int* __restrict__ cblock_cnt,
-                                                     int* __restrict__ first, int* __restrict__ second, double* __restrict__ cd2) {
+                                                     int* __restrict__ first, int* __restrict__ second, double* __restrict__ cd2,
+                                                     int* __restrict__ qpos, const int* __restrict__ dirty) {
   __shared__ int wave_tot[NT / 64];
   const int b = blockIdx.x;
   const int e = find_edge(cblock_off, E, b);
+  if (dirty[e] == 0) return;
   const int lb = b - cblock_off[e];
   const int n = nsrc[e];
   const long long base = cap_off[e];
@@ -122,8 +128,9 @@ __global__ __launch_bounds__(NT) void scatter_kernel(const int* __restrict__ cbl
   int pos = cblock_cnt[b] + block_exclusive_scan(cnt, wave_tot, &total);
 #pragma unroll
   for (int i = 0; i < IPT; ++i) {
-    if (!ok[i]) continue;
     const int k = lb * kCompactBlock + threadIdx.x * IPT + i;
+    if (k < n) qpos[base + k] = ok[i] ? pos : -1;
+    if (!ok[i]) continue;
     first[base + pos] = k;
     second[base + pos] = idx[i];
     cd2[base + pos] = d2[i];
@@ -136,9 +143,10 @@ __global__ __launch_bounds__(NT) void gather_kernel(const int* __restrict__ cblo
                                                     const long long* __restrict__ cap_off, long long total_cap, const int* __restrict__ first,
                                                     const int* __restrict__ second, const PointRec* const* __restrict__ src_rec,
                                                     const PointRec* const* __restrict__ dst_rec, const double* const* __restrict__ dst_nor,
-                                                    double* __restrict__ stream) {
+                                                    double* __restrict__ stream, const int* __restrict__ dirty) {
   const int b = blockIdx.x;
   const int e = find_edge(cblock_off, E, b);
+  if (dirty[e] == 0) return;  // same list -> same operands
   const int lb = b - cblock_off[e];
   const int cnt = count[e];
   if (lb * kCompactBlock >= cnt) return;
@@ -238,10 +246,10 @@ int launch_compact(mvicp_ctx* c, double d2_bound) {
   for (int e = 0; e < c->E; ++e) if (c->owned[e]) bytes += 2.0 * 12.0 * c->frames[c->esrc[e]].n;
   ProfScope ps(c, "compact", bytes);
   hipLaunchKernelGGL(count_kernel, dim3(c->n_cblocks), dim3(NT), 0, c->stream, c->d_cblock_off, c->E, c->d_nsrc, c->d_cap_off, c->d_nn_idx,
-                     c->d_nn_d2, d2_bound, c->d_cblock_cnt);
-  hipLaunchKernelGGL(scan_kernel, dim3(c->E), dim3(NT), 0, c->stream, c->d_cblock_off, c->d_cblock_cnt, c->d_count);
+                     c->d_nn_d2, d2_bound, c->d_cblock_cnt, c->d_dirty);
+  hipLaunchKernelGGL(scan_kernel, dim3(c->E), dim3(NT), 0, c->stream, c->d_cblock_off, c->d_cblock_cnt, c->d_count, c->d_dirty);
   hipLaunchKernelGGL(scatter_kernel, dim3(c->n_cblocks), dim3(NT), 0, c->stream, c->d_cblock_off, c->E, c->d_nsrc, c->d_cap_off, c->d_nn_idx,
-                     c->d_nn_d2, d2_bound, c->d_cblock_cnt, c->d_first, c->d_second, c->d_cd2);
+                     c->d_nn_d2, d2_bound, c->d_cblock_cnt, c->d_first, c->d_second, c->d_cd2, c->d_qpos, c->d_dirty);
   MV_HIP(hipGetLastError());
   return MVICP_OK;
 }
@@ -261,7 +269,7 @@ int launch_gather_stream(mvicp_ctx* c) {
   {
     ProfScope ps(c, "gather", 0.0);
     hipLaunchKernelGGL(gather_kernel, dim3(c->n_cblocks), dim3(NT), 0, c->stream, c->d_cblock_off, c->E, c->d_count, c->d_cap_off, c->total_cap,
-                       c->d_first, c->d_second, (const PointRec* const*)d_tab, (const PointRec* const*)(d_tab + c->E), (const double* const*)(d_tab + 2 * c->E), c->d_stream);
+                       c->d_first, c->d_second, (const PointRec* const*)d_tab, (const PointRec* const*)(d_tab + c->E), (const double* const*)(d_tab + 2 * c->E), c->d_stream, c->d_dirty);
   }
   MV_HIP(hipGetLastError());
   return MVICP_OK;

@@ -58,6 +58,8 @@ struct GridJob {
   int n;
   int* out_idx; double* out_d2;
   const int* inv;      // target original index -> sorted position (null: emit original indices, raw-query API)
+  // "did anything change?" bookkeeping of the edge's compacted list (all null for the raw-query API)
+  const int* qpos; const int* second; double* cd2; int* dirty;
   double* out_lb;      // per query: lower bound on the distance to every target other than out_idx (null: no cache)
 };
 
@@ -126,6 +128,24 @@ __device__ __forceinline__ bool __lane0() {
   return (int)(threadIdx.x & 63) == __ffsll((long long)mask) - 1;
 }
 
+// The edge's compacted correspondence list survives a round unchanged when every query keeps both its acceptance
+// (cutoff test) and its neighbour; then only the squared distances need refreshing (in place), and compaction + operand
+// gather are skipped for that edge.  Anything else marks the edge dirty.
+__device__ __forceinline__ bool list_still_valid(const GridJob& job, int i, int idx_new, double d2_new, double bound) {
+  // an edge that is already dirty (forced by the host: no valid list yet, or flagged by another wave) needs no checking —
+  // and its qpos may be uninitialised
+  if (__hip_atomic_load(job.dirty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+  const int pos = job.qpos[i];
+  const bool acc = idx_new >= 0 && d2_new < bound;
+  if (pos < 0) return !acc;
+  if (!acc || job.second[pos] != idx_new) return false;
+  job.cd2[pos] = d2_new;
+  return true;
+}
+__device__ __forceinline__ void mark_dirty(const GridJob& job, bool clean) {
+  if (__ballot(!clean) != 0ull && __lane0()) atomicOr(job.dirty, 1);
+}
+
 // ---- phase 1: spatial-hash block lookup for every query; queries it cannot prove optimal go to the far list ----
 template <bool TREE_ONLY>
 __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__ jobs, double bound, unsigned long long* __restrict__ stats, int skip_far,
@@ -178,10 +198,11 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
       if (sqrt(d) * (1.0 + 1e-12) < nlb) {
         job.out_d2[out] = d;
         job.out_lb[out] = nlb;
+        if (job.dirty) mark_dirty(job, list_still_valid(job, i, pi, d, bound));
         if (stats) {
           unsigned long long c1 = __reduce_add_u64(1ull);
           const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + (threadIdx.x >> 6);
-          if (__lane0()) atomicAdd(&stats[3 * slot], c1);
+          if (__lane0()) atomicAdd(&stats[4 * slot + 3], c1);
         }
         return;
       }
@@ -237,6 +258,7 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
   job.out_d2[out] = best;
   // every other target is either a scanned candidate (>= second) or outside the block (>= m)
   if (job.out_lb != nullptr) job.out_lb[out] = resolved ? sqrt(fmin(second, m2)) * (1.0 - 1e-12) : 0.0;
+  if (job.dirty && (resolved || skip_far)) mark_dirty(job, list_still_valid(job, i, bi == 0x7fffffff ? -1 : job.inv[bi], best, bound));
   if (!resolved && !skip_far) {
     // wave-aggregated append: one atomic per wave
     const unsigned long long mask = __ballot(1);
@@ -254,7 +276,7 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
     unsigned long long c = n_cand, far = resolved ? 0 : 1;
     c = __reduce_add_u64(c); far = __reduce_add_u64(far);
     const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + (threadIdx.x >> 6);
-    if (__lane0()) { atomicAdd(&stats[3 * slot], c); atomicAdd(&stats[3 * slot + 2], far); }
+    if (__lane0()) { atomicAdd(&stats[4 * slot], c); atomicAdd(&stats[4 * slot + 2], far); }
   }
 }
 
@@ -275,7 +297,7 @@ __device__ __forceinline__ double oct_box_lb(double qx, double qy, double qz, co
   return __dadd_rn(__dadd_rn(__dmul_rn(g0, g0), __dmul_rn(g1, g1)), __dmul_rn(g2, g2));
 }
 
-__global__ __launch_bounds__(NT) void nn_far_kernel(const GridJob* __restrict__ jobs, const int2* __restrict__ far_list,
+__global__ __launch_bounds__(NT) void nn_far_kernel(const GridJob* __restrict__ jobs, const int2* __restrict__ far_list, double bound,
                                                     const unsigned int* __restrict__ far_count, unsigned long long* __restrict__ stats, size_t stats_slots) {
   __shared__ int s_id[NT / 8][OCT_STACK];
   __shared__ double s_lb[NT / 8][OCT_STACK];
@@ -380,6 +402,7 @@ __global__ __launch_bounds__(NT) void nn_far_kernel(const GridJob* __restrict__ 
       job.out_d2[out] = best;
       // every other target was scanned (>= second) or sits in a skipped box (>= its lower bound)
       if (job.out_lb != nullptr) job.out_lb[out] = bi == 0x7fffffff ? 0.0 : sqrt(fmin(second, pruned)) * (1.0 - 1e-12);
+      if (job.dirty && !list_still_valid(job, i, bi == 0x7fffffff ? -1 : job.inv[bi], best, bound)) atomicOr(job.dirty, 1);
     }
   }
   if (stats) {
@@ -387,20 +410,22 @@ __global__ __launch_bounds__(NT) void nn_far_kernel(const GridJob* __restrict__ 
     unsigned long long c = l == 0 ? n_cand : 0, nd = l == 0 ? n_nodes : 0;
     c = __reduce_add_u64(c); nd = __reduce_add_u64(nd);
     const size_t slot = ((size_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6)) % stats_slots;
-    if (__lane0()) { atomicAdd(&stats[3 * slot], c); atomicAdd(&stats[3 * slot + 1], nd); }
+    if (__lane0()) { atomicAdd(&stats[4 * slot], c); atomicAdd(&stats[4 * slot + 1], nd); }
   }
 }
 
-__global__ __launch_bounds__(256) void census_sum_kernel(const unsigned long long* __restrict__ stats, size_t slots, unsigned long long* __restrict__ out3) {
-  __shared__ unsigned long long sh[3][256];
-  unsigned long long a = 0, b = 0, c = 0;
-  for (size_t i = threadIdx.x; i < slots; i += 256) { a += stats[3 * i]; b += stats[3 * i + 1]; c += stats[3 * i + 2]; }
-  sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = b; sh[2][threadIdx.x] = c;
+// sums the per-wave census slots (4 counters each) into out4 (zeroed by the caller); 64 workgroups, 4 atomics each
+__global__ __launch_bounds__(256) void census_sum_kernel(const unsigned long long* __restrict__ stats, size_t slots, unsigned long long* __restrict__ out4) {
+  __shared__ unsigned long long sh[4][256];
+  unsigned long long v[4] = {0, 0, 0, 0};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < slots; i += (size_t)gridDim.x * 256)
+    for (int k = 0; k < 4; ++k) v[k] += stats[4 * i + k];
+  for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] = v[k];
   __syncthreads();
-  if (threadIdx.x < 3) {
+  if (threadIdx.x < 4) {
     unsigned long long s = 0;
     for (int i = 0; i < 256; ++i) s += sh[threadIdx.x][i];
-    out3[threadIdx.x] = s;
+    atomicAdd(&out4[threadIdx.x], s);
   }
 }
 
@@ -636,7 +661,7 @@ int run(mvicp_ctx* c, const std::vector<GridJob>& jobs, double bound) {
   unsigned long long* d_stats = nullptr;
   const size_t slots = (size_t)((max_n + NT - 1) / NT) * jobs.size() * (NT / 64);
   if (c->profile && c->nn_census) {
-    const size_t need = sizeof(unsigned long long) * 3 * (slots + 1);
+    const size_t need = sizeof(unsigned long long) * 4 * (slots + 1);
     if (need > c->census_bytes) {
       if (c->d_census) MV_HIP(hipFree(c->d_census));
       MV_HIP(hipMalloc((void**)&c->d_census, need));
@@ -655,7 +680,7 @@ int run(mvicp_ctx* c, const std::vector<GridJob>& jobs, double bound) {
   if (!c->d_far_count) MV_HIP(hipMalloc((void**)&c->d_far_count, sizeof(unsigned int)));
   MV_HIP(hipMemsetAsync(c->d_far_count, 0, sizeof(unsigned int), c->stream));
   {
-    ProfScope ps(c, "nn", (36.0 + (c->nn_tree_only ? 0.0 : 128.0)) * nq);  // query 24 B + result 12 B + 8 hash slots x 16 B; candidate bytes come from the census below
+    ProfScope ps(c, "nn", 36.0 * nq);  // query 24 B + result 12 B; the rest comes from the census below (0 if the census is off)
     const dim3 grid((max_n + NT - 1) / NT, (unsigned)jobs.size());
     if (c->nn_tree_only)
       hipLaunchKernelGGL((nn_grid_kernel<true>), grid, dim3(NT), 0, c->stream, d_jobs, bound, d_stats, 0, (int2*)c->d_far_list, c->d_far_count);
@@ -663,17 +688,20 @@ int run(mvicp_ctx* c, const std::vector<GridJob>& jobs, double bound) {
       hipLaunchKernelGGL((nn_grid_kernel<false>), grid, dim3(NT), 0, c->stream, d_jobs, bound, d_stats, c->nn_skip_far ? 1 : 0, (int2*)c->d_far_list, c->d_far_count);
     // phase 2: persistent grid-stride launch (the far count is only known on the device)
     const unsigned int far_blocks = (unsigned int)std::min<size_t>(256 * 8, (total_q * 8 + NT - 1) / NT);
-    hipLaunchKernelGGL(nn_far_kernel, dim3(far_blocks), dim3(NT), 0, c->stream, d_jobs, (const int2*)c->d_far_list, c->d_far_count, d_stats, slots);
+    hipLaunchKernelGGL(nn_far_kernel, dim3(far_blocks), dim3(NT), 0, c->stream, d_jobs, (const int2*)c->d_far_list, bound, c->d_far_count, d_stats, slots);
   }
   MV_HIP(hipGetLastError());
   if (d_stats) {
-    unsigned long long st[3];
-    hipLaunchKernelGGL(census_sum_kernel, dim3(1), dim3(256), 0, c->stream, d_stats, slots, d_stats + 3 * slots);
-    MV_HIP(hipMemcpyAsync(st, d_stats + 3 * slots, sizeof(st), hipMemcpyDeviceToHost, c->stream));
+    unsigned long long st[4];
+    hipLaunchKernelGGL(census_sum_kernel, dim3(64), dim3(256), 0, c->stream, d_stats, slots, d_stats + 4 * slots);
+    MV_HIP(hipMemcpyAsync(st, d_stats + 4 * slots, sizeof(st), hipMemcpyDeviceToHost, c->stream));
     MV_HIP(hipStreamSynchronize(c->stream));
     ProfEntry& pe = c->prof["nn"];
-    pe.bytes += 28.0 * (double)st[0] + 24.0 * (double)st[1];  // candidates: 24 B xyz + 4 B index; tree nodes: 24 B AABB
-    c->nn_candidates += (double)st[0]; c->nn_nodes += (double)st[1]; c->nn_far += (double)st[2]; c->nn_queries += nq;
+    // cache hit: previous index 4 B + bound 8 B + one 32-B record + bound write 8 B; searched query: 8 hash slots x 16 B + bound
+    // write 8 B; every candidate point examined: one 32-B record; every tree box tested: 32 B
+    const double hits = (double)st[3], searched = nq - hits;
+    pe.bytes += 52.0 * hits + (c->nn_tree_only ? 8.0 : 136.0) * searched + 32.0 * (double)st[0] + 32.0 * (double)st[1];
+    c->nn_candidates += (double)st[0]; c->nn_nodes += (double)st[1]; c->nn_far += (double)st[2]; c->nn_queries += nq; c->nn_hits += hits;
   }
   return MVICP_OK;
 }
@@ -691,6 +719,7 @@ int launch_nn_grid_edges(mvicp_ctx* c, double d2_bound) {
     j.q = s.grid.spts; j.qidx = nullptr; j.xf = c->d_xf + (size_t)e * kEdgeXf; j.n = s.n;
     j.out_idx = c->d_nn_idx + c->cap_off[e]; j.out_d2 = c->d_nn_d2 + c->cap_off[e];
     j.inv = d.grid.inv; j.out_lb = c->d_nn_lb + c->cap_off[e];
+    j.qpos = c->d_qpos + c->cap_off[e]; j.second = c->d_second + c->cap_off[e]; j.cd2 = c->d_cd2 + c->cap_off[e]; j.dirty = c->d_dirty + e;
     jobs.push_back(j);
   }
   return run(c, jobs, d2_bound);
@@ -703,6 +732,7 @@ int launch_nn_grid_queries(mvicp_ctx* c, const FrameDev& f, const double* d_q, i
   jobs[0].q = d_q; jobs[0].qidx = nullptr; jobs[0].xf = nullptr; jobs[0].n = n;
   jobs[0].out_idx = d_idx; jobs[0].out_d2 = d_d2;
   jobs[0].inv = nullptr; jobs[0].out_lb = nullptr;
+  jobs[0].qpos = nullptr; jobs[0].second = nullptr; jobs[0].cd2 = nullptr; jobs[0].dirty = nullptr;
   return run(c, jobs, 1.7976931348623157e308);
 }
 

@@ -241,20 +241,22 @@ __global__ __launch_bounds__(NT, 6) void nn_tile_kernel(const TileJob* __restric
     // wave-uniform counters: candidates examined PER LANE x active lanes, boxes tested per wave
     const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + wave;
     const unsigned long long act = (unsigned long long)min(64, job.n - (i & ~63));
-    stats[3 * slot] = n_cand; stats[3 * slot + 1] = n_box; stats[3 * slot + 2] = n_cand * act;
+    stats[4 * slot] = n_cand; stats[4 * slot + 1] = n_box; stats[4 * slot + 2] = n_cand * act;
   }
 }
 
-__global__ __launch_bounds__(256) void census_sum_kernel(const unsigned long long* __restrict__ stats, size_t slots, unsigned long long* __restrict__ out3) {
-  __shared__ unsigned long long sh[3][256];
-  unsigned long long a = 0, b = 0, c = 0;
-  for (size_t i = threadIdx.x; i < slots; i += 256) { a += stats[3 * i]; b += stats[3 * i + 1]; c += stats[3 * i + 2]; }
-  sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = b; sh[2][threadIdx.x] = c;
+// sums the per-wave census slots (4 counters each) into out4 (zeroed by the caller); 64 workgroups, 4 atomics each
+__global__ __launch_bounds__(256) void census_sum_kernel(const unsigned long long* __restrict__ stats, size_t slots, unsigned long long* __restrict__ out4) {
+  __shared__ unsigned long long sh[4][256];
+  unsigned long long v[4] = {0, 0, 0, 0};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < slots; i += (size_t)gridDim.x * 256)
+    for (int k = 0; k < 4; ++k) v[k] += stats[4 * i + k];
+  for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] = v[k];
   __syncthreads();
-  if (threadIdx.x < 3) {
+  if (threadIdx.x < 4) {
     unsigned long long s = 0;
     for (int i = 0; i < 256; ++i) s += sh[threadIdx.x][i];
-    out3[threadIdx.x] = s;
+    atomicAdd(&out4[threadIdx.x], s);
   }
 }
 
@@ -340,7 +342,7 @@ int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound) {
   unsigned long long* d_stats = nullptr;
   const size_t slots = (size_t)((max_n + NT - 1) / NT) * jobs.size() * (NT / 64);
   if (c->profile && c->nn_census) {
-    const size_t need = sizeof(unsigned long long) * 3 * (slots + 1);
+    const size_t need = sizeof(unsigned long long) * 4 * (slots + 1);
     if (need > c->census_bytes) {
       if (c->d_census) MV_HIP(hipFree(c->d_census));
       MV_HIP(hipMalloc((void**)&c->d_census, need));
@@ -355,9 +357,9 @@ int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound) {
   }
   MV_HIP(hipGetLastError());
   if (d_stats) {
-    unsigned long long st[3];
-    hipLaunchKernelGGL(census_sum_kernel, dim3(1), dim3(256), 0, c->stream, d_stats, slots, d_stats + 3 * slots);
-    MV_HIP(hipMemcpyAsync(st, d_stats + 3 * slots, sizeof(st), hipMemcpyDeviceToHost, c->stream));
+    unsigned long long st[4];
+    hipLaunchKernelGGL(census_sum_kernel, dim3(64), dim3(256), 0, c->stream, d_stats, slots, d_stats + 4 * slots);
+    MV_HIP(hipMemcpyAsync(st, d_stats + 4 * slots, sizeof(st), hipMemcpyDeviceToHost, c->stream));
     MV_HIP(hipStreamSynchronize(c->stream));
     ProfEntry& pe = c->prof["nn"];
     // memory-side algorithmic bytes: every opened tile is loaded ONCE per wave (24 B xyz + 4 B index per point) and

@@ -271,6 +271,7 @@ int mvicp_optimize(mvicp_ctx* c, double* poses, unsigned char* fixed, int param,
   hipError_t e = hipSetDevice(c->device);
   if (e != hipSuccess) { set_error("hipSetDevice: %s", hipGetErrorString(e)); return MVICP_ERR_HIP; }
   if (c->E == 0) { set_error("no graph"); return MVICP_ERR_STATE; }
+  HostScope hs(c, "host.optimize");
   CtxEval u{c, point_to_plane, robust};
   const int st = lm_solve(c->n_frames, c->E, c->esrc.data(), c->edst.data(), poses, fixed, param, max_iterations, ctx_eval, &u, summary);
   if (c->profile) prof_collect(c);

@@ -419,6 +419,7 @@ def test_temporal_cache_is_bit_identical_to_full_search(orc):
     for cache in (1, 0):
         e = mvicp.Engine(0)
         e.set_option("nn_cache", cache)
+        e.set_option("list_reuse", cache)  # reference engine: search everything, re-compact and re-gather every round
         e.set_frames(pb["pts"], pb["nor"]); e.set_graph(pb["src"], pb["dst"])
         e.profile(True); e.set_option("nn_census", 1)
         engs.append(e)
@@ -434,14 +435,16 @@ def test_temporal_cache_is_bit_identical_to_full_search(orc):
         assert np.array_equal(c1, c0) and np.array_equal(w1, w0), r
         for a, b in zip(l1, l0):
             assert all(np.array_equal(x, y) for x, y in zip(a, b)), r
-        hits.append(s1["candidates"] / s1["queries"])
+        hits.append(1.0 - s1["hits"] / s1["queries"])
         if r in (0, 8):
             for k, (s, d) in enumerate(zip(pb["src"], pb["dst"])):
                 f, sec, dist, wt, _, _ = orc.correspond_edge(pb["pts"][s], poses[s], pb["pts"][d], poses[d], 0.05)
                 assert np.array_equal(l1[k][0], f) and np.array_equal(l1[k][1], sec) and np.array_equal(l1[k][2], dist) and w1[k] == wt
+        blk1 = engs[0].linearize(poses, 1, 1); blk0 = engs[1].linearize(poses, 1, 1)
+        assert np.array_equal(blk1, blk0), r   # reused lists / operand streams are the very same bytes
         poses, sm = engs[0].optimize(poses, pb["fixed"], L.PARAM_SOPHUS_SE3, 1, True, 50)
-    # the cache must actually engage once the poses settle (candidates examined per query collapse towards 1)
-    assert hits[-1] < 0.2 * hits[0], hits
+    # the cache must actually engage once the poses settle (fraction of queries still searched collapses)
+    assert hits[0] == 1.0 and hits[-1] < 0.2, hits
     # a changed cutoff or a perturbed pose must fall back to searching and stay exact
     poses2 = poses.copy(); poses2[2][:3, 3] += [0.004, -0.003, 0.002]
     for e in engs:
