@@ -101,8 +101,8 @@ template <typename T> void dev_free(T*& p) {
 void free_graph(mvicp_ctx* c) {
   dev_free(c->d_esrc); dev_free(c->d_edst); dev_free(c->d_cap_off); dev_free(c->d_nsrc); dev_free(c->d_count); dev_free(c->d_a);
   dev_free(c->d_xf); dev_free(c->d_rel); dev_free(c->d_nn_idx); dev_free(c->d_nn_d2); dev_free(c->d_nn_lb); dev_free(c->d_first); dev_free(c->d_second);
-  dev_free(c->d_cd2); dev_free(c->d_qpos); dev_free(c->d_dirty); dev_free(c->d_stream); dev_free(c->d_cblock_off); dev_free(c->d_cblock_cnt); dev_free(c->d_sel_prefix);
-  dev_free(c->d_sel_k); dev_free(c->d_sel_hist); dev_free(c->d_median); dev_free(c->d_chunk_edge); dev_free(c->d_chunk_start);
+  dev_free(c->d_cd2); dev_free(c->d_qpos); dev_free(c->d_dirty); dev_free(c->d_dirty_slots); dev_free(c->d_dslot_off); dev_free(c->d_stream); dev_free(c->d_cblock_off); dev_free(c->d_cblock_cnt); if (c->d_sel_state) (void)hipFree(c->d_sel_state);
+  c->d_sel_state = nullptr; dev_free(c->d_sel_hist); dev_free(c->d_median); dev_free(c->d_chunk_edge); dev_free(c->d_chunk_start);
   dev_free(c->d_chunk_first); dev_free(c->d_partials); dev_free(c->d_out);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   c->h_pin = nullptr; c->h_pin_doubles = 0;
@@ -373,8 +373,13 @@ int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) {
   MV_CHECK(dev_alloc(&c->d_qpos, cap)); MV_CHECK(dev_alloc(&c->d_dirty, (size_t)E));
   MV_HIP(hipMemset(c->d_qpos, 0xff, sizeof(int) * std::max<size_t>(cap, 1)));
   c->list_valid.assign(E, 0);
+  c->dslot_off.assign(E + 1, 0);
+  for (int e = 0; e < E; ++e) c->dslot_off[e + 1] = c->dslot_off[e] + (int)(((c->owned[e] ? c->frames[src[e]].n : 0) + 255) / 256);
+  c->n_dslots = c->dslot_off[E];
+  MV_CHECK(dev_alloc(&c->d_dirty_slots, (size_t)c->n_dslots)); MV_CHECK(dev_alloc(&c->d_dslot_off, (size_t)E + 1));
+  MV_HIP(hipMemcpy(c->d_dslot_off, c->dslot_off.data(), sizeof(int) * (E + 1), hipMemcpyHostToDevice));
   MV_CHECK(dev_alloc(&c->d_cblock_off, E + 1)); MV_CHECK(dev_alloc(&c->d_cblock_cnt, (size_t)c->n_cblocks));
-  MV_CHECK(dev_alloc(&c->d_sel_prefix, E)); MV_CHECK(dev_alloc(&c->d_sel_k, E)); MV_CHECK(dev_alloc(&c->d_sel_hist, (size_t)E * 256));
+  MV_HIP(hipMalloc(&c->d_sel_state, 16 * 8 * (size_t)std::max(E, 1))); MV_CHECK(dev_alloc(&c->d_sel_hist, (size_t)E * 256 * 8));
   MV_CHECK(dev_alloc(&c->d_median, E));
   MV_CHECK(dev_alloc(&c->d_chunk_edge, (size_t)c->n_chunks)); MV_CHECK(dev_alloc(&c->d_chunk_start, (size_t)c->n_chunks));
   MV_CHECK(dev_alloc(&c->d_chunk_first, E + 1));
@@ -471,6 +476,7 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
     int* hd = reinterpret_cast<int*>(c->h_pin + (size_t)E * kEdgeXf);
     std::memcpy(hd, dirty.data(), sizeof(int) * E);
     MV_HIP(hipMemcpyAsync(c->d_dirty, hd, sizeof(int) * E, hipMemcpyHostToDevice, c->stream));
+    if (c->n_dslots) MV_HIP(hipMemsetAsync(c->d_dirty_slots, 0, sizeof(int) * (size_t)c->n_dslots, c->stream));
   }
   if (method == MVICP_NN_BRUTE) MV_CHECK(launch_nn_brute_edges(c));
   else if (method == MVICP_NN_GRID) MV_CHECK(launch_nn_grid_edges(c, bound));

@@ -123,6 +123,7 @@ struct mvicp_ctx {
   int* d_first = nullptr; int* d_second = nullptr; double* d_cd2 = nullptr;
   int* d_qpos = nullptr;            // per query: its position in the edge's compacted list, or -1 (rejected by the cutoff)
   int* d_dirty = nullptr;           // E: != 0 -> the edge's list (membership or a neighbour) changed this round: re-compact + re-gather
+  int* d_dirty_slots = nullptr; int* d_dslot_off = nullptr; std::vector<int> dslot_off; int n_dslots = 0;  // one slot per 256 queries
   std::vector<char> list_valid;     // E: d_qpos / lists describe last round's result of this edge
   double* d_stream = nullptr;       // 9 x total_cap SoA: px py pz qx qy qz nx ny nz
   // compaction scratch
@@ -130,7 +131,7 @@ struct mvicp_ctx {
   std::vector<int> cblock_off;      // E+1
   int* d_cblock_off = nullptr; int* d_cblock_cnt = nullptr;
   // select scratch
-  unsigned long long* d_sel_prefix = nullptr; int* d_sel_k = nullptr; unsigned int* d_sel_hist = nullptr; double* d_median = nullptr;
+  void* d_sel_state = nullptr; unsigned int* d_sel_hist = nullptr; double* d_median = nullptr;
   // linearize chunks
   int lin_chunk = 4096;             // correspondences per linearize workgroup (chosen from the GLOBAL problem size)
   int n_chunks = 0;

@@ -177,65 +177,97 @@ __global__ __launch_bounds__(NT) void gather_kernel(const int* __restrict__ cblo
   }
 }
 
-// ---- radix select (8 passes x 8 bits, MSB first) over the fp64 patterns of the accepted d2 ------
-__global__ void select_init_kernel(const int* __restrict__ count, unsigned long long* __restrict__ prefix, int* __restrict__ kth,
-                                   unsigned int* __restrict__ hist, int E) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < E * 256) hist[t] = 0u;
-  if (t < E) { prefix[t] = 0ull; kth[t] = count[t] / 2; }  // dists.begin() + size()/2  (frame.cpp:166)
+// ---- radix select (8 passes x 8 bits, MSB first) over the fp64 patterns of the accepted d2 ------------------------
+// hist is [8 passes][E][256], zeroed once per call.  The digit pick of pass p+1 is recomputed by EVERY workgroup of
+// pass p from that pass's finished histogram (256 bins, trivial) instead of a separate 1-block-per-edge launch per
+// pass: 8 + 1 launches instead of 17, and no latency-bound pick kernels between the streaming passes.
+struct SelState { unsigned long long prefix; int k; };
+
+// One pick: given the finished histogram of digit `p` (restricted to keys matching st.prefix above it) choose the bin
+// holding rank st.k.  Wave 0 scans 4 bins per lane + a wave prefix sum; result shared through LDS.
+__device__ __forceinline__ SelState select_pick(const unsigned int* __restrict__ hist_pe, int p, SelState st, SelState* sh_state) {
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    const uint4 h = reinterpret_cast<const uint4*>(hist_pe)[lane];
+    const unsigned int tot = h.x + h.y + h.z + h.w;
+    unsigned int inc = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned int o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    const unsigned int before = inc - tot;  // keys in bins below this lane's 4
+    const unsigned int k = (unsigned int)st.k;
+    const bool mine = before <= k && k < inc;
+    // if no lane owns rank k (k >= total: cannot happen for k < count) the last bin is taken
+    const unsigned long long owners = __ballot(mine);
+    const int owner = owners ? __ffsll((long long)owners) - 1 : 63;
+    if (lane == owner) {
+      unsigned int cum = before;
+      int bin = 4 * lane + 3;
+      const unsigned int hv[4] = {h.x, h.y, h.z, h.w};
+      unsigned int cb = before;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (cum + hv[i] > k) { bin = 4 * lane + i; cb = cum; break; }
+        cum += hv[i];
+        cb = cum;
+      }
+      if (!owners) cb = before + tot - hv[3];
+      SelState o;
+      o.prefix = st.prefix | ((unsigned long long)bin << (8 * p));
+      o.k = (int)(k - cb);
+      *sh_state = o;
+    }
+  }
+  __syncthreads();
+  return *sh_state;
 }
 
 __global__ __launch_bounds__(NT) void select_hist_kernel(const int* __restrict__ cblock_off, int E, const int* __restrict__ count,
-                                                         const long long* __restrict__ cap_off, const double* __restrict__ cd2,
-                                                         const unsigned long long* __restrict__ prefix, int pass, unsigned int* __restrict__ hist) {
+                                                         const long long* __restrict__ cap_off, const double* __restrict__ cd2, int pass,
+                                                         unsigned int* __restrict__ hist, SelState* __restrict__ state) {
   __shared__ unsigned int lh[256];
+  __shared__ SelState sh_state;
   const int b = blockIdx.x;
   const int e = find_edge(cblock_off, E, b);
   const int lb = b - cblock_off[e];
   const int cnt = count[e];
   if (lb * kCompactBlock >= cnt) return;
+  // state after digit pass+1: start of the chain for pass 7, otherwise one pick on top of the state stored by the previous launch
+  SelState st;
+  st.prefix = 0ull; st.k = cnt / 2;   // dists.begin() + size()/2  (frame.cpp:166)
+  if (pass < 7) {
+    if (pass < 6) st = state[(size_t)(pass + 2) * E + e];
+    st = select_pick(hist + ((size_t)(pass + 1) * E + e) * 256, pass + 1, st, &sh_state);
+    if (lb == 0 && threadIdx.x == 0) state[(size_t)(pass + 1) * E + e] = st;
+  }
   lh[threadIdx.x] = 0u;
   __syncthreads();
   const long long base = cap_off[e];
-  const unsigned long long pre = prefix[e];
   const int shift = 8 * pass;
   for (int i = 0; i < IPT; ++i) {
     const int pos = lb * kCompactBlock + i * NT + threadIdx.x;
     if (pos < cnt) {
       const unsigned long long key = (unsigned long long)__double_as_longlong(cd2[base + pos]);
-      const bool match = (pass == 7) || ((key >> (shift + 8)) == (pre >> (shift + 8)));
+      const bool match = (pass == 7) || ((key >> (shift + 8)) == (st.prefix >> (shift + 8)));
       if (match) atomicAdd(&lh[(key >> shift) & 255ull], 1u);
     }
   }
   __syncthreads();
   const unsigned int v = lh[threadIdx.x];
-  if (v) atomicAdd(&hist[e * 256 + threadIdx.x], v);
+  if (v) atomicAdd(&hist[((size_t)pass * E + e) * 256 + threadIdx.x], v);
 }
 
-__global__ __launch_bounds__(256) void select_pick_kernel(unsigned long long* __restrict__ prefix, int* __restrict__ kth,
-                                                          unsigned int* __restrict__ hist, const int* __restrict__ count, int pass,
-                                                          double* __restrict__ median) {
-  __shared__ unsigned int sh[256];
+__global__ __launch_bounds__(256) void select_final_kernel(const unsigned int* __restrict__ hist, int E, const int* __restrict__ count,
+                                                           const SelState* __restrict__ state, double* __restrict__ median) {
+  __shared__ SelState sh_state;
   const int e = blockIdx.x;
-  sh[threadIdx.x] = hist[e * 256 + threadIdx.x];
-  hist[e * 256 + threadIdx.x] = 0u;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    if (count[e] > 0) {
-      unsigned int k = (unsigned int)kth[e], cum = 0;
-      int bin = 255;
-      for (int i = 0; i < 256; ++i) {
-        if (cum + sh[i] > k) { bin = i; break; }
-        cum += sh[i];
-      }
-      const unsigned long long p = prefix[e] | ((unsigned long long)bin << (8 * pass));
-      prefix[e] = p;
-      kth[e] = (int)(k - cum);
-      if (pass == 0) median[e] = __longlong_as_double((long long)p);
-    } else if (pass == 0) {
-      median[e] = 0.0;
-    }
-  }
+  const int cnt = count[e];
+  if (cnt <= 0) { if (threadIdx.x == 0) median[e] = 0.0; return; }
+  SelState st = state[(size_t)1 * E + e];
+  st = select_pick(hist + ((size_t)0 * E + e) * 256, 0, st, &sh_state);
+  if (threadIdx.x == 0) median[e] = __longlong_as_double((long long)st.prefix);
 }
 
 }  // namespace
@@ -277,15 +309,15 @@ int launch_gather_stream(mvicp_ctx* c) {
 
 int launch_select_median(mvicp_ctx* c) {
   if (c->n_cblocks == 0 || c->E == 0) return MVICP_OK;
-  ProfScope ps(c, "select", 0.0);
-  hipLaunchKernelGGL(select_init_kernel, dim3((c->E * 256 + 255) / 256), dim3(256), 0, c->stream, c->d_count, c->d_sel_prefix, c->d_sel_k,
-                     c->d_sel_hist, c->E);
-  for (int pass = 7; pass >= 0; --pass) {
+  double bytes = 0;
+  for (int e = 0; e < c->E; ++e) if (c->owned[e]) bytes += 64.0 * c->h_count[e];
+  ProfScope ps(c, "select", bytes);
+  MV_HIP(hipMemsetAsync(c->d_sel_hist, 0, sizeof(unsigned int) * 8 * (size_t)c->E * 256, c->stream));
+  for (int pass = 7; pass >= 0; --pass)
     hipLaunchKernelGGL(select_hist_kernel, dim3(c->n_cblocks), dim3(NT), 0, c->stream, c->d_cblock_off, c->E, c->d_count, c->d_cap_off, c->d_cd2,
-                       c->d_sel_prefix, pass, c->d_sel_hist);
-    hipLaunchKernelGGL(select_pick_kernel, dim3(c->E), dim3(256), 0, c->stream, c->d_sel_prefix, c->d_sel_k, c->d_sel_hist, c->d_count, pass,
-                       c->d_median);
-  }
+                       pass, c->d_sel_hist, (SelState*)c->d_sel_state);
+  hipLaunchKernelGGL(select_final_kernel, dim3(c->E), dim3(256), 0, c->stream, c->d_sel_hist, c->E, c->d_count, (const SelState*)c->d_sel_state,
+                     c->d_median);
   MV_HIP(hipGetLastError());
   return MVICP_OK;
 }

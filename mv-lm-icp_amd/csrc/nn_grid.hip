@@ -59,7 +59,7 @@ struct GridJob {
   int* out_idx; double* out_d2;
   const int* inv;      // target original index -> sorted position (null: emit original indices, raw-query API)
   // "did anything change?" bookkeeping of the edge's compacted list (all null for the raw-query API)
-  const int* qpos; const int* second; double* cd2; int* dirty;
+  const int* qpos; const int* second; double* cd2; const int* dirty; int* dirty_slots;  // dirty: host-forced flag; slots: one per NT queries
   double* out_lb;      // per query: lower bound on the distance to every target other than out_idx (null: no cache)
 };
 
@@ -131,19 +131,26 @@ __device__ __forceinline__ bool __lane0() {
 // The edge's compacted correspondence list survives a round unchanged when every query keeps both its acceptance
 // (cutoff test) and its neighbour; then only the squared distances need refreshing (in place), and compaction + operand
 // gather are skipped for that edge.  Anything else marks the edge dirty.
-__device__ __forceinline__ bool list_still_valid(const GridJob& job, int i, int idx_new, double d2_new, double bound) {
-  // an edge that is already dirty (forced by the host: no valid list yet, or flagged by another wave) needs no checking —
-  // and its qpos may be uninitialised
-  if (__hip_atomic_load(job.dirty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+// No hot-address atomics: a query that invalidates the list stores 1 into its workgroup's slot (plain store, benign
+// same-value race); dirty_reduce_kernel ORs the slots per edge afterwards.
+__device__ __forceinline__ void update_list(const GridJob& job, int i, int idx_new, double d2_new, double bound) {
+  if (*job.dirty != 0) return;   // forced dirty by the host (no valid list yet): nothing to check, qpos may be uninitialised
   const int pos = job.qpos[i];
   const bool acc = idx_new >= 0 && d2_new < bound;
-  if (pos < 0) return !acc;
-  if (!acc || job.second[pos] != idx_new) return false;
-  job.cd2[pos] = d2_new;
-  return true;
+  bool clean;
+  if (pos < 0) clean = !acc;
+  else {
+    clean = acc && job.second[pos] == idx_new;
+    if (clean) job.cd2[pos] = d2_new;
+  }
+  if (!clean) job.dirty_slots[i / NT] = 1;
 }
-__device__ __forceinline__ void mark_dirty(const GridJob& job, bool clean) {
-  if (__ballot(!clean) != 0ull && __lane0()) atomicOr(job.dirty, 1);
+
+__global__ void dirty_reduce_kernel(int E, const int* __restrict__ slot_off, const int* __restrict__ slots, int* __restrict__ dirty) {
+  const int e = blockIdx.x;
+  int any = 0;
+  for (int k = slot_off[e] + threadIdx.x; k < slot_off[e + 1]; k += blockDim.x) any |= slots[k];
+  if (__syncthreads_or(any) && threadIdx.x == 0) dirty[e] = 1;
 }
 
 // ---- phase 1: spatial-hash block lookup for every query; queries it cannot prove optimal go to the far list ----
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
       if (sqrt(d) * (1.0 + 1e-12) < nlb) {
         job.out_d2[out] = d;
         job.out_lb[out] = nlb;
-        if (job.dirty) mark_dirty(job, list_still_valid(job, i, pi, d, bound));
+        if (job.dirty) update_list(job, i, pi, d, bound);
         if (stats) {
           unsigned long long c1 = __reduce_add_u64(1ull);
           const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + (threadIdx.x >> 6);
@@ -258,7 +265,7 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
   job.out_d2[out] = best;
   // every other target is either a scanned candidate (>= second) or outside the block (>= m)
   if (job.out_lb != nullptr) job.out_lb[out] = resolved ? sqrt(fmin(second, m2)) * (1.0 - 1e-12) : 0.0;
-  if (job.dirty && (resolved || skip_far)) mark_dirty(job, list_still_valid(job, i, bi == 0x7fffffff ? -1 : job.inv[bi], best, bound));
+  if (job.dirty && (resolved || skip_far)) update_list(job, i, bi == 0x7fffffff ? -1 : job.inv[bi], best, bound);
   if (!resolved && !skip_far) {
     // wave-aggregated append: one atomic per wave
     const unsigned long long mask = __ballot(1);
@@ -402,7 +409,7 @@ __global__ __launch_bounds__(NT) void nn_far_kernel(const GridJob* __restrict__ 
       job.out_d2[out] = best;
       // every other target was scanned (>= second) or sits in a skipped box (>= its lower bound)
       if (job.out_lb != nullptr) job.out_lb[out] = bi == 0x7fffffff ? 0.0 : sqrt(fmin(second, pruned)) * (1.0 - 1e-12);
-      if (job.dirty && !list_still_valid(job, i, bi == 0x7fffffff ? -1 : job.inv[bi], best, bound)) atomicOr(job.dirty, 1);
+      if (job.dirty) update_list(job, i, bi == 0x7fffffff ? -1 : job.inv[bi], best, bound);
     }
   }
   if (stats) {
@@ -689,6 +696,8 @@ int run(mvicp_ctx* c, const std::vector<GridJob>& jobs, double bound) {
     // phase 2: persistent grid-stride launch (the far count is only known on the device)
     const unsigned int far_blocks = (unsigned int)std::min<size_t>(256 * 8, (total_q * 8 + NT - 1) / NT);
     hipLaunchKernelGGL(nn_far_kernel, dim3(far_blocks), dim3(NT), 0, c->stream, d_jobs, (const int2*)c->d_far_list, bound, c->d_far_count, d_stats, slots);
+    if (jobs[0].dirty_slots != nullptr)
+      hipLaunchKernelGGL(dirty_reduce_kernel, dim3(c->E), dim3(256), 0, c->stream, c->E, c->d_dslot_off, c->d_dirty_slots, c->d_dirty);
   }
   MV_HIP(hipGetLastError());
   if (d_stats) {
@@ -720,6 +729,7 @@ int launch_nn_grid_edges(mvicp_ctx* c, double d2_bound) {
     j.out_idx = c->d_nn_idx + c->cap_off[e]; j.out_d2 = c->d_nn_d2 + c->cap_off[e];
     j.inv = d.grid.inv; j.out_lb = c->d_nn_lb + c->cap_off[e];
     j.qpos = c->d_qpos + c->cap_off[e]; j.second = c->d_second + c->cap_off[e]; j.cd2 = c->d_cd2 + c->cap_off[e]; j.dirty = c->d_dirty + e;
+    j.dirty_slots = c->d_dirty_slots + c->dslot_off[e];
     jobs.push_back(j);
   }
   return run(c, jobs, d2_bound);
@@ -732,7 +742,7 @@ int launch_nn_grid_queries(mvicp_ctx* c, const FrameDev& f, const double* d_q, i
   jobs[0].q = d_q; jobs[0].qidx = nullptr; jobs[0].xf = nullptr; jobs[0].n = n;
   jobs[0].out_idx = d_idx; jobs[0].out_d2 = d_d2;
   jobs[0].inv = nullptr; jobs[0].out_lb = nullptr;
-  jobs[0].qpos = nullptr; jobs[0].second = nullptr; jobs[0].cd2 = nullptr; jobs[0].dirty = nullptr;
+  jobs[0].qpos = nullptr; jobs[0].second = nullptr; jobs[0].cd2 = nullptr; jobs[0].dirty = nullptr; jobs[0].dirty_slots = nullptr;
   return run(c, jobs, 1.7976931348623157e308);
 }
 
