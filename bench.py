@@ -174,19 +174,16 @@ def main():
     eng.profile(False)
 
     def pmc_traffic(name):
-        """HBM bytes per launch from the committed rocprofv3 PMC passes of THIS workload (tools/profile.sh): separate
-        --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled for the 16-B/lane coalesced linearize stream as
-        MI355X_MICROARCH.md §HBM prescribes for gfx950; other access patterns are uncalibrated and reported raw."""
-        path = os.path.join(ROOT, "profiles", f"r01_{args.workload}_{'grid' if args.nn in ('auto', 'grid') else args.nn}_kernels.json")
-        if world != 1 or not os.path.exists(path):
+        """HBM bytes per launch from the committed rocprofv3 PMC passes of THIS command (tools/profile.sh -> profiles/):
+        separate --pmc FETCH_SIZE / WRITE_SIZE runs, per bench scope, warm-up launches skipped.  FETCH_SIZE is doubled for
+        the 16-B/lane coalesced linearize stream as MI355X_MICROARCH.md §HBM prescribes for gfx950; the NN stage mixes access
+        widths (uncalibrated there), so its raw counters are used as they are."""
+        path = os.path.join(ROOT, "profiles", f"r01_{args.workload}_kernels.json")
+        if world != 1 or args.nn != "auto" or not os.path.exists(path):
             return None
         try:
-            kern = json.load(open(path))["kernels"]
-            key = {"linearize": "linearize_kernel<true, true>" if plane else "linearize_kernel<false, true>",
-                   "nn": {"grid": "nn_grid_kernel<false>", "auto": "nn_grid_kernel<false>", "tile": "nn_tile_kernel", "brute": "nn_brute_kernel"}[args.nn]}[name]
-            k = kern[key]
-            fetch = k["FETCH_SIZE_KiB"] * (2.0 if name == "linearize" else 1.0)
-            return (fetch + k["WRITE_SIZE_KiB"]) * 1024.0
+            sc = json.load(open(path))["scopes"][name]
+            return (sc["FETCH_SIZE_KiB"] * (2.0 if name == "linearize" else 1.0) + sc["WRITE_SIZE_KiB"]) * 1024.0
         except Exception:
             return None
 

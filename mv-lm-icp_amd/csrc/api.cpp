@@ -460,7 +460,7 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
       int m = 0;
       for (int e = 0; e < E; ++e)
         if (c->h_count[e] > 0) { dist += c->h_weight[e] / 1.5; cell += c->frames[c->edst[e]].grid.cell; ++m; }
-      if (m > 0 && dist < 0.5 * cell) method = MVICP_NN_GRID;
+      if (m > 0 && dist < 1.5 * cell) method = MVICP_NN_GRID;  // ICP contracts fast: next round's distances are a fraction of last round's
     }
   }
   if (method == MVICP_NN_GRID || method == MVICP_NN_TILE) {

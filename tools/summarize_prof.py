@@ -1,4 +1,9 @@
-"""Condenses rocprofv3 CSV output (tools/profile.sh) into small text summaries for profiles/."""
+"""Condenses rocprofv3 CSV output (tools/profile.sh) into small text/JSON summaries for profiles/.
+
+Per-kernel table (calls, total, avg, min, max) from the kernel trace; per-kernel PMC averages; and two SCOPES that match
+bench.py's HIP-event scopes: "nn" = every kernel of one mvicp_correspond NN stage (nn_grid phase 1, nn_far, nn_tile,
+dirty_reduce, census) and "linearize" = one linearize_kernel launch.  Scope figures skip the first `warmup` correspond
+calls (bench.py's untimed warm-up steps) so they are per TIMED launch like bench.py's `roofline.achieved`."""
 import csv
 import glob
 import json
@@ -7,6 +12,13 @@ import sys
 from collections import defaultdict
 
 out_dir, tag = sys.argv[1], sys.argv[2]
+warmup = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+
+KERNELS = ("nn_grid_kernel", "nn_far_kernel", "nn_tile_kernel", "nn_brute_kernel", "nn_brute_merge_kernel", "dirty_reduce_kernel", "census_sum_kernel",
+           "linearize_kernel", "reduce_expand_kernel", "gather_kernel", "scatter_kernel", "count_kernel", "scan_kernel", "select_hist_kernel",
+           "select_final_kernel", "normals_kernel")
+NN_SCOPE = ("nn_grid_kernel", "nn_far_kernel", "nn_tile_kernel", "nn_brute_kernel", "nn_brute_merge_kernel", "dirty_reduce_kernel", "census_sum_kernel")
+NN_HEAD = ("nn_grid_kernel", "nn_tile_kernel", "nn_brute_kernel")  # first kernel of an NN stage
 
 
 def find(sub, pat):
@@ -15,78 +27,93 @@ def find(sub, pat):
 
 
 def short(name):
-    n = name
-    for k in ("nn_grid_kernel", "nn_tile_kernel", "nn_brute_kernel", "linearize_kernel", "reduce_expand_kernel", "gather_kernel", "scatter_kernel",
-              "count_kernel", "scan_kernel", "select_hist_kernel", "select_pick_kernel", "select_init_kernel", "census_sum_kernel", "nn_brute_merge_kernel"):
-        if k in n:
-            i = n.find(k) + len(k)
-            extra = n[i:n.find(">", i) + 1] if n[i:i + 1] == "<" else ""
+    for k in KERNELS:
+        i = name.find(k)
+        if i >= 0:
+            j = i + len(k)
+            extra = name[j:name.find(">", j) + 1] if name[j:j + 1] == "<" else ""
             return k + extra
-    return n.split("(")[0][:60]
+    return name.split("(")[0][:60]
+
+
+def base(name):
+    return short(name).split("<")[0]
+
+
+def scope_calls(rows, value_of):
+    """rows: dispatches in Dispatch_Id order -> list of per-call sums for the nn scope, and list for linearize launches."""
+    nn_calls, lin = [], []
+    for r in rows:
+        b = base(r["Kernel_Name"])
+        if b in NN_HEAD:
+            nn_calls.append(0.0)
+        if b in NN_SCOPE and nn_calls:
+            nn_calls[-1] += value_of(r)
+        if b == "linearize_kernel":
+            lin.append(value_of(r))
+    return nn_calls, lin
 
 
 lines = []
+kern = {}
+scopes = {"nn": {}, "linearize": {}}
 tr = find("trace", "*kernel_trace.csv")
 if tr:
+    rows = sorted(csv.DictReader(open(tr)), key=lambda r: int(r["Dispatch_Id"]))
+    dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     agg = defaultdict(lambda: [0, 0.0, 1e30, 0.0])
-    with open(tr) as f:
-        for r in csv.DictReader(f):
-            d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-            a = agg[short(r["Kernel_Name"])]
-            a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
+    for r in rows:
+        a = agg[short(r["Kernel_Name"])]
+        d = dur(r)
+        a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
     tot = sum(a[1] for a in agg.values())
     lines.append(f"# rocprofv3 --kernel-trace --stats : {tag}")
     lines.append(f"{'kernel':48s} {'calls':>7s} {'total_us':>12s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'%':>6s}")
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         lines.append(f"{k:48s} {a[0]:7d} {a[1]:12.1f} {a[1]/a[0]:10.2f} {a[2]:10.2f} {a[3]:10.2f} {100*a[1]/tot:6.2f}")
+        kern.setdefault(k, {})["avg_us"] = a[1] / a[0]; kern[k]["calls"] = a[0]
+    nn_calls, lin = scope_calls(rows, dur)
+    if len(nn_calls) > warmup:
+        t = nn_calls[warmup:]
+        scopes["nn"].update(avg_us=sum(t) / len(t), calls=len(t))
+    if lin:
+        scopes["linearize"].update(avg_us=sum(lin) / len(lin), calls=len(lin))
+    lines.append("")
+    lines.append(f"# scopes (bench.py HIP-event scopes; first {warmup} NN stage(s) = warm-up skipped)")
+    for k, v in scopes.items():
+        if v:
+            lines.append(f"{k:12s} calls {v['calls']:5d}  avg_us {v['avg_us']:10.2f}")
 for sub, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     cc = find(sub, "*counter_collection.csv")
     if not cc:
         continue
+    rows = sorted((r for r in csv.DictReader(open(cc)) if r.get("Counter_Name") == ctr), key=lambda r: int(r["Dispatch_Id"]))
     agg = defaultdict(lambda: [0, 0.0])
-    with open(cc) as f:
-        for r in csv.DictReader(f):
-            if r.get("Counter_Name") != ctr:
-                continue
-            a = agg[short(r["Kernel_Name"])]
-            a[0] += 1; a[1] += float(r["Counter_Value"])
+    for r in rows:
+        a = agg[short(r["Kernel_Name"])]
+        a[0] += 1; a[1] += float(r["Counter_Value"])
     lines.append("")
     lines.append(f"# rocprofv3 --pmc {ctr} (KiB per dispatch, raw counter; gfx950: FETCH_SIZE reads 1/2 of a wide coalesced stream, MI355X_MICROARCH.md §HBM)")
     lines.append(f"{'kernel':48s} {'dispatches':>10s} {'avg_KiB':>14s}")
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         lines.append(f"{k:48s} {a[0]:10d} {a[1]/a[0]:14.1f}")
-for nm in ("bench_trace.json",):
-    p = os.path.join(out_dir, nm)
-    if os.path.exists(p):
-        try:
-            j = json.loads(open(p).read().strip().splitlines()[-1])
-            lines.append("")
-            lines.append("# bench line of the traced run (HIP-event figures measured live in bench.py)")
-            lines.append(json.dumps({k: j[k] for k in ("value", "ms_per_step", "roofline", "roofline_nn", "roofline_linearize", "kernel_ms_per_step") if k in j}))
-        except Exception as ex:
-            lines.append(f"# bench line unreadable: {ex}")
-# machine-readable per-kernel figures for bench.py's `traffic` field
-kern = {}
-if tr:
-    with open(tr) as f:
-        agg = defaultdict(lambda: [0, 0.0])
-        for r in csv.DictReader(f):
-            a = agg[short(r["Kernel_Name"])]
-            a[0] += 1; a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-        for k, a in agg.items():
-            kern.setdefault(k, {})["avg_us"] = a[1] / a[0]; kern[k]["calls"] = a[0]
-for sub, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-    cc = find(sub, "*counter_collection.csv")
-    if cc:
-        agg = defaultdict(lambda: [0, 0.0])
-        with open(cc) as f:
-            for r in csv.DictReader(f):
-                if r.get("Counter_Name") == ctr:
-                    a = agg[short(r["Kernel_Name"])]
-                    a[0] += 1; a[1] += float(r["Counter_Value"])
-        for k, a in agg.items():
-            kern.setdefault(k, {})[ctr + "_KiB"] = a[1] / a[0]
-json.dump({"tag": tag, "kernels": kern}, open(os.path.join(out_dir, f"{tag}_kernels.json"), "w"), indent=1, sort_keys=True)
+        kern.setdefault(k, {})[ctr + "_KiB"] = a[1] / a[0]
+    nn_calls, lin = scope_calls(rows, lambda r: float(r["Counter_Value"]))
+    if len(nn_calls) > warmup:
+        t = nn_calls[warmup:]
+        scopes["nn"][ctr + "_KiB"] = sum(t) / len(t)
+    if lin:
+        scopes["linearize"][ctr + "_KiB"] = sum(lin) / len(lin)
+p = os.path.join(out_dir, "bench_trace.json")
+if os.path.exists(p):
+    try:
+        j = json.loads(open(p).read().strip().splitlines()[-1])
+        lines.append("")
+        lines.append("# bench line of the traced run (HIP-event figures measured live in bench.py)")
+        lines.append(json.dumps({k: j[k] for k in ("value", "ms_per_step", "roofline", "roofline_nn", "roofline_linearize", "kernel_ms_per_step") if k in j}))
+    except Exception as ex:
+        lines.append(f"# bench line unreadable: {ex}")
+json.dump({"tag": tag, "warmup_skipped": warmup, "kernels": kern, "scopes": scopes}, open(os.path.join(out_dir, f"{tag}_kernels.json"), "w"), indent=1, sort_keys=True)
 txt = "\n".join(lines) + "\n"
 open(os.path.join(out_dir, f"{tag}_summary.txt"), "w").write(txt)
 print(txt)
