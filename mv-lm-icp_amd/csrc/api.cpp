@@ -20,6 +20,22 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+int cached_upload(mvicp_ctx* c, const char* key, const void* src, size_t bytes, void** dptr) {
+  mvicp_ctx::CachedTable& t = c->tables[key];
+  if (t.d && t.bytes.size() == bytes && std::memcmp(t.bytes.data(), src, bytes) == 0) { *dptr = t.d; return MVICP_OK; }
+  MV_HIP(hipStreamSynchronize(c->stream));  // earlier kernels may still read the old copy
+  if (bytes > t.cap) {
+    if (t.d) MV_HIP(hipFree(t.d));
+    t.d = nullptr;
+    MV_HIP(hipMalloc(&t.d, std::max<size_t>(bytes, 256)));
+    t.cap = std::max<size_t>(bytes, 256);
+  }
+  MV_HIP(hipMemcpy(t.d, src, bytes, hipMemcpyHostToDevice));
+  t.bytes.assign((const char*)src, (const char*)src + bytes);
+  *dptr = t.d;
+  return MVICP_OK;
+}
+
 void scratch_reset(mvicp_ctx* c) { c->scratch_used = 0; }
 
 int scratch_upload(mvicp_ctx* c, const void* src, size_t bytes, void** dptr) {
@@ -150,7 +166,7 @@ int ensure_pin(mvicp_ctx* c, size_t doubles) {
 
 // Per-edge relative transform for the LM kernels: A = R_d^T R_s, t = R_d^T (t_s - t_d).
 int upload_rel(mvicp_ctx* c, const double* poses) {
-  double* h = c->h_pin;  // E x 12 at offset 0
+  double* h = c->h_pin + (size_t)c->E * kEdgeXf;  // rel region
   for (int e = 0; e < c->E; ++e) {
     const double* Ps = poses + 16 * (size_t)c->esrc[e];
     const double* Pd = poses + 16 * (size_t)c->edst[e];
@@ -179,7 +195,7 @@ int evaluate_blocks(mvicp_ctx* c, const double* poses, int plane, int robust, do
   MV_CHECK(launch_linearize(c, plane, robust));
   const size_t n = (size_t)c->E * MVICP_EDGE_BLOCK;
   if (c->comm) MV_CHECK(comm_allreduce_sum(c, c->d_out, n));
-  double* h = c->h_pin + (size_t)c->E * kEdgeRel;
+  double* h = c->h_pin + (size_t)c->E * (kEdgeXf + kEdgeRel);  // blocks region
   MV_HIP(hipMemcpyAsync(h, c->d_out, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
   MV_HIP(hipStreamSynchronize(c->stream));
   std::memcpy(out, h, sizeof(double) * n);
@@ -221,6 +237,7 @@ int mvicp_destroy(mvicp_ctx* c) {
   free_graph(c);
   for (FrameDev& f : c->frames) { dev_free(f.pts); dev_free(f.nor); free_grid(f.grid); }
   dev_free(c->d_split_idx); dev_free(c->d_split_d2); dev_free(c->d_scratch);
+  for (auto& kv : c->tables) if (kv.second.d) (void)hipFree(kv.second.d);
   if (c->d_census) (void)hipFree(c->d_census);
   if (c->d_far_list) (void)hipFree(c->d_far_list);
   if (c->d_far_count) (void)hipFree(c->d_far_count);
@@ -398,7 +415,7 @@ int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) {
     MV_HIP(hipMemcpy(c->d_chunk_edge, chunk_edge.data(), sizeof(int) * c->n_chunks, hipMemcpyHostToDevice));
     MV_HIP(hipMemcpy(c->d_chunk_start, chunk_start.data(), sizeof(int) * c->n_chunks, hipMemcpyHostToDevice));
   }
-  MV_CHECK(ensure_pin(c, (size_t)E * (kEdgeXf + kEdgeRel + MVICP_EDGE_BLOCK + 8) + 64));
+  MV_CHECK(ensure_pin(c, (size_t)E * (kEdgeXf + kEdgeRel + MVICP_EDGE_BLOCK + 8) + 64));  // regions: see pin_* below
   return MVICP_OK;
 }
 
@@ -441,9 +458,11 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
     std::memcpy(pq, Mq, sizeof(Mq));
   }
   MV_HIP(hipMemcpyAsync(c->d_xf, hx, sizeof(double) * (size_t)E * kEdgeXf, hipMemcpyHostToDevice, c->stream));
-  MV_HIP(hipStreamSynchronize(c->stream));
-  std::memcpy(hx, nsrc.data(), sizeof(int) * E);
-  MV_HIP(hipMemcpyAsync(c->d_nsrc, hx, sizeof(int) * E, hipMemcpyHostToDevice, c->stream));
+  // pinned regions (doubles): [0, E*kEdgeXf) xf | +E*12 rel | +E*91 blocks | then 8 slices of E: nsrc, dirty, counts, medians, a, ...
+  double* pin_misc = c->h_pin + (size_t)E * (kEdgeXf + kEdgeRel + MVICP_EDGE_BLOCK);
+  int* hn = reinterpret_cast<int*>(pin_misc);
+  std::memcpy(hn, nsrc.data(), sizeof(int) * E);
+  MV_HIP(hipMemcpyAsync(c->d_nsrc, hn, sizeof(int) * E, hipMemcpyHostToDevice, c->stream));
 
   const double bound = sqrt_bound((double)thresh);
   double t_mark = now_ms();
@@ -473,7 +492,7 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
     std::vector<int> dirty(E, 1);
     if (method == MVICP_NN_GRID && !c->nn_tree_only && !c->nn_skip_far && c->list_reuse)
       for (int e = 0; e < E; ++e) if (c->active[e] && c->list_valid[e]) dirty[e] = 0;
-    int* hd = reinterpret_cast<int*>(c->h_pin + (size_t)E * kEdgeXf);
+    int* hd = reinterpret_cast<int*>(pin_misc + E);
     std::memcpy(hd, dirty.data(), sizeof(int) * E);
     MV_HIP(hipMemcpyAsync(c->d_dirty, hd, sizeof(int) * E, hipMemcpyHostToDevice, c->stream));
     if (c->n_dslots) MV_HIP(hipMemsetAsync(c->d_dirty_slots, 0, sizeof(int) * (size_t)c->n_dslots, c->stream));
@@ -494,8 +513,8 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   MV_CHECK(launch_select_median(c));
   mark("host.corr.post_launch");
   // counts + median d2 back; weight = (float)(1.5 * sqrt(median d2))  (frame.cpp:168-176)
-  int* hc = reinterpret_cast<int*>(c->h_pin);
-  double* hm = c->h_pin + E;  // leave room: E ints fit in E doubles
+  int* hc = reinterpret_cast<int*>(pin_misc + 2 * (size_t)E);
+  double* hm = pin_misc + 3 * (size_t)E;
   MV_HIP(hipMemcpyAsync(hc, c->d_count, sizeof(int) * E, hipMemcpyDeviceToHost, c->stream));
   MV_HIP(hipMemcpyAsync(hm, c->d_median, sizeof(double) * E, hipMemcpyDeviceToHost, c->stream));
   MV_HIP(hipStreamSynchronize(c->stream));
@@ -504,7 +523,7 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   for (int e = 0; e < E; ++e)
     if (c->owned[e]) { pack[2 * e] = c->active[e] ? hc[e] : 0; pack[2 * e + 1] = (c->active[e] && hc[e] > 0) ? hm[e] : 0.0; }
   if (c->comm) MV_CHECK(comm_allreduce_host(c, pack.data(), pack.size()));
-  double* ha = c->h_pin;
+  double* ha = pin_misc + 4 * (size_t)E;   // own region: the async copy below is not waited for
   for (int e = 0; e < E; ++e) {
     c->h_count[e] = (int)pack[2 * e];
     const double nth = std::sqrt(pack[2 * e + 1]);
@@ -514,7 +533,6 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
     if (weights) weights[e] = c->h_weight[e];
   }
   MV_HIP(hipMemcpyAsync(c->d_a, ha, sizeof(double) * E, hipMemcpyHostToDevice, c->stream));
-  MV_HIP(hipStreamSynchronize(c->stream));
   c->have_corr = true;
   mark("host.corr.finish");
   if (c->profile) prof_collect(c);

@@ -144,6 +144,9 @@ struct mvicp_ctx {
   // brute-force split scratch
   int* d_split_idx = nullptr; double* d_split_d2 = nullptr; size_t split_cap = 0;
 
+  // cached small tables
+  struct CachedTable { std::vector<char> bytes; void* d = nullptr; size_t cap = 0; };
+  std::map<std::string, CachedTable> tables;
   // table scratch
   char* d_scratch = nullptr; size_t scratch_bytes = 0, scratch_used = 0;
   std::vector<char> active;        // E: owned && src not fixed (set by correspond)
@@ -186,6 +189,8 @@ int launch_normals(mvicp_ctx* c, FrameDev& f, int k, int* d_knn);               
 
 // small host->device table uploads through a persistent bump-allocated scratch buffer; the copy is a
 // synchronous hipMemcpy (tables are tiny) so the pageable source may die right after the call.
+// device copy of a small host table, re-uploaded only when its bytes change (job / pointer tables are the same every round)
+int cached_upload(mvicp_ctx* c, const char* key, const void* src, size_t bytes, void** dptr);
 void scratch_reset(mvicp_ctx* c);
 int scratch_upload(mvicp_ctx* c, const void* src, size_t bytes, void** dptr);
 

@@ -296,8 +296,7 @@ int launch_gather_stream(mvicp_ctx* c) {
     tab[2 * c->E + e] = c->frames[c->edst[e]].grid.snor;
   }
   const void** d_tab = nullptr;
-  scratch_reset(c);
-  MV_CHECK(scratch_upload(c, tab.data(), sizeof(void*) * tab.size(), (void**)&d_tab));
+  MV_CHECK(cached_upload(c, "gather_tab", tab.data(), sizeof(void*) * tab.size(), (void**)&d_tab));
   {
     ProfScope ps(c, "gather", 0.0);
     hipLaunchKernelGGL(gather_kernel, dim3(c->n_cblocks), dim3(NT), 0, c->stream, c->d_cblock_off, c->E, c->d_count, c->d_cap_off, c->total_cap,

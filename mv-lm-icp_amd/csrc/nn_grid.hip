@@ -663,8 +663,7 @@ int run(mvicp_ctx* c, const std::vector<GridJob>& jobs, double bound) {
   for (const GridJob& j : jobs) { max_n = std::max(max_n, j.n); nq += j.n; }
   if (max_n == 0) return MVICP_OK;
   GridJob* d_jobs = nullptr;
-  scratch_reset(c);
-  MV_CHECK(scratch_upload(c, jobs.data(), sizeof(GridJob) * jobs.size(), (void**)&d_jobs));
+  MV_CHECK(cached_upload(c, jobs[0].xf ? "grid_jobs" : "grid_jobs_raw", jobs.data(), sizeof(GridJob) * jobs.size(), (void**)&d_jobs));
   unsigned long long* d_stats = nullptr;
   const size_t slots = (size_t)((max_n + NT - 1) / NT) * jobs.size() * (NT / 64);
   if (c->profile && c->nn_census) {
@@ -724,6 +723,7 @@ int launch_nn_grid_edges(mvicp_ctx* c, double d2_bound) {
     const FrameDev& d = c->frames[c->edst[e]];
     if (!s.has_grid || !d.has_grid) { set_error("grid NN needs the per-cloud structure on frames %d and %d", c->esrc[e], c->edst[e]); return MVICP_ERR_STATE; }
     GridJob j;
+    std::memset(&j, 0, sizeof(j));  // padding too: the table is cached by content
     j.dst = view_of(d);
     j.q = s.grid.spts; j.qidx = nullptr; j.xf = c->d_xf + (size_t)e * kEdgeXf; j.n = s.n;
     j.out_idx = c->d_nn_idx + c->cap_off[e]; j.out_d2 = c->d_nn_d2 + c->cap_off[e];

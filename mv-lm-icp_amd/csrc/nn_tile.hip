@@ -21,6 +21,7 @@
 // (centimetre misalignment) and the converged regime run the same code, the former just opens more leaves.
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <limits>
 #include <vector>
 
@@ -327,6 +328,7 @@ int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound) {
     const FrameDev& d = c->frames[c->edst[e]];
     if (!s.has_grid || !d.has_grid) { set_error("tile NN needs the per-cloud structure on frames %d and %d", c->esrc[e], c->edst[e]); return MVICP_ERR_STATE; }
     TileJob j;
+    std::memset(&j, 0, sizeof(j));  // padding too: the table is cached by content
     j.dst = view_of(d);
     j.q = s.grid.spts; j.qidx = nullptr; j.xf = c->d_xf + (size_t)e * kEdgeXf; j.n = s.n;
     j.out_idx = c->d_nn_idx + c->cap_off[e]; j.out_d2 = c->d_nn_d2 + c->cap_off[e];
@@ -337,8 +339,7 @@ int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound) {
   }
   if (jobs.empty() || max_n == 0) return MVICP_OK;
   TileJob* d_jobs = nullptr;
-  scratch_reset(c);
-  MV_CHECK(scratch_upload(c, jobs.data(), sizeof(TileJob) * jobs.size(), (void**)&d_jobs));
+  MV_CHECK(cached_upload(c, jobs[0].xf ? "tile_jobs" : "tile_jobs_raw", jobs.data(), sizeof(TileJob) * jobs.size(), (void**)&d_jobs));
   unsigned long long* d_stats = nullptr;
   const size_t slots = (size_t)((max_n + NT - 1) / NT) * jobs.size() * (NT / 64);
   if (c->profile && c->nn_census) {
