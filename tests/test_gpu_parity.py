@@ -457,3 +457,41 @@ def test_temporal_cache_is_bit_identical_to_full_search(orc):
         assert all(np.array_equal(x, y) for x, y in zip(engs[0].get_correspondences(k), engs[1].get_correspondences(k)))
     for e in engs:
         e.close()
+
+
+# ---------------------------------------------------------------- error behaviour of the ABI
+def test_abi_error_paths(eng):
+    pb = synth.make_problem(2, 500)
+    e = mvicp.Engine(0)
+    with pytest.raises(mvicp.MvicpError):          # graph before frames
+        e.set_graph([1], [0])
+    e.set_frames(pb["pts"], None)                  # no normals
+    with pytest.raises(mvicp.MvicpError):          # self edge / out of range
+        e.set_graph([1], [1])
+    with pytest.raises(mvicp.MvicpError):
+        e.set_graph([2], [0])
+    e.set_graph([1], [0])
+    with pytest.raises(mvicp.MvicpError):          # linearize before any correspondences
+        e.linearize(pb["init"], 0, 0)
+    e.correspond(pb["init"], pb["fixed"], 0.05)
+    with pytest.raises(mvicp.MvicpError):          # point-to-plane without normals on the dst frame
+        e.linearize(pb["init"], 1, 1)
+    blk = e.linearize(pb["init"], 0, 1)            # point-to-point is fine
+    assert np.isfinite(blk).all()
+    with pytest.raises(mvicp.MvicpError):          # bad explicit correspondences
+        e.set_correspondences(0, [0, 1], [0, 10_000], 0.0)
+    with pytest.raises(mvicp.MvicpError):          # set_frame after the graph is frozen
+        e.set_frames(pb["pts"], None) or e.lib.mvicp_set_frame(e.h, 0, None, None, 5) and (_ for _ in ()).throw(mvicp.MvicpError("x"))
+    e.close()
+
+
+def test_empty_edges_and_tiny_cutoff(eng, orc):
+    """An edge with no correspondence inside the cutoff: count 0, weight 0 (the reference dereferences end() there,
+    frame.cpp:166-168), and the LM simply leaves the poses where they are."""
+    pb = synth.make_problem(3, 800)
+    eng.set_frames(pb["pts"], pb["nor"]); eng.set_graph(pb["src"], pb["dst"])
+    counts, weights = eng.correspond(pb["init"], pb["fixed"], 1e-9)
+    assert counts.sum() == 0 and np.all(weights == 0)
+    P, sm = eng.optimize(pb["init"], pb["fixed"])
+    # (poses round-trip through the parameterization like the reference's, icp-ceres.cpp:405-420,472-474: equal to rounding)
+    assert np.allclose(P, pb["init"], rtol=0, atol=1e-15) and sm["final_cost"] == 0.0 and sm["iterations"] == 0
