@@ -361,7 +361,8 @@ int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) {
   {
     double total = 0;
     for (int e = 0; e < E; ++e) total += c->frames[src[e]].n;
-    c->lin_chunk = total >= 6e6 ? 4096 : total >= 2e6 ? 2048 : total >= 5e5 ? 1024 : 512;
+    c->lin_chunk = total >= 6e6 ? 8192 : total >= 2e6 ? 4096 : total >= 5e5 ? 1024 : 512;
+    if (c->lin_chunk_override > 0) c->lin_chunk = c->lin_chunk_override;
   }
   const int kLinChunk = c->lin_chunk;
   c->cap_off.assign(E + 1, 0);
@@ -647,6 +648,7 @@ int mvicp_set_option(mvicp_ctx* c, const char* name, double value) {
   if (!name) { set_error("null option name"); return MVICP_ERR_ARG; }
   if (std::strcmp(name, "nn_tree_only") == 0) { c->nn_tree_only = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "nn_cache") == 0) { c->nn_cache_enable = value != 0.0; c->nn_cache_valid = false; return MVICP_OK; }
+  if (std::strcmp(name, "lin_chunk") == 0) { c->lin_chunk_override = (int)value; return MVICP_OK; }  // takes effect at the next mvicp_set_graph
   if (std::strcmp(name, "list_reuse") == 0) { c->list_reuse = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "nn_census") == 0) { c->nn_census = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "nn_skip_far") == 0) { c->nn_skip_far = value != 0.0; return MVICP_OK; }

@@ -133,6 +133,7 @@ struct mvicp_ctx {
   // select scratch
   void* d_sel_state = nullptr; unsigned int* d_sel_hist = nullptr; double* d_median = nullptr;
   // linearize chunks
+  int lin_chunk_override = 0;
   int lin_chunk = 4096;             // correspondences per linearize workgroup (chosen from the GLOBAL problem size)
   int n_chunks = 0;
   std::vector<int> chunk_first;     // E+1

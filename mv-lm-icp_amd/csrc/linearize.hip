@@ -183,25 +183,30 @@ __device__ __forceinline__ void cross_mat(const double* a, double* M) {  // row-
 }
 
 template <bool PLANE>
-__global__ __launch_bounds__(64) void reduce_expand_kernel(const int* __restrict__ chunk_first, int chunk, const int* __restrict__ count,
+__global__ __launch_bounds__(256) void reduce_expand_kernel(const int* __restrict__ chunk_first, int chunk, const int* __restrict__ count,
                                                            const double* __restrict__ rel, const double* __restrict__ partials,
                                                            double* __restrict__ out) {
   const int e = blockIdx.x;
   const int tid = threadIdx.x;
-  __shared__ double m[2][NACC];
+  __shared__ double m[8][NACC];
   __shared__ double S[36], X[36], Y[36], Ad[36], T1[36], T2[36], H[144], v[6];
   const int c0 = chunk_first[e];
   const int nchunks = min(chunk_first[e + 1] - c0, (count[e] + chunk - 1) / chunk);
   {
-    // 64 threads: two interleaved fixed-order partial sums per value, combined in fixed order
-    const int val = tid & (NACC - 1), half = tid >> 5;
+    // 256 threads: eight interleaved fixed-order partial sums per value (short dependent-load chains), combined in fixed order
+    const int val = tid & (NACC - 1), part = tid >> 5;
     double s = 0.0;
-    for (int c = half; c < nchunks; c += 2) s += partials[(size_t)(c0 + c) * NACC + val];
-    m[half][val] = s;
+    for (int c = part; c < nchunks; c += 8) s += partials[(size_t)(c0 + c) * NACC + val];
+    m[part][val] = s;
   }
   if (tid < 36) { S[tid] = 0.0; X[tid] = 0.0; Y[tid] = 0.0; Ad[tid] = 0.0; }
   __syncthreads();
-  if (tid < NACC) m[0][tid] += m[1][tid];
+  if (tid < NACC) {
+    double s = m[0][tid];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) s += m[k][tid];
+    m[0][tid] = s;
+  }
   __syncthreads();
   const double* mm = m[0];
   const double* A = rel + (size_t)e * kEdgeRel;  // column-major 3x3
@@ -287,7 +292,7 @@ __global__ __launch_bounds__(64) void reduce_expand_kernel(const int* __restrict
     o[90] = count[e] > 0 ? mm[PLANE ? 27 : 28] : 0.0;
   }
   __syncthreads();
-  for (int k = tid; k < 78; k += 64) {
+  for (int k = tid; k < 78; k += 256) {
     int i = 0, r = k;
     while (r >= 12 - i) { r -= 12 - i; ++i; }
     const int j = i + r;
@@ -317,9 +322,9 @@ int launch_linearize(mvicp_ctx* c, int plane, int robust) {
   {
     ProfScope ps(c, "reduce", 0.0);
     if (plane)
-      hipLaunchKernelGGL((reduce_expand_kernel<true>), dim3(c->E), dim3(64), 0, c->stream, c->d_chunk_first, chunk, c->d_count, c->d_rel, c->d_partials, c->d_out);
+      hipLaunchKernelGGL((reduce_expand_kernel<true>), dim3(c->E), dim3(256), 0, c->stream, c->d_chunk_first, chunk, c->d_count, c->d_rel, c->d_partials, c->d_out);
     else
-      hipLaunchKernelGGL((reduce_expand_kernel<false>), dim3(c->E), dim3(64), 0, c->stream, c->d_chunk_first, chunk, c->d_count, c->d_rel, c->d_partials, c->d_out);
+      hipLaunchKernelGGL((reduce_expand_kernel<false>), dim3(c->E), dim3(256), 0, c->stream, c->d_chunk_first, chunk, c->d_count, c->d_rel, c->d_partials, c->d_out);
   }
   MV_HIP(hipGetLastError());
   return MVICP_OK;

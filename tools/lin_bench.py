@@ -11,6 +11,8 @@ K, N = int(sys.argv[1]) if len(sys.argv) > 1 else 16, int(sys.argv[2]) if len(sy
 reps = 20
 pb = synth.make_problem(K, N)
 eng = mvicp.Engine(0)
+if len(sys.argv) > 3:
+    eng.set_option("lin_chunk", int(sys.argv[3]))
 eng.set_frames(pb["pts"], pb["nor"])
 eng.set_graph(pb["src"], pb["dst"])
 eng.correspond(pb["init"], pb["fixed"], 0.05, L.NN_GRID)
