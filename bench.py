@@ -30,6 +30,7 @@ WORKLOADS = {
     "cfg3": (8, 100_000, 1, 1, "cfg3: multiview 8 views x 100k pts, point-to-plane, angle-axis"),
     "cfg4": (32, 200_000, 1, 2, "cfg4: multiview 32 views x 200k pts, point-to-plane, SophusSE3 (E=62)"),
     "cfg5": (64, 1_000_000, 1, 2, "cfg5: multiview 64 views x 1M pts, point-to-plane, SophusSE3 (E=126)"),
+    "shard8": (5, 200_000, 1, 2, "shard8: 5 views x 200k pts (E=8): the per-rank share of cfg4 on 8 GPUs, for fixed-cost analysis"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
 
