@@ -51,8 +51,6 @@ struct GridDev {
   std::vector<int> h_order, h_inv;  // host copies: sorted -> original, original -> sorted
   void* table = nullptr;       // open-addressing hash: cell -> (start, count), 16-B entries
   unsigned int table_mask = 0; int table_shift = 0;
-  float* bvh = nullptr;        // implicit complete AABB tree, 6 floats per node (outward rounded)
-  int depth = 0;
   float* oct = nullptr;        // implicit complete 8-ary box tree, 8 floats per node {lo.xyz, hi.xyz, pad2}
   int oct_depth = 0; long long oct_first_leaf = 0;
   // 64-wide box hierarchy over the same sorted array (nn_tile.hip): level 0 = boxes of 64-point leaves,

@@ -14,12 +14,13 @@
 //     cloud: neighbouring lanes ask about neighbouring places, so hash slots / point runs / tree nodes are
 //     shared inside a wave and stay in L2.
 //   * an open-addressing hash table  cell -> (start, count)  (16-B entries, <= 50 % load): the spatial hash.
-//   * an implicit complete binary tree over the sorted array (leaf j = points [j n / 2^D, (j+1) n / 2^D),
-//     4..8 points) with float AABBs rounded OUTWARD per node, heap-indexed: no pointers.
-// Query = (1) scan the 2x2x2 cell block around the query through the hash; the best candidate is provably
-// the global NN iff it is closer than the distance to the block's faces (>= h/2); (2) otherwise an exact
-// branch-and-bound descent of the AABB tree seeded with that candidate (or with the cutoff bound: matches
-// at or beyond the cutoff are discarded by frame.cpp:156 anyway, so nothing beyond it needs resolving).
+//   * an implicit complete 8-ary box tree over the sorted array (leaf j = points [j n / 8^D, (j+1) n / 8^D), float
+//     AABBs rounded OUTWARD, 32 B per node, heap-indexed: no pointers).
+// Query = (0) temporal cache: if last round's neighbour is provably still nearest, re-evaluate its distance and stop;
+// (1) scan the 2x2x2 cell block around the query through the hash; the best candidate is provably the global NN iff
+// it is closer than the distance to the block's faces (>= h/2); (2) otherwise the query joins a compacted far list
+// and an octet of lanes runs an exact branch-and-bound descent of the 8-ary tree seeded with that candidate (or with
+// the cutoff bound: matches at or beyond the cutoff are discarded by frame.cpp:156 anyway).
 // Pruning is exact in floating point: the box lower bound is evaluated with the SAME rounded operations as
 // the point distance, and every rounding is monotone, so lb <= d2 for every point in the box; nodes are
 // skipped only when lb > best (ties are still visited for the index rule).
@@ -37,7 +38,6 @@ namespace mvicp {
 namespace {
 
 constexpr int NT = 256;
-constexpr int MAXD = 24;
 constexpr unsigned long long EMPTY = ~0ull;
 
 struct HashEntry { unsigned long long key; unsigned int start, count; };
@@ -47,7 +47,6 @@ struct GridView {  // device view of one cloud's structure
   const HashEntry* table; unsigned int mask; int shift;
   double ox, oy, oz, h, inv_h;
   int dx, dy, dz;
-  const float* bvh; int depth;
   const float* oct; int oct_depth; long long oct_first_leaf;   // implicit 8-ary box tree (32-B boxes), phase 2
 };
 
@@ -85,14 +84,6 @@ __device__ __forceinline__ void xf_point(const double* __restrict__ x, double p0
 __device__ __forceinline__ double dist2(double qx, double qy, double qz, double x, double y, double z) {
   const double d0 = __dsub_rn(qx, x), d1 = __dsub_rn(qy, y), d2 = __dsub_rn(qz, z);
   return __dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2));
-}
-
-// exact-order lower bound of dist2(q, p) over all p in the (outward rounded) box
-__device__ __forceinline__ double box_lb(double qx, double qy, double qz, const float* __restrict__ b) {
-  const double g0 = fmax(fmax(__dsub_rn((double)b[0], qx), __dsub_rn(qx, (double)b[3])), 0.0);
-  const double g1 = fmax(fmax(__dsub_rn((double)b[1], qy), __dsub_rn(qy, (double)b[4])), 0.0);
-  const double g2 = fmax(fmax(__dsub_rn((double)b[2], qz), __dsub_rn(qz, (double)b[5])), 0.0);
-  return __dadd_rn(__dadd_rn(__dmul_rn(g0, g0), __dmul_rn(g1, g1)), __dmul_rn(g2, g2));
 }
 
 // keeps the running (d2, index) minimum AND `second` = the smallest d2 among all other scanned candidates
@@ -549,30 +540,9 @@ int build_grid(mvicp_ctx* c, FrameDev& f, const double* xyz) {
     table[s] = r;
   }
 
-  // implicit complete AABB tree over the sorted array
-  int D = 0;
-  while (((long long)n + 7) / 8 > (1ll << D)) ++D;
-  if (D > MAXD - 1) { set_error("cloud too large for the NN tree (n=%d)", n); return MVICP_ERR_ARG; }
-  const size_t nodes = (1ull << (D + 1)) - 1;
-  std::vector<float> bvh(6 * nodes);
   const float finf = std::numeric_limits<float>::infinity();
   auto down = [](double v) { float f = (float)v; if ((double)f > v) f = std::nextafterf(f, -std::numeric_limits<float>::infinity()); return f; };
   auto up = [](double v) { float f = (float)v; if ((double)f < v) f = std::nextafterf(f, std::numeric_limits<float>::infinity()); return f; };
-  const size_t leaf0 = (1ull << D) - 1;
-  for (long long j = 0; j < (1ll << D); ++j) {
-    const int a = (int)((j * n) >> D), b = (int)(((j + 1) * n) >> D);
-    float* bx = &bvh[6 * (leaf0 + (size_t)j)];
-    bx[0] = bx[1] = bx[2] = finf; bx[3] = bx[4] = bx[5] = -finf;  // empty leaf: lb = +inf, never visited
-    for (int k = a; k < b; ++k)
-      for (int ax = 0; ax < 3; ++ax) { bx[ax] = std::min(bx[ax], down(spts[3 * (size_t)k + ax])); bx[3 + ax] = std::max(bx[3 + ax], up(spts[3 * (size_t)k + ax])); }
-  }
-  for (long long id = (long long)leaf0 - 1; id >= 0; --id) {
-    const float* l = &bvh[6 * (size_t)(2 * id + 1)];
-    const float* r = &bvh[6 * (size_t)(2 * id + 2)];
-    float* bx = &bvh[6 * (size_t)id];
-    for (int ax = 0; ax < 3; ++ax) { bx[ax] = std::min(l[ax], r[ax]); bx[3 + ax] = std::max(l[3 + ax], r[3 + ax]); }
-  }
-
   // implicit complete 8-ary box tree over the sorted array (phase 2 of the grid kernel): 32-B boxes {lo.xyz, hi.xyz, pad}
   int D8 = 0;
   while ((1ll << (3 * (D8 + 1))) <= (long long)n / 6) ++D8;
@@ -604,7 +574,7 @@ int build_grid(mvicp_ctx* c, FrameDev& f, const double* xyz) {
   G.origin[0] = g.o[0]; G.origin[1] = g.o[1]; G.origin[2] = g.o[2];
   G.cell = g.h; G.inv_cell = g.inv_h;
   G.n_cells = (int)runs.size();
-  G.table_mask = mask; G.table_shift = shift; G.depth = D;
+  G.table_mask = mask; G.table_shift = shift;
   {
     std::vector<PointRec> rec(n);
     for (int i = 0; i < n; ++i) { rec[i].x = spts[3 * (size_t)i]; rec[i].y = spts[3 * (size_t)i + 1]; rec[i].z = spts[3 * (size_t)i + 2]; rec[i].idx = order[i]; }
@@ -614,7 +584,6 @@ int build_grid(mvicp_ctx* c, FrameDev& f, const double* xyz) {
   MV_HIP(hipMalloc((void**)&G.spts, sizeof(double) * 3 * (size_t)n));
   MV_HIP(hipMalloc((void**)&G.sidx, sizeof(int) * (size_t)n));
   MV_HIP(hipMalloc((void**)&G.table, sizeof(HashEntry) * (size_t)tsize));
-  MV_HIP(hipMalloc((void**)&G.bvh, sizeof(float) * 6 * nodes));
   MV_HIP(hipMemcpy(G.spts, spts.data(), sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice));
   MV_HIP(hipMemcpy(G.sidx, order.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
   G.h_order = order;
@@ -623,8 +592,7 @@ int build_grid(mvicp_ctx* c, FrameDev& f, const double* xyz) {
   MV_HIP(hipMalloc((void**)&G.inv, sizeof(int) * (size_t)std::max(n, 1)));
   MV_HIP(hipMemcpy(G.inv, G.h_inv.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
   MV_HIP(hipMemcpy(G.table, table.data(), sizeof(HashEntry) * (size_t)tsize, hipMemcpyHostToDevice));
-  MV_HIP(hipMemcpy(G.bvh, bvh.data(), sizeof(float) * 6 * nodes, hipMemcpyHostToDevice));
-  G.struct_bytes = sizeof(HashEntry) * (double)tsize + sizeof(float) * 6.0 * nodes;
+  G.struct_bytes = sizeof(HashEntry) * (double)tsize + sizeof(float) * 8.0 * nodes8;
   MV_CHECK(build_wide(f, spts.data()));
   f.has_grid = true;
   return MVICP_OK;
@@ -637,7 +605,6 @@ void free_grid(GridDev& g) {
   if (g.snor) (void)hipFree(g.snor);
   if (g.inv) (void)hipFree(g.inv);
   if (g.table) (void)hipFree(g.table);
-  if (g.bvh) (void)hipFree(g.bvh);
   if (g.wide) (void)hipFree(g.wide);
   if (g.oct) (void)hipFree(g.oct);
   g = GridDev();
@@ -651,7 +618,6 @@ GridView view_of(const FrameDev& f) {
   v.table = (const HashEntry*)g.table; v.mask = g.table_mask; v.shift = g.table_shift;
   v.ox = g.origin[0]; v.oy = g.origin[1]; v.oz = g.origin[2]; v.h = g.cell; v.inv_h = g.inv_cell;
   v.dx = g.dims[0]; v.dy = g.dims[1]; v.dz = g.dims[2];
-  v.bvh = g.bvh; v.depth = g.depth;
   v.oct = g.oct; v.oct_depth = g.oct_depth; v.oct_first_leaf = g.oct_first_leaf;
   return v;
 }

@@ -495,3 +495,40 @@ def test_empty_edges_and_tiny_cutoff(eng, orc):
     P, sm = eng.optimize(pb["init"], pb["fixed"])
     # (poses round-trip through the parameterization like the reference's, icp-ceres.cpp:405-420,472-474: equal to rounding)
     assert np.allclose(P, pb["init"], rtol=0, atol=1e-15) and sm["final_cost"] == 0.0 and sm["iterations"] == 0
+
+
+def test_full_size_properties_cfg4():
+    """BASELINE config 4 size (32 views x 200k points, 62 edges): size-independent properties of the whole round —
+    (1) a second search at the same poses (temporal cache + list reuse engaged) returns exactly the first result;
+    (2) rank-0-of-2 + rank-1-of-2 shards sum bit-exactly to the unsharded per-edge blocks and counts;
+    (3) moving every pose by one common rigid transform changes neither the correspondences nor the blocks beyond rounding;
+    (4) lists are strictly ascending in the source index and the counts checksum matches."""
+    pb = synth.make_problem(32, 200_000)
+    full = mvicp.Engine(0)
+    full.set_frames(pb["pts"], pb["nor"]); full.set_graph(pb["src"], pb["dst"])
+    c1, w1 = full.correspond(pb["gt"], pb["fixed"], 0.05)
+    b1 = full.linearize(pb["gt"], 1, 1)
+    l1 = [full.get_correspondences(e) for e in (0, 17, 61)]
+    c2, w2 = full.correspond(pb["gt"], pb["fixed"], 0.05)          # cache hits everywhere, lists reused
+    b2 = full.linearize(pb["gt"], 1, 1)
+    l2 = [full.get_correspondences(e) for e in (0, 17, 61)]
+    assert np.array_equal(c1, c2) and np.array_equal(w1, w2) and np.array_equal(b1, b2)
+    for a, b in zip(l1, l2):
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)) and np.all(np.diff(a[0]) > 0)
+    assert int(c1.sum()) == sum(len(pb["pts"][s]) for s in pb["src"])  # cutoff 5 cm: every query finds a partner on this scene
+    T = np.eye(4); T[:3, :3] = synth.so3_exp(np.array([-0.4, 0.1, 0.25])); T[:3, 3] = [0.05, -0.2, 0.3]
+    moved = np.array([T @ P for P in pb["gt"]])
+    c3, w3 = full.correspond(moved, pb["fixed"], 0.05)
+    same = [np.array_equal(full.get_correspondences(e)[1], l1[k][1]) for k, e in enumerate((0, 17, 61))]
+    assert np.array_equal(c3, c1) and all(same)  # (the query map changes by rounding only: neighbours are identical here)
+    b3 = full.linearize(moved, 1, 1)
+    assert np.allclose(b3, b1, rtol=1e-8, atol=1e-12 * np.abs(b1[:, :78]).max())
+    full.close()
+    parts, counts = [], []
+    for r in range(2):
+        e = mvicp.Engine(0, rank=r, world=2)
+        e.set_frames(pb["pts"], pb["nor"]); e.set_graph(pb["src"], pb["dst"])
+        c, w = e.correspond(pb["gt"], pb["fixed"], 0.05)
+        parts.append(e.linearize(pb["gt"], 1, 1)); counts.append(c)
+        e.close()
+    assert np.array_equal(parts[0] + parts[1], b1) and np.array_equal(counts[0] + counts[1], c1)
