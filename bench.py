@@ -106,6 +106,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("MVICP_FORCE_DEVICE") is not None:   # debugging aid: several ranks on one GPU
+        local = int(os.environ["MVICP_FORCE_DEVICE"])
     if world != args.gpus and world > 1:
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU: the product path has no CPU fallback"
@@ -129,7 +131,26 @@ def main():
         if rank == 0:
             uid.copy_(torch.frombuffer(bytearray(mvicp.Engine.comm_unique_id(rccl)), dtype=torch.uint8))
         dist.broadcast(uid, 0)
-        eng.comm_init(bytes(uid.cpu().numpy().tobytes()), rccl)
+        try:
+            eng.comm_init(bytes(uid.cpu().numpy().tobytes()), rccl)
+            ok = torch.ones(1, device="cuda")
+        except Exception as ex:  # keep the run alive: host-staged exchange over gloo (slower, same results)
+            print(f"[bench] rank {rank}: RCCL communicator unavailable ({ex}); falling back to the host-staged all-reduce", file=sys.stderr)
+            ok = torch.zeros(1, device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        exchange = "rccl all-reduce of per-edge blocks"
+        if ok.item() == 0:
+            gloo = dist.new_group(backend="gloo")
+
+            def _host_allreduce(a):
+                t = torch.from_numpy(a)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=gloo)
+
+            eng.lib.mvicp_comm_init  # (communicator, if any, is simply not used)
+            eng.comm_set_callback(_host_allreduce)
+            exchange = "host-staged gloo all-reduce (RCCL init failed)"
+    if world == 1:
+        exchange = "none"
     method = {"auto": L.NN_AUTO, "brute": L.NN_BRUTE, "grid": L.NN_GRID, "tile": L.NN_TILE}[args.nn]
 
     poses = pb["init"].copy()
@@ -206,7 +227,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "views": K, "pts_per_view": N, "edges": int(eng.E), "cutoff": 0.05, "knn": 2, "robust": True,
-                       "parallelism": f"edge-sharded x{world}" if world > 1 else "single GPU", "nn": args.nn},
+                       "parallelism": f"edge-sharded x{world}, {exchange}" if world > 1 else "single GPU", "nn": args.nn},
             "roofline": roof(dominant), "roofline_nn": roof("nn"), "roofline_linearize": roof("linearize"),
             "phase_ms_per_step": {"correspond": float(np.mean([l["nn_ms"] for l in log])), "optimize": float(np.mean([l["lm_ms"] for l in log])),
                                   "lm_iterations": float(np.mean([l["lm_iters"] for l in log])), "device_evaluations": float(np.mean([l["evals"] for l in log])),

@@ -86,6 +86,12 @@ int mvicp_edge_owner(int n_edges, const int* n_src, int world, int* owner);
 int mvicp_comm_unique_id(const char* librccl_path, void* unique_id_128);
 int mvicp_comm_init(mvicp_ctx* ctx, const char* librccl_path, const void* unique_id_128, int rank, int world);
 
+/* Alternative exchange without RCCL: the launcher supplies an in-place sum all-reduce over HOST doubles (e.g. MPI or
+ * torch.distributed/gloo); the library stages the per-edge blocks through host memory.  Same sharding, same exactness;
+ * meant for bring-up and for testing the N > 1 path where RCCL cannot run (several ranks on one GPU). */
+typedef int (*mvicp_allreduce_fn)(void* user, double* host_buf, size_t n);
+int mvicp_comm_set_callback(mvicp_ctx* ctx, mvicp_allreduce_fn fn, void* user);
+
 /* ---- S1: correspondence search ----------------------------------------------------------------
  * Replaces, for ALL non-fixed frames at once, Frame::computeClosestPointsToNeighbours(frames, thresh)
  * (include/frame.h:54, src/internal/frame.cpp:91-185; caller main_multiview.cpp:119-127).

@@ -194,7 +194,7 @@ int evaluate_blocks(mvicp_ctx* c, const double* poses, int plane, int robust, do
   MV_CHECK(upload_rel(c, poses));
   MV_CHECK(launch_linearize(c, plane, robust));
   const size_t n = (size_t)c->E * MVICP_EDGE_BLOCK;
-  if (c->comm) MV_CHECK(comm_allreduce_sum(c, c->d_out, n));
+  if (c->comm || c->ar_fn) MV_CHECK(comm_allreduce_sum(c, c->d_out, n));
   double* h = c->h_pin + (size_t)c->E * (kEdgeXf + kEdgeRel);  // blocks region
   MV_HIP(hipMemcpyAsync(h, c->d_out, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
   MV_HIP(hipStreamSynchronize(c->stream));
@@ -523,7 +523,7 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   std::vector<double> pack(2 * (size_t)E, 0.0);
   for (int e = 0; e < E; ++e)
     if (c->owned[e]) { pack[2 * e] = c->active[e] ? hc[e] : 0; pack[2 * e + 1] = (c->active[e] && hc[e] > 0) ? hm[e] : 0.0; }
-  if (c->comm) MV_CHECK(comm_allreduce_host(c, pack.data(), pack.size()));
+  if (c->comm || c->ar_fn) MV_CHECK(comm_allreduce_host(c, pack.data(), pack.size()));
   double* ha = pin_misc + 4 * (size_t)E;   // own region: the async copy below is not waited for
   for (int e = 0; e < E; ++e) {
     c->h_count[e] = (int)pack[2 * e];

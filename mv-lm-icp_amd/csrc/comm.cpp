@@ -78,6 +78,16 @@ void comm_destroy(mvicp_ctx* c) {
 }
 
 int comm_allreduce_sum(mvicp_ctx* c, double* d_buf, size_t n) {
+  if (!c->comm && c->ar_fn) {
+    // host-staged exchange through the launcher's callback (e.g. gloo): device -> host -> all-reduce -> device
+    c->ar_host.resize(n);
+    MV_HIP(hipMemcpyAsync(c->ar_host.data(), d_buf, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    MV_HIP(hipStreamSynchronize(c->stream));
+    if (c->ar_fn(c->ar_user, c->ar_host.data(), n) != 0) { set_error("all-reduce callback failed"); return MVICP_ERR_COMM; }
+    MV_HIP(hipMemcpyAsync(d_buf, c->ar_host.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    MV_HIP(hipStreamSynchronize(c->stream));
+    return MVICP_OK;
+  }
   if (!c->comm) return MVICP_OK;
   const int r = c->rccl->AllReduce(d_buf, d_buf, n, /*ncclFloat64*/ 8, /*ncclSum*/ 0, c->comm, c->stream);
   if (r != 0) { set_error("ncclAllReduce: %s", errstr(c->rccl, r)); return MVICP_ERR_COMM; }
@@ -85,6 +95,10 @@ int comm_allreduce_sum(mvicp_ctx* c, double* d_buf, size_t n) {
 }
 
 int comm_allreduce_host(mvicp_ctx* c, double* h_buf, size_t n) {
+  if (!c->comm && c->ar_fn) {
+    if (c->ar_fn(c->ar_user, h_buf, n) != 0) { set_error("all-reduce callback failed"); return MVICP_ERR_COMM; }
+    return MVICP_OK;
+  }
   if (!c->comm) return MVICP_OK;
   RcclApi* a = c->rccl;
   if (a->small_n < n) {
@@ -106,6 +120,11 @@ extern "C" {
 int mvicp_comm_unique_id(const char* librccl_path, void* unique_id_128) {
   if (!unique_id_128) { set_error("null id"); return MVICP_ERR_ARG; }
   return comm_unique_id(librccl_path, unique_id_128);
+}
+int mvicp_comm_set_callback(mvicp_ctx* c, mvicp_allreduce_fn fn, void* user) {
+  if (!c) { set_error("null context"); return MVICP_ERR_ARG; }
+  c->ar_fn = fn; c->ar_user = user;
+  return MVICP_OK;
 }
 int mvicp_comm_init(mvicp_ctx* c, const char* librccl_path, const void* unique_id_128, int rank, int world) {
   if (!c || !unique_id_128) { set_error("null argument"); return MVICP_ERR_ARG; }

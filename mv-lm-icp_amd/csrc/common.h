@@ -153,6 +153,8 @@ struct mvicp_ctx {
   // comm
   mvicp::RcclApi* rccl = nullptr;
   void* comm = nullptr;
+  mvicp_allreduce_fn ar_fn = nullptr; void* ar_user = nullptr;   // host-staged all-reduce supplied by the launcher (no RCCL)
+  std::vector<double> ar_host;
 
   // options / NN census (profiling only)
   bool list_reuse = true;          // skip compaction + gather for edges whose list did not change

@@ -13,7 +13,7 @@ EDGE_BLOCK = 91
 
 SYMBOLS = [
     "mvicp_last_error", "mvicp_version", "mvicp_create", "mvicp_destroy", "mvicp_set_num_frames", "mvicp_set_frame",
-    "mvicp_recompute_normals", "mvicp_set_graph", "mvicp_set_shard", "mvicp_edge_owner", "mvicp_comm_unique_id", "mvicp_comm_init", "mvicp_correspond",
+    "mvicp_recompute_normals", "mvicp_set_graph", "mvicp_set_shard", "mvicp_edge_owner", "mvicp_comm_unique_id", "mvicp_comm_init", "mvicp_comm_set_callback", "mvicp_correspond",
     "mvicp_get_correspondences", "mvicp_set_correspondences", "mvicp_nn_query", "mvicp_linearize", "mvicp_optimize",
     "mvicp_lm_solve", "mvicp_set_option", "mvicp_nn_census", "mvicp_profile_enable", "mvicp_profile_reset", "mvicp_profile_get", "mvicp_stream", "mvicp_sync",
 ]
@@ -31,6 +31,7 @@ class Summary(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_t)
 EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double))
 
 _lib = None
@@ -58,6 +59,7 @@ def load_library(path=None):
     lib.mvicp_edge_owner.argtypes = [C.c_int, ip, C.c_int, ip]
     lib.mvicp_comm_unique_id.argtypes = [C.c_char_p, vp]
     lib.mvicp_comm_init.argtypes = [vp, C.c_char_p, vp, C.c_int, C.c_int]
+    lib.mvicp_comm_set_callback.argtypes = [vp, ALLREDUCE_FN, vp]
     lib.mvicp_correspond.argtypes = [vp, dp, u8p, C.c_float, C.c_int, ip, fp]
     lib.mvicp_get_correspondences.argtypes = [vp, C.c_int, C.c_int, ip, ip, dp]
     lib.mvicp_set_correspondences.argtypes = [vp, C.c_int, C.c_int, ip, ip, C.c_float]
@@ -192,6 +194,17 @@ class Engine:
         buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
         path = librccl_path.encode() if librccl_path else None
         _check(self.lib, self.lib.mvicp_comm_init(self.h, path, C.cast(buf, C.c_void_p), self.rank, self.world))
+
+    def comm_set_callback(self, allreduce):
+        """allreduce(numpy float64 array) must sum it in place over all ranks (host-staged exchange, no RCCL)."""
+        def _cb(_user, ptr, n):
+            try:
+                allreduce(np.ctypeslib.as_array(ptr, shape=(n,)))
+                return 0
+            except Exception:
+                return -1
+        self._ar_cb = ALLREDUCE_FN(_cb)   # keep alive
+        _check(self.lib, self.lib.mvicp_comm_set_callback(self.h, self._ar_cb, None))
 
     @staticmethod
     def comm_unique_id(librccl_path=None):
