@@ -146,7 +146,6 @@ def main():
                 t = torch.from_numpy(a)
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=gloo)
 
-            eng.lib.mvicp_comm_init  # (communicator, if any, is simply not used)
             eng.comm_set_callback(_host_allreduce)
             exchange = "host-staged gloo all-reduce (RCCL init failed)"
     if world == 1:

@@ -78,7 +78,7 @@ void comm_destroy(mvicp_ctx* c) {
 }
 
 int comm_allreduce_sum(mvicp_ctx* c, double* d_buf, size_t n) {
-  if (!c->comm && c->ar_fn) {
+  if (c->ar_fn) {   // an explicit callback overrides the RCCL communicator
     // host-staged exchange through the launcher's callback (e.g. gloo): device -> host -> all-reduce -> device
     c->ar_host.resize(n);
     MV_HIP(hipMemcpyAsync(c->ar_host.data(), d_buf, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
@@ -95,7 +95,7 @@ int comm_allreduce_sum(mvicp_ctx* c, double* d_buf, size_t n) {
 }
 
 int comm_allreduce_host(mvicp_ctx* c, double* h_buf, size_t n) {
-  if (!c->comm && c->ar_fn) {
+  if (c->ar_fn) {
     if (c->ar_fn(c->ar_user, h_buf, n) != 0) { set_error("all-reduce callback failed"); return MVICP_ERR_COMM; }
     return MVICP_OK;
   }
