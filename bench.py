@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--nn", default="auto", choices=["auto", "brute", "grid", "tile"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--grid-target", type=float, default=None)
+    ap.add_argument("--opt", action="append", default=[], help="library option name=value (mvicp_set_option), repeatable; tuning / A-B runs")
     args = ap.parse_args()
 
     import torch
@@ -122,6 +123,9 @@ def main():
     eng = mvicp.Engine(local, rank, world)
     if args.grid_target:
         eng.set_option("grid_target", args.grid_target)
+    for kv in args.opt:
+        name, val = kv.split("=")
+        eng.set_option(name, float(val))
     eng.set_frames(pb["pts"], pb["nor"])
     eng.set_graph(pb["src"], pb["dst"])
     if world > 1:

@@ -144,7 +144,10 @@ int mvicp_lm_solve(int n_frames, int n_edges, const int* src, const int* dst, do
  * "grid_target" (points per occupied hash cell the cell-edge heuristic aims at; set before mvicp_set_frame).
  * "nn_cache" (0/1, default 1): temporal cache of the grid kernel — a query whose previous neighbour is provably still
  * nearest after the pose update skips the search (results are bit-identical either way).
- * "nn_census" (0/1): count candidates / boxes / cache hits per launch while profiling (feeds the algorithmic-byte model). */
+ * "nn_census" (0/1): count candidates / boxes / cache hits per launch while profiling (feeds the algorithmic-byte model).
+ * "spin_wait" (0/1, default 0): poll the stream for up to 2 ms before blocking on the per-evaluation / per-round waits.
+ * "tile_seed" (0/1, default 1): the tile kernel starts from last round's neighbours; "tile_waves" (4..8, default 8):
+ * occupancy variant of the tile kernel.  Tuning knobs: results are bit-identical for every setting. */
 int mvicp_set_option(mvicp_ctx* ctx, const char* name, double value);
 /* NN census accumulated while profiling and the "nn_census" option are on: out[0..4] = queries, candidate points
  * examined, tree boxes tested, queries that needed the tree fallback, queries answered by the temporal cache. */

@@ -115,13 +115,16 @@ template <typename T> void dev_free(T*& p) {
 }
 
 void free_graph(mvicp_ctx* c) {
-  dev_free(c->d_esrc); dev_free(c->d_edst); dev_free(c->d_cap_off); dev_free(c->d_nsrc); dev_free(c->d_count); dev_free(c->d_a);
-  dev_free(c->d_xf); dev_free(c->d_rel); dev_free(c->d_nn_idx); dev_free(c->d_nn_d2); dev_free(c->d_nn_lb); dev_free(c->d_first); dev_free(c->d_second);
-  dev_free(c->d_cd2); dev_free(c->d_qpos); dev_free(c->d_dirty); dev_free(c->d_dirty_slots); dev_free(c->d_dslot_off); dev_free(c->d_stream); dev_free(c->d_cblock_off); dev_free(c->d_cblock_cnt); if (c->d_sel_state) (void)hipFree(c->d_sel_state);
+  dev_free(c->d_esrc); dev_free(c->d_edst); dev_free(c->d_cap_off); dev_free(c->d_count);
+  dev_free(c->d_ctl); c->d_nsrc = nullptr; c->d_a = nullptr; c->d_xf = nullptr; c->d_rel = nullptr; c->d_dirty = nullptr;
+  dev_free(c->d_nn_idx); dev_free(c->d_nn_d2); dev_free(c->d_nn_lb); dev_free(c->d_first); dev_free(c->d_second);
+  dev_free(c->d_sblock_off); dev_free(c->d_sel_keys1); dev_free(c->d_sel_keys2); c->n_sblocks = 0;
+  dev_free(c->d_cd2); dev_free(c->d_qpos); dev_free(c->d_dirty_slots); dev_free(c->d_dslot_off); dev_free(c->d_stream); dev_free(c->d_cblock_off); dev_free(c->d_cblock_cnt); if (c->d_sel_state) (void)hipFree(c->d_sel_state);
   c->d_sel_state = nullptr; dev_free(c->d_sel_hist); dev_free(c->d_median); dev_free(c->d_chunk_edge); dev_free(c->d_chunk_start);
   dev_free(c->d_chunk_first); dev_free(c->d_partials); dev_free(c->d_out);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
-  c->h_pin = nullptr; c->h_pin_doubles = 0;
+  c->h_pin = nullptr; c->h_pin_doubles = 0; c->d_res_host = nullptr; c->d_blocks_host = nullptr; c->lin_out = nullptr;
+  c->census_pending = false;
   c->E = 0; c->total_cap = 0; c->n_cblocks = 0; c->n_chunks = 0; c->have_corr = false;
 }
 
@@ -157,7 +160,8 @@ int ensure_pin(mvicp_ctx* c, size_t doubles) {
   if (doubles <= c->h_pin_doubles) return MVICP_OK;
   if (c->h_pin) MV_HIP(hipHostFree(c->h_pin));
   c->h_pin = nullptr;
-  MV_HIP(hipHostMalloc((void**)&c->h_pin, sizeof(double) * doubles, hipHostMallocDefault));
+  MV_HIP(hipHostMalloc((void**)&c->h_pin, sizeof(double) * doubles, hipHostMallocMapped));
+  std::memset(c->h_pin, 0, sizeof(double) * doubles);
   c->h_pin_doubles = doubles;
   return MVICP_OK;
 }
@@ -166,7 +170,7 @@ int ensure_pin(mvicp_ctx* c, size_t doubles) {
 
 // Per-edge relative transform for the LM kernels: A = R_d^T R_s, t = R_d^T (t_s - t_d).
 int upload_rel(mvicp_ctx* c, const double* poses) {
-  double* h = c->h_pin + (size_t)c->E * kEdgeXf;  // rel region
+  double* h = c->h_pin + c->ctl_r2_off;  // region 2 of the control block: rel | a (a = SoftLOne scales, set by correspond)
   for (int e = 0; e < c->E; ++e) {
     const double* Ps = poses + 16 * (size_t)c->esrc[e];
     const double* Pd = poses + 16 * (size_t)c->edst[e];
@@ -176,8 +180,46 @@ int upload_rel(mvicp_ctx* c, const double* poses) {
     const double dt[3] = {Ps[12] - Pd[12], Ps[13] - Pd[13], Ps[14] - Pd[14]};
     for (int i = 0; i < 3; ++i) r[9 + i] = Pd[0 + 4 * i] * dt[0] + Pd[1 + 4 * i] * dt[1] + Pd[2 + 4 * i] * dt[2];
   }
-  MV_HIP(hipMemcpyAsync(c->d_rel, h, sizeof(double) * (size_t)c->E * kEdgeRel, hipMemcpyHostToDevice, c->stream));
+  MV_HIP(hipMemcpyAsync(c->d_rel, h, sizeof(double) * c->ctl_r2, hipMemcpyHostToDevice, c->stream));
   return MVICP_OK;
+}
+
+// Wait for the stream.  The hot loop waits ~5 times per ICP round for a few hundred microseconds of GPU work; a blocking
+// wait adds a scheduler wake-up to each, so poll first and only block when the work is long.
+int stream_wait(mvicp_ctx* c) {
+  if (c->spin_wait) {
+    const double t0 = now_ms();
+    for (;;) {
+      const hipError_t q = hipStreamQuery(c->stream);
+      if (q == hipSuccess) return MVICP_OK;
+      if (q != hipErrorNotReady) { set_error("hipStreamQuery -> %s", hipGetErrorString(q)); return MVICP_ERR_HIP; }
+      if (now_ms() - t0 > 2.0) break;
+    }
+  }
+  MV_HIP(hipStreamSynchronize(c->stream));
+  return MVICP_OK;
+}
+
+// NN census (profiling only): the counters of the last NN launch were copied to pinned memory asynchronously; fold them
+// into the "nn" profile entry once the stream has been waited for anyway.
+void census_resolve(mvicp_ctx* c) {
+  if (!c->census_pending) return;
+  c->census_pending = false;
+  const unsigned long long* st = c->h_census;
+  const double nq = c->census_nq;
+  ProfEntry& pe = c->prof["nn"];
+  if (c->census_kind == 2) {
+    // tile kernel, memory side: every opened tile is loaded ONCE per wave (24 B xyz + 4 B index per point) and every tested
+    // box once per wave (24 B); the per-lane distance evaluations (st[2]) are served from LDS.
+    pe.bytes += 28.0 * (double)st[0] + 24.0 * (double)st[1];
+    c->nn_candidates += (double)st[2]; c->nn_nodes += (double)st[1]; c->nn_queries += nq;
+  } else {
+    // cache hit: previous index 4 B + bound 8 B + one 32-B record + bound write 8 B; searched query: 8 hash slots x 16 B + bound
+    // write 8 B; every candidate point examined: one 32-B record; every tree box tested: 32 B
+    const double hits = (double)st[3], searched = nq - hits;
+    pe.bytes += 52.0 * hits + (c->census_kind == 1 ? 8.0 : 136.0) * searched + 32.0 * (double)st[0] + 32.0 * (double)st[1];
+    c->nn_candidates += (double)st[0]; c->nn_nodes += (double)st[1]; c->nn_far += (double)st[2]; c->nn_queries += nq; c->nn_hits += hits;
+  }
 }
 
 // One device evaluation of all per-edge blocks at `poses` -> host `out` (E x 91), all-reduced over ranks.
@@ -192,12 +234,18 @@ int evaluate_blocks(mvicp_ctx* c, const double* poses, int plane, int robust, do
   }
   HostScope hs(c, "host.evaluate");
   MV_CHECK(upload_rel(c, poses));
-  MV_CHECK(launch_linearize(c, plane, robust));
   const size_t n = (size_t)c->E * MVICP_EDGE_BLOCK;
-  if (c->comm || c->ar_fn) MV_CHECK(comm_allreduce_sum(c, c->d_out, n));
-  double* h = c->h_pin + (size_t)c->E * (kEdgeXf + kEdgeRel);  // blocks region
-  MV_HIP(hipMemcpyAsync(h, c->d_out, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
-  MV_HIP(hipStreamSynchronize(c->stream));
+  double* h = c->h_pin + c->pin_blocks_off;
+  if (c->comm || c->ar_fn) {
+    c->lin_out = c->d_out;
+    MV_CHECK(launch_linearize(c, plane, robust));
+    MV_CHECK(comm_allreduce_sum(c, c->d_out, n));
+    MV_HIP(hipMemcpyAsync(h, c->d_out, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  } else {
+    c->lin_out = c->d_blocks_host;   // 8 * 91 * E bytes: the reduce kernel stores them straight into mapped host memory
+    MV_CHECK(launch_linearize(c, plane, robust));
+  }
+  MV_CHECK(stream_wait(c));
   std::memcpy(out, h, sizeof(double) * n);
   return MVICP_OK;
 }
@@ -239,6 +287,7 @@ int mvicp_destroy(mvicp_ctx* c) {
   dev_free(c->d_split_idx); dev_free(c->d_split_d2); dev_free(c->d_scratch);
   for (auto& kv : c->tables) if (kv.second.d) (void)hipFree(kv.second.d);
   if (c->d_census) (void)hipFree(c->d_census);
+  if (c->h_census) (void)hipHostFree(c->h_census);
   if (c->d_far_list) (void)hipFree(c->d_far_list);
   if (c->d_far_count) (void)hipFree(c->d_far_count);
   for (auto& kv : c->prof) {
@@ -382,22 +431,36 @@ int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) {
   c->n_chunks = c->chunk_first[E];
   const size_t cap = (size_t)c->total_cap;
   MV_CHECK(dev_alloc(&c->d_esrc, E)); MV_CHECK(dev_alloc(&c->d_edst, E)); MV_CHECK(dev_alloc(&c->d_cap_off, E + 1));
-  MV_CHECK(dev_alloc(&c->d_nsrc, E)); MV_CHECK(dev_alloc(&c->d_count, E)); MV_CHECK(dev_alloc(&c->d_a, E));
-  MV_CHECK(dev_alloc(&c->d_xf, (size_t)E * kEdgeXf)); MV_CHECK(dev_alloc(&c->d_rel, (size_t)E * kEdgeRel));
+  MV_CHECK(dev_alloc(&c->d_count, E));
+  // control block (see common.h): region 1 = xf | nsrc | dirty, region 2 = rel | a
+  c->ctl_r1 = (size_t)E * kEdgeXf + (size_t)E;                 // 2E ints = E doubles
+  c->ctl_r2_off = (c->ctl_r1 + 1) & ~(size_t)1;                // 16-B aligned
+  c->ctl_r2 = (size_t)E * (kEdgeRel + 1);
+  MV_CHECK(dev_alloc(&c->d_ctl, c->ctl_r2_off + c->ctl_r2));
+  MV_HIP(hipMemset(c->d_ctl, 0, sizeof(double) * std::max<size_t>(c->ctl_r2_off + c->ctl_r2, 1)));
+  c->d_xf = c->d_ctl; c->d_nsrc = reinterpret_cast<int*>(c->d_ctl + (size_t)E * kEdgeXf); c->d_dirty = c->d_nsrc + E;
+  c->d_rel = c->d_ctl + c->ctl_r2_off; c->d_a = c->d_rel + (size_t)E * kEdgeRel;
   MV_CHECK(dev_alloc(&c->d_nn_idx, cap)); MV_CHECK(dev_alloc(&c->d_nn_d2, cap)); MV_CHECK(dev_alloc(&c->d_nn_lb, cap));
-  c->nn_cache_valid = false; c->prev_q.assign((size_t)E * 12, 0.0);
+  c->nn_cache_valid = false; c->prev_q.assign((size_t)E * 12, 0.0); c->nn_cache_edge.assign(E, 0);
   MV_CHECK(dev_alloc(&c->d_first, cap)); MV_CHECK(dev_alloc(&c->d_second, cap)); MV_CHECK(dev_alloc(&c->d_cd2, cap));
   MV_CHECK(dev_alloc(&c->d_stream, 9 * cap));
-  MV_CHECK(dev_alloc(&c->d_qpos, cap)); MV_CHECK(dev_alloc(&c->d_dirty, (size_t)E));
+  MV_CHECK(dev_alloc(&c->d_qpos, cap));
   MV_HIP(hipMemset(c->d_qpos, 0xff, sizeof(int) * std::max<size_t>(cap, 1)));
   c->list_valid.assign(E, 0);
   c->dslot_off.assign(E + 1, 0);
   for (int e = 0; e < E; ++e) c->dslot_off[e + 1] = c->dslot_off[e] + (int)(((c->owned[e] ? c->frames[src[e]].n : 0) + 255) / 256);
   c->n_dslots = c->dslot_off[E];
   MV_CHECK(dev_alloc(&c->d_dirty_slots, (size_t)c->n_dslots)); MV_CHECK(dev_alloc(&c->d_dslot_off, (size_t)E + 1));
+  MV_HIP(hipMemset(c->d_dirty_slots, 0, sizeof(int) * std::max<size_t>((size_t)c->n_dslots, 1)));   // dirty_reduce_kernel re-zeroes what it reads
   MV_HIP(hipMemcpy(c->d_dslot_off, c->dslot_off.data(), sizeof(int) * (E + 1), hipMemcpyHostToDevice));
   MV_CHECK(dev_alloc(&c->d_cblock_off, E + 1)); MV_CHECK(dev_alloc(&c->d_cblock_cnt, (size_t)c->n_cblocks));
-  MV_HIP(hipMalloc(&c->d_sel_state, 16 * 8 * (size_t)std::max(E, 1))); MV_CHECK(dev_alloc(&c->d_sel_hist, (size_t)E * 256 * 8));
+  MV_HIP(hipMalloc(&c->d_sel_state, 16 * 3 * (size_t)std::max(E, 1))); MV_CHECK(dev_alloc(&c->d_sel_hist, (size_t)E * (3 * 2048 + 5)));
+  c->sblock_off.assign(E + 1, 0);
+  for (int e = 0; e < E; ++e) c->sblock_off[e + 1] = c->sblock_off[e] + (int)(((c->owned[e] ? c->frames[src[e]].n : 0) + kSelBlock - 1) / kSelBlock);
+  c->n_sblocks = c->sblock_off[E];
+  MV_CHECK(dev_alloc(&c->d_sblock_off, (size_t)E + 1));
+  MV_HIP(hipMemcpy(c->d_sblock_off, c->sblock_off.data(), sizeof(int) * (E + 1), hipMemcpyHostToDevice));
+  MV_CHECK(dev_alloc(&c->d_sel_keys1, cap)); MV_CHECK(dev_alloc(&c->d_sel_keys2, cap));
   MV_CHECK(dev_alloc(&c->d_median, E));
   MV_CHECK(dev_alloc(&c->d_chunk_edge, (size_t)c->n_chunks)); MV_CHECK(dev_alloc(&c->d_chunk_start, (size_t)c->n_chunks));
   MV_CHECK(dev_alloc(&c->d_chunk_first, E + 1));
@@ -406,8 +469,6 @@ int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) {
     MV_HIP(hipMemcpy(c->d_esrc, src, sizeof(int) * E, hipMemcpyHostToDevice));
     MV_HIP(hipMemcpy(c->d_edst, dst, sizeof(int) * E, hipMemcpyHostToDevice));
     MV_HIP(hipMemset(c->d_count, 0, sizeof(int) * E));
-    MV_HIP(hipMemset(c->d_nsrc, 0, sizeof(int) * E));
-    MV_HIP(hipMemset(c->d_a, 0, sizeof(double) * E));
   }
   MV_HIP(hipMemcpy(c->d_cap_off, c->cap_off.data(), sizeof(long long) * (E + 1), hipMemcpyHostToDevice));
   MV_HIP(hipMemcpy(c->d_cblock_off, c->cblock_off.data(), sizeof(int) * (E + 1), hipMemcpyHostToDevice));
@@ -416,7 +477,19 @@ int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) {
     MV_HIP(hipMemcpy(c->d_chunk_edge, chunk_edge.data(), sizeof(int) * c->n_chunks, hipMemcpyHostToDevice));
     MV_HIP(hipMemcpy(c->d_chunk_start, chunk_start.data(), sizeof(int) * c->n_chunks, hipMemcpyHostToDevice));
   }
-  MV_CHECK(ensure_pin(c, (size_t)E * (kEdgeXf + kEdgeRel + MVICP_EDGE_BLOCK + 8) + 64));  // regions: see pin_* below
+  // pinned, device-mapped staging: control-block mirror | blocks | results | misc
+  c->pin_blocks_off = c->ctl_r2_off + c->ctl_r2;
+  c->pin_res_off = c->pin_blocks_off + (size_t)E * MVICP_EDGE_BLOCK;
+  c->pin_misc_off = c->pin_res_off + 2 * (size_t)E;
+  if (c->h_pin) { MV_HIP(hipHostFree(c->h_pin)); c->h_pin = nullptr; c->h_pin_doubles = 0; }
+  MV_CHECK(ensure_pin(c, c->pin_misc_off + 4 * (size_t)E + 64));
+  {
+    void* dp = nullptr;
+    MV_HIP(hipHostGetDevicePointer(&dp, c->h_pin, 0));
+    c->d_blocks_host = (double*)dp + c->pin_blocks_off;
+    c->d_res_host = (double*)dp + c->pin_res_off;
+  }
+  if (!c->h_census) MV_HIP(hipHostMalloc((void**)&c->h_census, 4 * sizeof(unsigned long long), hipHostMallocDefault));
   return MVICP_OK;
 }
 
@@ -458,12 +531,10 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
     for (int k = 37; k < kEdgeXf; ++k) x[k] = 0.0;
     std::memcpy(pq, Mq, sizeof(Mq));
   }
-  MV_HIP(hipMemcpyAsync(c->d_xf, hx, sizeof(double) * (size_t)E * kEdgeXf, hipMemcpyHostToDevice, c->stream));
-  // pinned regions (doubles): [0, E*kEdgeXf) xf | +E*12 rel | +E*91 blocks | then 8 slices of E: nsrc, dirty, counts, medians, a, ...
-  double* pin_misc = c->h_pin + (size_t)E * (kEdgeXf + kEdgeRel + MVICP_EDGE_BLOCK);
-  int* hn = reinterpret_cast<int*>(pin_misc);
+  // region 1 of the control block (xf | nsrc | dirty) goes up in ONE copy once the dirty flags are known (below)
+  int* hn = reinterpret_cast<int*>(hx + (size_t)E * kEdgeXf);
+  int* hd = hn + E;
   std::memcpy(hn, nsrc.data(), sizeof(int) * E);
-  MV_HIP(hipMemcpyAsync(c->d_nsrc, hn, sizeof(int) * E, hipMemcpyHostToDevice, c->stream));
 
   const double bound = sqrt_bound((double)thresh);
   double t_mark = now_ms();
@@ -493,10 +564,8 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
     std::vector<int> dirty(E, 1);
     if (method == MVICP_NN_GRID && !c->nn_tree_only && !c->nn_skip_far && c->list_reuse)
       for (int e = 0; e < E; ++e) if (c->active[e] && c->list_valid[e]) dirty[e] = 0;
-    int* hd = reinterpret_cast<int*>(pin_misc + E);
     std::memcpy(hd, dirty.data(), sizeof(int) * E);
-    MV_HIP(hipMemcpyAsync(c->d_dirty, hd, sizeof(int) * E, hipMemcpyHostToDevice, c->stream));
-    if (c->n_dslots) MV_HIP(hipMemsetAsync(c->d_dirty_slots, 0, sizeof(int) * (size_t)c->n_dslots, c->stream));
+    MV_HIP(hipMemcpyAsync(c->d_ctl, hx, sizeof(double) * c->ctl_r1, hipMemcpyHostToDevice, c->stream));
   }
   if (method == MVICP_NN_BRUTE) MV_CHECK(launch_nn_brute_edges(c));
   else if (method == MVICP_NN_GRID) MV_CHECK(launch_nn_grid_edges(c, bound));
@@ -513,18 +582,17 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   MV_CHECK(launch_gather_stream(c));
   MV_CHECK(launch_select_median(c));
   mark("host.corr.post_launch");
-  // counts + median d2 back; weight = (float)(1.5 * sqrt(median d2))  (frame.cpp:168-176)
-  int* hc = reinterpret_cast<int*>(pin_misc + 2 * (size_t)E);
-  double* hm = pin_misc + 3 * (size_t)E;
-  MV_HIP(hipMemcpyAsync(hc, c->d_count, sizeof(int) * E, hipMemcpyDeviceToHost, c->stream));
-  MV_HIP(hipMemcpyAsync(hm, c->d_median, sizeof(double) * E, hipMemcpyDeviceToHost, c->stream));
-  MV_HIP(hipStreamSynchronize(c->stream));
+  // (count, median d2) per edge arrive in mapped host memory, written by select_final_kernel;
+  // weight = (float)(1.5 * sqrt(median d2))  (frame.cpp:168-176)
+  MV_CHECK(stream_wait(c));
+  census_resolve(c);
   mark("host.corr.wait");
+  const double* hr = c->h_pin + c->pin_res_off;
   std::vector<double> pack(2 * (size_t)E, 0.0);
   for (int e = 0; e < E; ++e)
-    if (c->owned[e]) { pack[2 * e] = c->active[e] ? hc[e] : 0; pack[2 * e + 1] = (c->active[e] && hc[e] > 0) ? hm[e] : 0.0; }
+    if (c->owned[e] && c->active[e]) { pack[2 * e] = hr[2 * e]; pack[2 * e + 1] = hr[2 * e] > 0 ? hr[2 * e + 1] : 0.0; }
   if (c->comm || c->ar_fn) MV_CHECK(comm_allreduce_host(c, pack.data(), pack.size()));
-  double* ha = pin_misc + 4 * (size_t)E;   // own region: the async copy below is not waited for
+  double* ha = c->h_pin + c->ctl_r2_off + (size_t)E * kEdgeRel;   // `a` slice of region 2: uploaded with rel by the next evaluation
   for (int e = 0; e < E; ++e) {
     c->h_count[e] = (int)pack[2 * e];
     const double nth = std::sqrt(pack[2 * e + 1]);
@@ -533,7 +601,6 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
     if (counts) counts[e] = c->h_count[e];
     if (weights) weights[e] = c->h_weight[e];
   }
-  MV_HIP(hipMemcpyAsync(c->d_a, ha, sizeof(double) * E, hipMemcpyHostToDevice, c->stream));
   c->have_corr = true;
   mark("host.corr.finish");
   if (c->profile) prof_collect(c);
@@ -597,6 +664,7 @@ int mvicp_set_correspondences(mvicp_ctx* c, int edge, int n, const int* first, c
   const double a = (double)weight;
   MV_HIP(hipMemcpy(c->d_count + edge, &n, sizeof(int), hipMemcpyHostToDevice));
   MV_HIP(hipMemcpy(c->d_a + edge, &a, sizeof(double), hipMemcpyHostToDevice));
+  c->h_pin[c->ctl_r2_off + (size_t)c->E * kEdgeRel + edge] = a;   // host mirror: region 2 is re-uploaded by every evaluation
   c->h_count[edge] = n;
   c->h_weight[edge] = weight;
   c->have_corr = true;
@@ -625,6 +693,7 @@ int mvicp_nn_query(mvicp_ctx* c, int frame, const double* queries, int n, int nn
   else { set_error("unknown nn_method %d", nn_method); st = MVICP_ERR_ARG; }
   if (st == MVICP_OK) {
     hipError_t e1 = hipStreamSynchronize(c->stream);
+    if (e1 == hipSuccess) census_resolve(c);
     hipError_t e2 = hipMemcpy(idx, di, sizeof(int) * n, hipMemcpyDeviceToHost);
     hipError_t e3 = hipMemcpy(d2, dd, sizeof(double) * n, hipMemcpyDeviceToHost);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { set_error("nn_query copy-back failed"); st = MVICP_ERR_HIP; }
@@ -652,6 +721,9 @@ int mvicp_set_option(mvicp_ctx* c, const char* name, double value) {
   if (std::strcmp(name, "list_reuse") == 0) { c->list_reuse = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "nn_census") == 0) { c->nn_census = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "nn_skip_far") == 0) { c->nn_skip_far = value != 0.0; return MVICP_OK; }
+  if (std::strcmp(name, "tile_seed") == 0) { c->tile_seed = value != 0.0; return MVICP_OK; }
+  if (std::strcmp(name, "tile_waves") == 0) { c->tile_waves = (int)value; return MVICP_OK; }
+  if (std::strcmp(name, "spin_wait") == 0) { c->spin_wait = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "grid_target") == 0) {
     if (!(value >= 0.5 && value <= 64.0)) { set_error("grid_target out of range"); return MVICP_ERR_ARG; }
     c->grid_target = value;

@@ -32,6 +32,7 @@ void set_error(const char* fmt, ...);
 constexpr int kLinPartial = 32;      // doubles per linearize workgroup partial (28 plane / 29 point, padded)
 constexpr int kLinThreads = 256;
 constexpr int kCompactBlock = 1024;  // queries per compaction workgroup
+constexpr int kSelBlock = 4096;      // keys per radix-select workgroup
 constexpr int kEdgeXf = 40;          // Rs(9) ts(3) Rdinv(9) td(3), column-major; [24] = temporal-cache switch (>= 0: on, value =
                                      // rounding allowance in metres), [25..36] = dM (9, col-major) dv (3): change of the query map
                                      // q = M p + v since the last search, so a query moved by exactly |dM p + dv|
@@ -103,7 +104,10 @@ struct mvicp_ctx {
   std::vector<float> h_weight;     // E
   bool have_corr = false;
 
-  // device per-edge tables
+  // device per-edge tables.  d_xf / d_nsrc / d_dirty and d_rel / d_a are views into ONE control block (d_ctl) mirrored in
+  // pinned host memory, so a round costs one upload before the NN stage and one per LM evaluation:
+  //   region 1 (correspond): xf [E x kEdgeXf] | nsrc [E int] | dirty [E int]        region 2 (evaluate): rel [E x kEdgeRel] | a [E]
+  double* d_ctl = nullptr; size_t ctl_r1 = 0, ctl_r2_off = 0, ctl_r2 = 0;   // sizes / offset in doubles
   int* d_esrc = nullptr; int* d_edst = nullptr;
   long long* d_cap_off = nullptr;   // E+1
   int* d_nsrc = nullptr;            // E: N_src if owned and active else 0
@@ -130,6 +134,8 @@ struct mvicp_ctx {
   int* d_cblock_off = nullptr; int* d_cblock_cnt = nullptr;
   // select scratch
   void* d_sel_state = nullptr; unsigned int* d_sel_hist = nullptr; double* d_median = nullptr;
+  int n_sblocks = 0; std::vector<int> sblock_off; int* d_sblock_off = nullptr;   // kSelBlock keys per workgroup
+  double* d_sel_keys1 = nullptr; double* d_sel_keys2 = nullptr;                  // compact key buffers of passes B and C (total_cap each)
   // linearize chunks
   int lin_chunk_override = 0;
   int lin_chunk = 4096;             // correspondences per linearize workgroup (chosen from the GLOBAL problem size)
@@ -138,8 +144,15 @@ struct mvicp_ctx {
   int* d_chunk_edge = nullptr; int* d_chunk_start = nullptr; int* d_chunk_first = nullptr;
   double* d_partials = nullptr;     // n_chunks x kLinPartial
   double* d_out = nullptr;          // E x 91
-  // pinned host staging
+  // pinned (device-mapped) host staging: [control-block mirror | blocks E x 91 | results E x 2 | misc]
   double* h_pin = nullptr; size_t h_pin_doubles = 0;
+  size_t pin_blocks_off = 0, pin_res_off = 0, pin_misc_off = 0;
+  double* d_res_host = nullptr;     // device view of the results region: (count, median d2) per edge, written by select_final_kernel
+  double* d_blocks_host = nullptr;  // device view of the blocks region: single-rank evaluations write the E x 91 blocks straight to the host
+  double* lin_out = nullptr;        // where the next launch_linearize puts the E x 91 blocks (d_out or d_blocks_host)
+  bool spin_wait = false;           // poll the stream instead of a blocking wait (measured: no gain, HIP's own wait already spins)
+  unsigned long long* h_census = nullptr;   // pinned: 4 counters of the last NN launch, resolved after the round's own sync
+  bool census_pending = false; double census_nq = 0; int census_kind = 0;   // kind: 0 grid, 1 tree-only grid, 2 tile
   // brute-force split scratch
   int* d_split_idx = nullptr; double* d_split_d2 = nullptr; size_t split_cap = 0;
 
@@ -162,7 +175,10 @@ struct mvicp_ctx {
   bool nn_census = false;          // count candidates / tree nodes per launch while profiling (small extra cost)
   void* d_census = nullptr; size_t census_bytes = 0;
   void* d_far_list = nullptr; size_t far_cap = 0; unsigned int* d_far_count = nullptr;  // nn_grid far-query list
+  bool far_count_clean = false;    // the last grid launch left the counter zeroed (dirty_reduce_kernel)
   bool nn_skip_far = false;        // PROFILING ONLY: leave unresolved queries unresolved (wrong results)
+  bool tile_seed = true;           // tile kernel starts from last round's neighbours when there are any
+  int tile_waves = 8;              // nn_tile_kernel variant: waves per SIMD it is compiled for (issue-bound kernel: 8 measured best)
   double grid_target = 6.0;        // points per occupied cell the cell-edge heuristic aims at
   double nn_candidates = 0, nn_nodes = 0, nn_far = 0, nn_queries = 0, nn_hits = 0;
 
@@ -187,6 +203,8 @@ int launch_gather_stream(mvicp_ctx* c);
 int launch_select_median(mvicp_ctx* c);
 int launch_linearize(mvicp_ctx* c, int plane, int robust);                            // linearize.hip
 int launch_normals(mvicp_ctx* c, FrameDev& f, int k, int* d_knn);                      // normals.hip
+int stream_wait(mvicp_ctx* c);      // api.cpp: wait for the context's stream (spin-polls first)
+void census_resolve(mvicp_ctx* c);  // api.cpp: fold the counters of the last NN launch into the profile (after a sync)
 
 // small host->device table uploads through a persistent bump-allocated scratch buffer; the copy is a
 // synchronous hipMemcpy (tables are tiny) so the pageable source may die right after the call.

@@ -177,97 +177,181 @@ __global__ __launch_bounds__(NT) void gather_kernel(const int* __restrict__ cblo
   }
 }
 
-// ---- radix select (8 passes x 8 bits, MSB first) over the fp64 patterns of the accepted d2 ------------------------
-// hist is [8 passes][E][256], zeroed once per call.  The digit pick of pass p+1 is recomputed by EVERY workgroup of
-// pass p from that pass's finished histogram (256 bins, trivial) instead of a separate 1-block-per-edge launch per
-// pass: 8 + 1 launches instead of 17, and no latency-bound pick kernels between the streaming passes.
-struct SelState { unsigned long long prefix; int k; };
+// ---- radix select over the fp64 patterns of the accepted d2: 3 streaming passes x 11 bits + an in-LDS finish ------------
+// d2 >= 0, so bit 63 is clear and the unsigned pattern is monotone in the value.  Digits, MSB first:
+//   A = bits 62..52 (the exponent), B = bits 51..41, C = bits 40..30, then 30 low bits resolved by one workgroup per edge.
+// Pass A histograms every key.  Pass B histograms the keys whose exponent is the picked one AND appends them to a
+// compact buffer (10-30 % of the list); pass C reads only that buffer, histograms the keys matching the 22-bit prefix and
+// appends those (a few dozen per edge) to a second buffer, which the finishing workgroup resolves with three 10-bit
+// passes in LDS.  Two full reads of the list instead of eight; every step is exact for any input (all-equal keys just
+// make the compact buffers as long as the list).  The digit of a pass is picked by a one-workgroup-per-edge kernel between
+// the passes (a "last workgroup picks" ticket scheme needs an agent-scope fence per workgroup, which on the 8-XCD part
+// writes back / invalidates L2 and made the select 4x slower).
+constexpr int kSelBins = 2048;
+struct SelState { unsigned long long prefix; int k; int pad; };
 
-// One pick: given the finished histogram of digit `p` (restricted to keys matching st.prefix above it) choose the bin
-// holding rank st.k.  Wave 0 scans 4 bins per lane + a wave prefix sum; result shared through LDS.
-__device__ __forceinline__ SelState select_pick(const unsigned int* __restrict__ hist_pe, int p, SelState st, SelState* sh_state) {
-  if (threadIdx.x < 64) {
-    const int lane = threadIdx.x;
-    const uint4 h = reinterpret_cast<const uint4*>(hist_pe)[lane];
-    const unsigned int tot = h.x + h.y + h.z + h.w;
-    unsigned int inc = tot;
+// Workgroup-wide: which of `nbins` bins (nbins = NT * PER) holds rank k, and how many keys sit in the bins below it.
+// `get(bin)` returns the count of a bin.  All NT threads must call; result valid in every thread.
+template <int PER, typename F>
+__device__ __forceinline__ void pick_bin(F get, unsigned int k, int* __restrict__ wave_tot, int* __restrict__ sh_pick, int& bin, unsigned int& below) {
+  unsigned int h[PER];
+  int mine = 0;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const unsigned int o = __shfl_up(inc, d, 64);
-      if (lane >= d) inc += o;
-    }
-    const unsigned int before = inc - tot;  // keys in bins below this lane's 4
-    const unsigned int k = (unsigned int)st.k;
-    const bool mine = before <= k && k < inc;
-    // if no lane owns rank k (k >= total: cannot happen for k < count) the last bin is taken
-    const unsigned long long owners = __ballot(mine);
-    const int owner = owners ? __ffsll((long long)owners) - 1 : 63;
-    if (lane == owner) {
-      unsigned int cum = before;
-      int bin = 4 * lane + 3;
-      const unsigned int hv[4] = {h.x, h.y, h.z, h.w};
-      unsigned int cb = before;
+  for (int i = 0; i < PER; ++i) { h[i] = get(threadIdx.x * PER + i); mine += (int)h[i]; }
+  int total;
+  const int ex = block_exclusive_scan(mine, wave_tot, &total);
+  if (threadIdx.x == 0) { sh_pick[0] = NT * PER - 1; sh_pick[1] = total; }   // unreachable default (k < total always)
+  __syncthreads();
+  if ((unsigned int)ex <= k && k < (unsigned int)(ex + mine)) {
+    unsigned int cum = (unsigned int)ex;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (cum + hv[i] > k) { bin = 4 * lane + i; cb = cum; break; }
-        cum += hv[i];
-        cb = cum;
-      }
-      if (!owners) cb = before + tot - hv[3];
-      SelState o;
-      o.prefix = st.prefix | ((unsigned long long)bin << (8 * p));
-      o.k = (int)(k - cb);
-      *sh_state = o;
+    for (int i = 0; i < PER; ++i) {
+      if (cum + h[i] > k) { sh_pick[0] = threadIdx.x * PER + i; sh_pick[1] = (int)cum; break; }
+      cum += h[i];
     }
   }
   __syncthreads();
-  return *sh_state;
+  bin = sh_pick[0]; below = (unsigned int)sh_pick[1];
+  __syncthreads();
 }
 
-__global__ __launch_bounds__(NT) void select_hist_kernel(const int* __restrict__ cblock_off, int E, const int* __restrict__ count,
-                                                         const long long* __restrict__ cap_off, const double* __restrict__ cd2, int pass,
-                                                         unsigned int* __restrict__ hist, SelState* __restrict__ state) {
-  __shared__ unsigned int lh[256];
-  __shared__ SelState sh_state;
+// PASS 0: keys = cd2 (count[e]), no filter, no output.   PASS 1: keys = cd2, filter on digit A, output -> out_keys/out_cnt.
+// PASS 2: keys = in_keys (in_cnt[e]), filter on digits A,B, output -> out_keys/out_cnt.
+template <int PASS>
+__global__ __launch_bounds__(NT) void select_pass_kernel(const int* __restrict__ sblock_off, int E, const int* __restrict__ count,
+                                                         const long long* __restrict__ cap_off, const double* __restrict__ in_keys,
+                                                         const unsigned int* __restrict__ in_cnt, unsigned int* __restrict__ hist,
+                                                         const SelState* __restrict__ state,
+                                                         double* __restrict__ out_keys, unsigned int* __restrict__ out_cnt) {
+  constexpr int SPT = kSelBlock / NT;                       // keys per thread
+  constexpr int SHIFT = PASS == 0 ? 52 : PASS == 1 ? 41 : 30;
+  __shared__ unsigned int lh[kSelBins];
+  __shared__ int wave_tot[NT / 64];
+  __shared__ unsigned int sh_base;
   const int b = blockIdx.x;
-  const int e = find_edge(cblock_off, E, b);
-  const int lb = b - cblock_off[e];
+  const int e = find_edge(sblock_off, E, b);
+  const int lb = b - sblock_off[e];
   const int cnt = count[e];
-  if (lb * kCompactBlock >= cnt) return;
-  // state after digit pass+1: start of the chain for pass 7, otherwise one pick on top of the state stored by the previous launch
+  const int n_in = PASS == 2 ? (cnt > 0 ? (int)in_cnt[e] : 0) : cnt;
+  if ((long long)lb * kSelBlock >= n_in) return;
   SelState st;
-  st.prefix = 0ull; st.k = cnt / 2;   // dists.begin() + size()/2  (frame.cpp:166)
-  if (pass < 7) {
-    if (pass < 6) st = state[(size_t)(pass + 2) * E + e];
-    st = select_pick(hist + ((size_t)(pass + 1) * E + e) * 256, pass + 1, st, &sh_state);
-    if (lb == 0 && threadIdx.x == 0) state[(size_t)(pass + 1) * E + e] = st;
-  }
-  lh[threadIdx.x] = 0u;
+  st.prefix = 0ull; st.k = cnt / 2; st.pad = 0;              // dists.begin() + size()/2  (frame.cpp:166)
+  if (PASS > 0) st = state[(size_t)(PASS - 1) * E + e];
+  for (int i = threadIdx.x; i < kSelBins; i += NT) lh[i] = 0u;
   __syncthreads();
   const long long base = cap_off[e];
-  const int shift = 8 * pass;
-  for (int i = 0; i < IPT; ++i) {
-    const int pos = lb * kCompactBlock + i * NT + threadIdx.x;
-    if (pos < cnt) {
-      const unsigned long long key = (unsigned long long)__double_as_longlong(cd2[base + pos]);
-      const bool match = (pass == 7) || ((key >> (shift + 8)) == (st.prefix >> (shift + 8)));
-      if (match) atomicAdd(&lh[(key >> shift) & 255ull], 1u);
+  unsigned long long keys[SPT];
+  int nmatch = 0;
+#pragma unroll
+  for (int i = 0; i < SPT; ++i) {
+    const int pos = lb * kSelBlock + i * NT + threadIdx.x;
+    bool match = pos < n_in;
+    unsigned long long key = 0ull;
+    if (match) {
+      key = (unsigned long long)__double_as_longlong(in_keys[base + pos]);
+      if (PASS > 0) match = (key >> (SHIFT + 11)) == (st.prefix >> (SHIFT + 11));
     }
+    const unsigned int bin = (unsigned int)(key >> SHIFT) & (kSelBins - 1);
+    if (PASS == 0) {
+      // exponent digit: a wave sees a handful of distinct bins -> aggregate equal bins, one LDS atomic per distinct value
+      unsigned long long todo = __ballot(match);
+      const int lane = threadIdx.x & 63;
+      while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const unsigned int lbin = (unsigned int)__builtin_amdgcn_readlane((int)bin, leader);
+        const unsigned long long same = __ballot(match && bin == lbin) & todo;
+        if (lane == leader) atomicAdd(&lh[lbin], (unsigned int)__popcll(same));
+        todo &= ~same;
+      }
+    } else if (match) {
+      atomicAdd(&lh[bin], 1u);
+    }
+    keys[i] = key;
+    if (PASS > 0 && match) { keys[i] |= 1ull << 63; ++nmatch; }   // bit 63 is free (d2 >= 0): mark the keys to keep
+  }
+  if (PASS > 0) {
+    int total;
+    int off = block_exclusive_scan(nmatch, wave_tot, &total);
+    if (threadIdx.x == 0) sh_base = total ? atomicAdd(&out_cnt[e], (unsigned int)total) : 0u;
+    __syncthreads();
+    off += (int)sh_base;
+#pragma unroll
+    for (int i = 0; i < SPT; ++i)
+      if (keys[i] >> 63) out_keys[base + off++] = __longlong_as_double((long long)(keys[i] & ~(1ull << 63)));
   }
   __syncthreads();
-  const unsigned int v = lh[threadIdx.x];
-  if (v) atomicAdd(&hist[((size_t)pass * E + e) * 256 + threadIdx.x], v);
+  for (int i = threadIdx.x; i < kSelBins; i += NT) {
+    const unsigned int v = lh[i];
+    if (v) atomicAdd(&hist[((size_t)PASS * E + e) * kSelBins + i], v);
+  }
 }
 
-__global__ __launch_bounds__(256) void select_final_kernel(const unsigned int* __restrict__ hist, int E, const int* __restrict__ count,
-                                                           const SelState* __restrict__ state, double* __restrict__ median) {
-  __shared__ SelState sh_state;
+// digit pick of pass PASS (0 = A, 1 = B): one workgroup per edge over the finished histogram
+template <int PASS>
+__global__ __launch_bounds__(NT) void select_pick_kernel(int E, const int* __restrict__ count, const unsigned int* __restrict__ hist,
+                                                         SelState* __restrict__ state) {
+  constexpr int SHIFT = PASS == 0 ? 52 : 41;
+  __shared__ int wave_tot[NT / 64];
+  __shared__ int sh_pick[2];
   const int e = blockIdx.x;
   const int cnt = count[e];
-  if (cnt <= 0) { if (threadIdx.x == 0) median[e] = 0.0; return; }
-  SelState st = state[(size_t)1 * E + e];
-  st = select_pick(hist + ((size_t)0 * E + e) * 256, 0, st, &sh_state);
-  if (threadIdx.x == 0) median[e] = __longlong_as_double((long long)st.prefix);
+  if (cnt <= 0) return;
+  SelState st;
+  st.prefix = 0ull; st.k = cnt / 2; st.pad = 0;              // dists.begin() + size()/2  (frame.cpp:166)
+  if (PASS > 0) st = state[(size_t)(PASS - 1) * E + e];
+  const unsigned int* hp = hist + ((size_t)PASS * E + e) * kSelBins;
+  int bin; unsigned int below;
+  pick_bin<kSelBins / NT>([&](int i) { return hp[i]; }, (unsigned int)st.k, wave_tot, sh_pick, bin, below);
+  if (threadIdx.x == 0) {
+    SelState o;
+    o.prefix = st.prefix | ((unsigned long long)bin << SHIFT);
+    o.k = st.k - (int)below; o.pad = 0;
+    state[(size_t)PASS * E + e] = o;
+  }
+}
+
+// one workgroup per edge: pick digit C, then the keys matching the 33-bit prefix (out of the second compact buffer) ->
+// 3 x 10-bit passes in LDS.  Also hands (count, median d2) to the host through the mapped result buffer.
+__global__ __launch_bounds__(NT) void select_final_kernel(int E, const int* __restrict__ count, const long long* __restrict__ cap_off,
+                                                          const double* __restrict__ keys2, const unsigned int* __restrict__ cnt2,
+                                                          const unsigned int* __restrict__ hist, const SelState* __restrict__ state,
+                                                          double* __restrict__ median, double* __restrict__ host_res) {
+  __shared__ unsigned int lh[1024];
+  __shared__ int wave_tot[NT / 64];
+  __shared__ int sh_pick[2];
+  const int e = blockIdx.x;
+  const int cnt = count[e];
+  double med = 0.0;
+  if (cnt > 0) {
+    SelState st = state[(size_t)1 * E + e];
+    {
+      const unsigned int* hp = hist + ((size_t)2 * E + e) * kSelBins;
+      int bin; unsigned int below;
+      pick_bin<kSelBins / NT>([&](int i) { return hp[i]; }, (unsigned int)st.k, wave_tot, sh_pick, bin, below);
+      st.prefix |= (unsigned long long)bin << 30;
+      st.k -= (int)below;
+    }
+    const int n2 = (int)cnt2[e];
+    const long long base = cap_off[e];
+    for (int shift = 20; shift >= 0; shift -= 10) {
+      for (int i = threadIdx.x; i < 1024; i += NT) lh[i] = 0u;
+      __syncthreads();
+      for (int pos = threadIdx.x; pos < n2; pos += NT) {
+        const unsigned long long key = (unsigned long long)__double_as_longlong(keys2[base + pos]);
+        if ((key >> (shift + 10)) == (st.prefix >> (shift + 10))) atomicAdd(&lh[(key >> shift) & 1023ull], 1u);
+      }
+      __syncthreads();
+      int bin; unsigned int below;
+      pick_bin<1024 / NT>([&](int i) { return lh[i]; }, (unsigned int)st.k, wave_tot, sh_pick, bin, below);
+      st.prefix |= (unsigned long long)bin << shift;
+      st.k -= (int)below;
+    }
+    med = __longlong_as_double((long long)st.prefix);
+  }
+  if (threadIdx.x == 0) {
+    median[e] = med;
+    if (host_res) { host_res[2 * e] = (double)(cnt > 0 ? cnt : 0); host_res[2 * e + 1] = med; }
+  }
 }
 
 }  // namespace
@@ -307,16 +391,29 @@ int launch_gather_stream(mvicp_ctx* c) {
 }
 
 int launch_select_median(mvicp_ctx* c) {
-  if (c->n_cblocks == 0 || c->E == 0) return MVICP_OK;
+  if (c->E == 0) return MVICP_OK;
   double bytes = 0;
-  for (int e = 0; e < c->E; ++e) if (c->owned[e]) bytes += 64.0 * c->h_count[e];
+  for (int e = 0; e < c->E; ++e) if (c->owned[e]) bytes += 16.0 * c->h_count[e];   // two full reads of the key list (last round's length)
   ProfScope ps(c, "select", bytes);
-  MV_HIP(hipMemsetAsync(c->d_sel_hist, 0, sizeof(unsigned int) * 8 * (size_t)c->E * 256, c->stream));
-  for (int pass = 7; pass >= 0; --pass)
-    hipLaunchKernelGGL(select_hist_kernel, dim3(c->n_cblocks), dim3(NT), 0, c->stream, c->d_cblock_off, c->E, c->d_count, c->d_cap_off, c->d_cd2,
-                       pass, c->d_sel_hist, (SelState*)c->d_sel_state);
-  hipLaunchKernelGGL(select_final_kernel, dim3(c->E), dim3(256), 0, c->stream, c->d_sel_hist, c->E, c->d_count, (const SelState*)c->d_sel_state,
-                     c->d_median);
+  const size_t E = (size_t)c->E;
+  unsigned int* hist = c->d_sel_hist;                 // [3][E][2048] | cnt1 [E] | cnt2 [E]  (one memset)
+  unsigned int* cnt1 = hist + 3 * E * kSelBins;
+  unsigned int* cnt2 = cnt1 + E;
+  SelState* st = (SelState*)c->d_sel_state;
+  if (c->n_sblocks) {
+    MV_HIP(hipMemsetAsync(hist, 0, sizeof(unsigned int) * (3 * E * kSelBins + 2 * E), c->stream));
+    const dim3 grid(c->n_sblocks), blk(NT);
+    hipLaunchKernelGGL((select_pass_kernel<0>), grid, blk, 0, c->stream, c->d_sblock_off, c->E, c->d_count, c->d_cap_off, c->d_cd2, (const unsigned int*)nullptr,
+                       hist, (const SelState*)st, (double*)nullptr, (unsigned int*)nullptr);
+    hipLaunchKernelGGL((select_pick_kernel<0>), dim3(c->E), blk, 0, c->stream, c->E, c->d_count, (const unsigned int*)hist, st);
+    hipLaunchKernelGGL((select_pass_kernel<1>), grid, blk, 0, c->stream, c->d_sblock_off, c->E, c->d_count, c->d_cap_off, c->d_cd2, (const unsigned int*)nullptr,
+                       hist, (const SelState*)st, c->d_sel_keys1, cnt1);
+    hipLaunchKernelGGL((select_pick_kernel<1>), dim3(c->E), blk, 0, c->stream, c->E, c->d_count, (const unsigned int*)hist, st);
+    hipLaunchKernelGGL((select_pass_kernel<2>), grid, blk, 0, c->stream, c->d_sblock_off, c->E, c->d_count, c->d_cap_off, c->d_sel_keys1, (const unsigned int*)cnt1,
+                       hist, (const SelState*)st, c->d_sel_keys2, cnt2);
+  }
+  hipLaunchKernelGGL(select_final_kernel, dim3(c->E), dim3(NT), 0, c->stream, c->E, c->d_count, c->d_cap_off, c->d_sel_keys2, (const unsigned int*)cnt2,
+                     (const unsigned int*)hist, (const SelState*)st, c->d_median, c->d_res_host);
   MV_HIP(hipGetLastError());
   return MVICP_OK;
 }

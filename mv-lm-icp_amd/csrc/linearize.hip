@@ -322,9 +322,9 @@ int launch_linearize(mvicp_ctx* c, int plane, int robust) {
   {
     ProfScope ps(c, "reduce", 0.0);
     if (plane)
-      hipLaunchKernelGGL((reduce_expand_kernel<true>), dim3(c->E), dim3(256), 0, c->stream, c->d_chunk_first, chunk, c->d_count, c->d_rel, c->d_partials, c->d_out);
+      hipLaunchKernelGGL((reduce_expand_kernel<true>), dim3(c->E), dim3(256), 0, c->stream, c->d_chunk_first, chunk, c->d_count, c->d_rel, c->d_partials, c->lin_out ? c->lin_out : c->d_out);
     else
-      hipLaunchKernelGGL((reduce_expand_kernel<false>), dim3(c->E), dim3(256), 0, c->stream, c->d_chunk_first, chunk, c->d_count, c->d_rel, c->d_partials, c->d_out);
+      hipLaunchKernelGGL((reduce_expand_kernel<false>), dim3(c->E), dim3(256), 0, c->stream, c->d_chunk_first, chunk, c->d_count, c->d_rel, c->d_partials, c->lin_out ? c->lin_out : c->d_out);
   }
   MV_HIP(hipGetLastError());
   return MVICP_OK;

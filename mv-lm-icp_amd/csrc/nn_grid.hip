@@ -137,11 +137,17 @@ __device__ __forceinline__ void update_list(const GridJob& job, int i, int idx_n
   if (!clean) job.dirty_slots[i / NT] = 1;
 }
 
-__global__ void dirty_reduce_kernel(int E, const int* __restrict__ slot_off, const int* __restrict__ slots, int* __restrict__ dirty) {
+// Also leaves the slots and the far-list counter zeroed for the next round (no memsets in the per-round launch sequence).
+__global__ void dirty_reduce_kernel(int E, const int* __restrict__ slot_off, int* __restrict__ slots, int* __restrict__ dirty,
+                                    unsigned int* __restrict__ far_count) {
   const int e = blockIdx.x;
   int any = 0;
-  for (int k = slot_off[e] + threadIdx.x; k < slot_off[e + 1]; k += blockDim.x) any |= slots[k];
+  for (int k = slot_off[e] + threadIdx.x; k < slot_off[e + 1]; k += blockDim.x) {
+    const int v = slots[k];
+    if (v) { any = 1; slots[k] = 0; }
+  }
   if (__syncthreads_or(any) && threadIdx.x == 0) dirty[e] = 1;
+  if (e == 0 && threadIdx.x == 0) *far_count = 0u;   // phase 2 has finished (stream order)
 }
 
 // ---- phase 1: spatial-hash block lookup for every query; queries it cannot prove optimal go to the far list ----
@@ -649,8 +655,14 @@ int run(mvicp_ctx* c, const std::vector<GridJob>& jobs, double bound) {
     MV_HIP(hipMalloc((void**)&c->d_far_list, sizeof(int2) * total_q));
     c->far_cap = total_q;
   }
-  if (!c->d_far_count) MV_HIP(hipMalloc((void**)&c->d_far_count, sizeof(unsigned int)));
-  MV_HIP(hipMemsetAsync(c->d_far_count, 0, sizeof(unsigned int), c->stream));
+  const bool edge_path = jobs[0].dirty_slots != nullptr;   // dirty_reduce_kernel re-zeroes the counter after phase 2
+  if (!c->d_far_count) {
+    MV_HIP(hipMalloc((void**)&c->d_far_count, sizeof(unsigned int)));
+    MV_HIP(hipMemsetAsync(c->d_far_count, 0, sizeof(unsigned int), c->stream));
+  } else if (!edge_path || !c->far_count_clean) {
+    MV_HIP(hipMemsetAsync(c->d_far_count, 0, sizeof(unsigned int), c->stream));
+  }
+  c->far_count_clean = edge_path;
   {
     ProfScope ps(c, "nn", 36.0 * nq);  // query 24 B + result 12 B; the rest comes from the census below (0 if the census is off)
     const dim3 grid((max_n + NT - 1) / NT, (unsigned)jobs.size());
@@ -661,21 +673,16 @@ int run(mvicp_ctx* c, const std::vector<GridJob>& jobs, double bound) {
     // phase 2: persistent grid-stride launch (the far count is only known on the device)
     const unsigned int far_blocks = (unsigned int)std::min<size_t>(256 * 8, (total_q * 8 + NT - 1) / NT);
     hipLaunchKernelGGL(nn_far_kernel, dim3(far_blocks), dim3(NT), 0, c->stream, d_jobs, (const int2*)c->d_far_list, bound, c->d_far_count, d_stats, slots);
-    if (jobs[0].dirty_slots != nullptr)
-      hipLaunchKernelGGL(dirty_reduce_kernel, dim3(c->E), dim3(256), 0, c->stream, c->E, c->d_dslot_off, c->d_dirty_slots, c->d_dirty);
+    if (edge_path)
+      hipLaunchKernelGGL(dirty_reduce_kernel, dim3(c->E), dim3(256), 0, c->stream, c->E, c->d_dslot_off, c->d_dirty_slots, c->d_dirty, c->d_far_count);
   }
   MV_HIP(hipGetLastError());
   if (d_stats) {
-    unsigned long long st[4];
+    if (!c->h_census) MV_HIP(hipHostMalloc((void**)&c->h_census, 4 * sizeof(unsigned long long), hipHostMallocDefault));
+    // counters -> pinned memory, asynchronously; census_resolve() folds them in after the caller's own wait (no extra sync)
     hipLaunchKernelGGL(census_sum_kernel, dim3(64), dim3(256), 0, c->stream, d_stats, slots, d_stats + 4 * slots);
-    MV_HIP(hipMemcpyAsync(st, d_stats + 4 * slots, sizeof(st), hipMemcpyDeviceToHost, c->stream));
-    MV_HIP(hipStreamSynchronize(c->stream));
-    ProfEntry& pe = c->prof["nn"];
-    // cache hit: previous index 4 B + bound 8 B + one 32-B record + bound write 8 B; searched query: 8 hash slots x 16 B + bound
-    // write 8 B; every candidate point examined: one 32-B record; every tree box tested: 32 B
-    const double hits = (double)st[3], searched = nq - hits;
-    pe.bytes += 52.0 * hits + (c->nn_tree_only ? 8.0 : 136.0) * searched + 32.0 * (double)st[0] + 32.0 * (double)st[1];
-    c->nn_candidates += (double)st[0]; c->nn_nodes += (double)st[1]; c->nn_far += (double)st[2]; c->nn_queries += nq; c->nn_hits += hits;
+    MV_HIP(hipMemcpyAsync(c->h_census, d_stats + 4 * slots, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    c->census_pending = true; c->census_nq = nq; c->census_kind = c->nn_tree_only ? 1 : 0;
   }
   return MVICP_OK;
 }

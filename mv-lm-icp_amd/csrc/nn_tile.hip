@@ -32,7 +32,10 @@ namespace mvicp {
 namespace {
 
 constexpr int NT = 256;
-constexpr int LEAF = 32;   // points per leaf tile
+#ifndef MVICP_TILE_LEAF
+#define MVICP_TILE_LEAF 32
+#endif
+constexpr int LEAF = MVICP_TILE_LEAF;   // points per leaf tile (tuning builds may override; 32 measured best)
 constexpr int FAN = 64;    // children per node = one box per lane
 
 struct TileView {
@@ -47,6 +50,7 @@ struct TileJob {
   const double* q; const int* qidx; const double* xf; int n;
   int* out_idx; double* out_d2;
   const int* inv;   // target original index -> sorted position
+  int seed;         // out_idx still holds last round's neighbours (sorted positions, -1 = none): use them as starting candidates
 };
 
 __device__ __forceinline__ void xf_point(const double* __restrict__ x, double p0, double p1, double p2, double& q0, double& q1, double& q2) {
@@ -61,15 +65,38 @@ __device__ __forceinline__ void xf_point(const double* __restrict__ x, double p0
   q2 = __dadd_rn(__dadd_rn(__dmul_rn(x[12 + 2], u[0]), __dmul_rn(x[12 + 5], u[1])), __dmul_rn(x[12 + 8], u[2]));
 }
 
+// Wave-wide reductions on the DPP network (row quad-perm / mirror steps, then row_bcast15 / row_bcast31; lane 63 ends up
+// with the result, broadcast through readlane -> SGPRs).  __shfl_xor would go through ds_bpermute: ~12 LDS-crossbar round
+// trips per fp64 reduction, and this kernel reduces once per traversal step.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false); }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_d(double v) {
+  return __hiloint2double(dpp_i<CTRL, ROW_MASK>(__double2hiint(v)), dpp_i<CTRL, ROW_MASK>(__double2loint(v)));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float v) { return __int_as_float(dpp_i<CTRL, ROW_MASK>(__float_as_int(v))); }
+__device__ __forceinline__ double uniform_d(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+#define MVICP_WAVE_REDUCE(T, DPP, OP, v)                              \
+  v = OP(v, DPP<0xB1, 0xf>(v));  /* quad_perm [1,0,3,2] */           \
+  v = OP(v, DPP<0x4E, 0xf>(v));  /* quad_perm [2,3,0,1] */           \
+  v = OP(v, DPP<0x141, 0xf>(v)); /* row_half_mirror */               \
+  v = OP(v, DPP<0x140, 0xf>(v)); /* row_mirror: every lane = row result */ \
+  v = OP(v, DPP<0x142, 0xa>(v)); /* row_bcast15 -> rows 1, 3 */       \
+  v = OP(v, DPP<0x143, 0xc>(v)); /* row_bcast31 -> rows 2, 3 */
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v = fmax(v, __shfl_xor(v, d, 64));
-  return v;
+  MVICP_WAVE_REDUCE(double, dpp_d, fmax, v)
+  return uniform_d(v, 63);
 }
 __device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v = fmin(v, __shfl_xor(v, d, 64));
-  return v;
+  MVICP_WAVE_REDUCE(double, dpp_d, fmin, v)
+  return uniform_d(v, 63);
+}
+__device__ __forceinline__ float wave_min_f(float v) {
+  MVICP_WAVE_REDUCE(float, dpp_f, fminf, v)
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float bcast(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
@@ -96,41 +123,71 @@ __device__ __forceinline__ double box_lb(const Lane& L, float b0, float b1, floa
 // Scan one leaf tile for the whole wave.  The tile is staged once in LDS as fp64 (exact evaluation) AND fp32
 // (screening): a candidate is evaluated in the reference's fp64 arithmetic only if its fp32 distance is within
 // a rigorous guard band of the lane's running best — |sqrt(d32) - sqrt(d)| <= slack, where `slack` bounds the two
-// float conversions (2^-24 |coord| each, per axis) plus the fp32 rounding of the sum (relative 2^-22).  Everything
-// the screen rejects is provably farther than `best`, so the result is unchanged bit for bit.
-__device__ __forceinline__ void leaf_scan(const TileView& g, int leaf, Lane& L, float slack, double* __restrict__ sx, double* __restrict__ sy,
-                                          double* __restrict__ sz, float4* __restrict__ sf, unsigned long long* n_cand) {
+// float conversions (2^-24 |coord| each, per axis) plus the fp32 rounding of the sum (relative 2^-22; the fused
+// multiply-adds used here round less often than the separate operations the bound was derived for).  Everything the
+// screen rejects is provably farther than `best`, so the result is unchanged bit for bit.
+// The screen is the hot loop of the kernel (VALU-bound): four candidates per step, SoA in LDS so that one 16-B read
+// brings four x (y, z) values, packed fp32 math (v_pk_add/mul/fma: two candidates per instruction), one branch per
+// four candidates; the fp64 confirmation runs only for the lanes / candidates that pass.
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+struct TileLds {   // per wave
+  double x[LEAF], y[LEAF], z[LEAF];
+  float fx[LEAF], fy[LEAF], fz[LEAF];
+  int id[LEAF];
+};
+
+__device__ __forceinline__ void leaf_scan(const TileView& g, int leaf, Lane& L, float slack, TileLds* __restrict__ T, unsigned int* n_cand) {
   const int lane = threadIdx.x & 63;
   const int lo = leaf * LEAF;
   const int cnt = min(LEAF, g.n - lo);
   __builtin_amdgcn_wave_barrier();
-  if (lane < cnt) {
-    const double* p = g.spts + 3 * (size_t)(lo + lane);
-    const double x = p[0], y = p[1], z = p[2];
-    sx[lane] = x; sy[lane] = y; sz[lane] = z;
-    sf[lane] = make_float4((float)x, (float)y, (float)z, __int_as_float(g.sidx[lo + lane]));
+  if (lane < LEAF) {
+    if (lane < cnt) {
+      const double* p = g.spts + 3 * (size_t)(lo + lane);
+      const double x = p[0], y = p[1], z = p[2];
+      T->x[lane] = x; T->y[lane] = y; T->z[lane] = z;
+      T->fx[lane] = (float)x; T->fy[lane] = (float)y; T->fz[lane] = (float)z;
+      T->id[lane] = g.sidx[lo + lane];
+    } else {
+      const float inf = __int_as_float(0x7f800000);
+      T->fx[lane] = inf; T->fy[lane] = inf; T->fz[lane] = inf;   // padded slots never pass a finite screen (and are re-checked below)
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  const float qx = (float)L.qx, qy = (float)L.qy, qz = (float)L.qz;
+  const float qxf = (float)L.qx, qyf = (float)L.qy, qzf = (float)L.qz;
+  const f2v qx2 = {qxf, qxf}, qy2 = {qyf, qyf}, qz2 = {qzf, qzf};
   // screen threshold: (sqrt(best) + slack)^2 with 2^-20 relative head-room, recomputed when best improves
   auto thr_of = [&](double best) {
     const float rb = (float)sqrt(best) * 1.000001f + slack;
     return rb * rb * 1.000002f;
   };
   float thr = thr_of(L.best);
-#pragma unroll 4
-  for (int k = 0; k < cnt; ++k) {
-    const float4 pf = sf[k];
-    const float e0 = qx - pf.x, e1 = qy - pf.y, e2 = qz - pf.z;
-    const float d32 = e0 * e0 + e1 * e1 + e2 * e2;
-    if (d32 <= thr) {
-      const double d0 = __dsub_rn(L.qx, sx[k]), d1 = __dsub_rn(L.qy, sy[k]), d2 = __dsub_rn(L.qz, sz[k]);
-      const double d = __dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2));
-      if (d <= L.best) {
-        const int oi = __float_as_int(pf.w);
-        if (d < L.best || oi < L.bi) { L.best = d; L.bi = oi; thr = thr_of(d); }
+  const float4* X4 = reinterpret_cast<const float4*>(T->fx);
+  const float4* Y4 = reinterpret_cast<const float4*>(T->fy);
+  const float4* Z4 = reinterpret_cast<const float4*>(T->fz);
+#pragma unroll 2
+  for (int k4 = 0; k4 < LEAF / 4; ++k4) {
+    const float4 X = X4[k4], Y = Y4[k4], Z = Z4[k4];
+    const f2v xa = {X.x, X.y}, xb = {X.z, X.w}, ya = {Y.x, Y.y}, yb = {Y.z, Y.w}, za = {Z.x, Z.y}, zb = {Z.z, Z.w};
+    const f2v ea = qx2 - xa, eb = qx2 - xb, fa = qy2 - ya, fb = qy2 - yb, ga = qz2 - za, gb = qz2 - zb;
+    const f2v da = __builtin_elementwise_fma(ga, ga, __builtin_elementwise_fma(fa, fa, ea * ea));
+    const f2v db = __builtin_elementwise_fma(gb, gb, __builtin_elementwise_fma(fb, fb, eb * eb));
+    const unsigned hit = (da.x <= thr ? 1u : 0u) | (da.y <= thr ? 2u : 0u) | (db.x <= thr ? 4u : 0u) | (db.y <= thr ? 8u : 0u);
+    if (hit) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = 4 * k4 + j;
+        if (((hit >> j) & 1u) && k < cnt) {
+          const double d0 = __dsub_rn(L.qx, T->x[k]), d1 = __dsub_rn(L.qy, T->y[k]), d2 = __dsub_rn(L.qz, T->z[k]);
+          const double d = __dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2));
+          if (d <= L.best) {
+            const int oi = T->id[k];
+            if (d < L.best || oi < L.bi) { L.best = d; L.bi = oi; thr = thr_of(d); }
+          }
+        }
       }
     }
   }
@@ -138,9 +195,14 @@ __device__ __forceinline__ void leaf_scan(const TileView& g, int leaf, Lane& L, 
 }
 
 // Test the `nchild` boxes [first, first + nchild) of level LEVEL (one per lane) and open what is needed.
+// Register budget: the traversal recurses (level 2 -> 1 -> 0 -> tile scan) and everything a level keeps across the descent
+// is live in all deeper levels.  Levels 1 and 2 therefore park their 64 child boxes in wave-private LDS (32 B each, read
+// back with one uniform-address load per step) and keep only {cull distance, order key, pending} per lane; level 0, the
+// hot one, keeps its boxes in registers and broadcasts them with v_readlane.
 template <int LEVEL>
-__device__ void visit(const TileView& g, int first, int nchild, Lane& L, const Group& G, double* sx, double* sy, double* sz, float4* si,
-                      unsigned long long* n_cand, unsigned long long* n_box) {
+__device__ void visit(const TileView& g, int first, int nchild, Lane& L, const Group& G, TileLds* __restrict__ T,
+                      float2* __restrict__ sbox, unsigned int* n_cand, unsigned int* n_box) {
+  constexpr bool IN_LDS = LEVEL == 1 || LEVEL == 2;
   const int lane = threadIdx.x & 63;
   const float inf = __int_as_float(0x7f800000);
   float b0 = inf, b1 = inf, b2 = inf, b3 = -inf, b4 = -inf, b5 = -inf;
@@ -150,44 +212,63 @@ __device__ void visit(const TileView& g, int first, int nchild, Lane& L, const G
     b0 = base[0]; b1 = base[st]; b2 = base[2 * st]; b3 = base[3 * st]; b4 = base[4 * st]; b5 = base[5 * st];
   }
   // coarse cull: child box vs the patch AABB; valid for every lane because lb_lane >= box-box distance
-  double dd, key;
+  float ddf, key;
   {
     const double e0 = fmax(fmax((double)b0 - G.hi[0], G.lo[0] - (double)b3), 0.0);
     const double e1 = fmax(fmax((double)b1 - G.hi[1], G.lo[1] - (double)b4), 0.0);
     const double e2 = fmax(fmax((double)b2 - G.hi[2], G.lo[2] - (double)b5), 0.0);
-    dd = (e0 * e0 + e1 * e1 + e2 * e2) * (1.0 - 1e-12);
+    ddf = (float)((e0 * e0 + e1 * e1 + e2 * e2) * (1.0 - 1e-6));   // rounded DOWN (fp32 rounding is 6e-8 relative): still a lower bound
     const double k0 = fmax(fmax((double)b0 - G.c[0], G.c[0] - (double)b3), 0.0);
     const double k1 = fmax(fmax((double)b1 - G.c[1], G.c[1] - (double)b4), 0.0);
     const double k2 = fmax(fmax((double)b2 - G.c[2], G.c[2] - (double)b5), 0.0);
-    key = k0 * k0 + k1 * k1 + k2 * k2;   // visiting order only
+    key = (float)(k0 * k0 + k1 * k1 + k2 * k2);   // visiting order only
+  }
+  float2* mybox = sbox + (IN_LDS ? (LEVEL - 1) * 3 * FAN : 0);   // [axis][child] -> (lo, hi)
+  if (IN_LDS) {
+    __builtin_amdgcn_wave_barrier();
+    mybox[lane] = make_float2(b0, b3);
+    mybox[FAN + lane] = make_float2(b1, b4);
+    mybox[2 * FAN + lane] = make_float2(b2, b5);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   *n_box += (unsigned)nchild;
   bool pend = lane < nchild;
+  // largest running best of the wave: only shrinks, and only when a tile was scanned below -> refreshed after descents
+  double gmax = wave_max(L.active ? L.best : -1.0);
   while (true) {
-    const double gmax = wave_max(L.active ? L.best : -1.0);
-    pend = pend && dd <= gmax;
+    pend = pend && (double)ddf <= gmax;
     const unsigned long long mask = __ballot(pend);
     if (mask == 0ull) break;
-    const double kmin = wave_min(pend ? key : 1.7976931348623157e308);
+    const float kmin = wave_min_f(pend ? key : inf);
     const unsigned long long pick = __ballot(pend && key == kmin);
     const int c = __builtin_amdgcn_readfirstlane(__ffsll((long long)pick) - 1);
     if (lane == c) pend = false;
-    const float c0 = bcast(b0, c), c1 = bcast(b1, c), c2 = bcast(b2, c), c3 = bcast(b3, c), c4 = bcast(b4, c), c5 = bcast(b5, c);
+    float c0, c1, c2, c3, c4, c5;
+    if (IN_LDS) {
+      const float2 u = mybox[c], v = mybox[FAN + c], w = mybox[2 * FAN + c];
+      c0 = u.x; c3 = u.y; c1 = v.x; c4 = v.y; c2 = w.x; c5 = w.y;
+    } else {
+      c0 = bcast(b0, c); c1 = bcast(b1, c); c2 = bcast(b2, c); c3 = bcast(b3, c); c4 = bcast(b4, c); c5 = bcast(b5, c);
+    }
     const double lb = box_lb(L, c0, c1, c2, c3, c4, c5);
     if (__ballot(L.active && lb <= L.best) == 0ull) continue;
     const int child = first + c;
     if (LEVEL == 0) {
-      leaf_scan(g, child, L, G.slack, sx, sy, sz, si, n_cand);
+      leaf_scan(g, child, L, G.slack, T, n_cand);
     } else {
       const int cf = child * FAN;
-      visit<(LEVEL > 0 ? LEVEL - 1 : 0)>(g, cf, min(FAN, g.cnt[LEVEL > 0 ? LEVEL - 1 : 0] - cf), L, G, sx, sy, sz, si, n_cand, n_box);
+      visit<(LEVEL > 0 ? LEVEL - 1 : 0)>(g, cf, min(FAN, g.cnt[LEVEL > 0 ? LEVEL - 1 : 0] - cf), L, G, T, sbox, n_cand, n_box);
     }
+    gmax = wave_max(L.active ? L.best : -1.0);
   }
 }
 
-__global__ __launch_bounds__(NT, 6) void nn_tile_kernel(const TileJob* __restrict__ jobs, double bound, unsigned long long* __restrict__ stats) {
-  __shared__ double s_x[NT / 64][LEAF], s_y[NT / 64][LEAF], s_z[NT / 64][LEAF];
-  __shared__ float4 s_i[NT / 64][LEAF];
+template <int WPE>
+__global__ __launch_bounds__(NT, WPE) void nn_tile_kernel(const TileJob* __restrict__ jobs, double bound, unsigned long long* __restrict__ stats) {
+  __shared__ TileLds s_tile[NT / 64];
+  __shared__ float2 s_box[NT / 64][2 * 3 * FAN];   // levels 1 and 2: 64 child boxes x 24 B each, per wave
   __shared__ double sxf[kEdgeXf];
   const TileJob& job = jobs[blockIdx.y];
   if (blockIdx.x * NT >= job.n) return;
@@ -208,30 +289,42 @@ __global__ __launch_bounds__(NT, 6) void nn_tile_kernel(const TileJob* __restric
     if (has_xf) xf_point(sxf, p0, p1, p2, L.qx, L.qy, L.qz);
     else { L.qx = p0; L.qy = p1; L.qz = p2; }
   }
-  Group G;
+  // Seed: last round's neighbour is an ordinary candidate (any target is), but starting from its distance instead of the
+  // cutoff bound lets the traversal discard almost every tile that does not hold a true neighbour of some lane.
+  if (job.seed && L.active) {
+    const int pi = job.out_idx[i];
+    if (pi >= 0 && pi < g.n) {
+      const double* p = g.spts + 3 * (size_t)pi;
+      const double d0 = __dsub_rn(L.qx, p[0]), d1 = __dsub_rn(L.qy, p[1]), d2 = __dsub_rn(L.qz, p[2]);
+      const double d = __dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2));
+      if (d <= L.best) { L.best = d; L.bi = g.sidx[pi]; }
+    }
+  }
+  Group G;   // wave-uniform: lives in SGPRs
   {
     const double big = 1.7976931348623157e308;
     G.lo[0] = wave_min(L.active ? L.qx : big); G.hi[0] = wave_max(L.active ? L.qx : -big);
     G.lo[1] = wave_min(L.active ? L.qy : big); G.hi[1] = wave_max(L.active ? L.qy : -big);
     G.lo[2] = wave_min(L.active ? L.qz : big); G.hi[2] = wave_max(L.active ? L.qz : -big);
 #pragma unroll
-    for (int a = 0; a < 3; ++a) G.c[a] = 0.5 * (G.lo[a] + G.hi[a]);
+    for (int a = 0; a < 3; ++a) G.c[a] = uniform_d(0.5 * (G.lo[a] + G.hi[a]), 0);
     // largest coordinate magnitude either operand of a difference can have: the patch and the cloud's bounding box
     double m = 0.0;
 #pragma unroll
     for (int a = 0; a < 3; ++a) m = fmax(m, fmax(fmax(fabs(G.lo[a]), fabs(G.hi[a])), g.maxabs));
     // per axis: |fl32(q) - q| + |fl32(p) - p| + rounding of the fp32 subtraction <= 3 * 2^-24 * m; x sqrt(3) axes, x2 safety
-    G.slack = (float)(m * (3.0 * 1.7320508 * 2.0 / 16777216.0)) + 1e-30f;
+    G.slack = bcast((float)(m * (3.0 * 1.7320508 * 2.0 / 16777216.0)) + 1e-30f, 0);
   }
-  unsigned long long n_cand = 0, n_box = 0;
+  unsigned int n_cand = 0, n_box = 0;
   const int top = g.levels - 1;
-  double* sx = s_x[wave]; double* sy = s_y[wave]; double* sz = s_z[wave]; float4* si = s_i[wave];
+  TileLds* T = &s_tile[wave];
+  float2* sbox = s_box[wave];
   switch (top) {
-    case 0: visit<0>(g, 0, g.cnt[0], L, G, sx, sy, sz, si, &n_cand, &n_box); break;
-    case 1: visit<1>(g, 0, g.cnt[1], L, G, sx, sy, sz, si, &n_cand, &n_box); break;
-    case 2: visit<2>(g, 0, g.cnt[2], L, G, sx, sy, sz, si, &n_cand, &n_box); break;
-    case 3: visit<3>(g, 0, g.cnt[3], L, G, sx, sy, sz, si, &n_cand, &n_box); break;
-    default: visit<4>(g, 0, g.cnt[4], L, G, sx, sy, sz, si, &n_cand, &n_box); break;
+    case 0: visit<0>(g, 0, g.cnt[0], L, G, T, sbox, &n_cand, &n_box); break;
+    case 1: visit<1>(g, 0, g.cnt[1], L, G, T, sbox, &n_cand, &n_box); break;
+    case 2: visit<2>(g, 0, g.cnt[2], L, G, T, sbox, &n_cand, &n_box); break;
+    case 3: visit<3>(g, 0, g.cnt[3], L, G, T, sbox, &n_cand, &n_box); break;
+    default: visit<4>(g, 0, g.cnt[4], L, G, T, sbox, &n_cand, &n_box); break;
   }
   if (L.active) {
     const int out = i;   // sorted order of the source cloud
@@ -242,7 +335,7 @@ __global__ __launch_bounds__(NT, 6) void nn_tile_kernel(const TileJob* __restric
     // wave-uniform counters: candidates examined PER LANE x active lanes, boxes tested per wave
     const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + wave;
     const unsigned long long act = (unsigned long long)min(64, job.n - (i & ~63));
-    stats[4 * slot] = n_cand; stats[4 * slot + 1] = n_box; stats[4 * slot + 2] = n_cand * act;
+    stats[4 * slot] = n_cand; stats[4 * slot + 1] = n_box; stats[4 * slot + 2] = (unsigned long long)n_cand * act;
   }
 }
 
@@ -333,6 +426,7 @@ int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound) {
     j.q = s.grid.spts; j.qidx = nullptr; j.xf = c->d_xf + (size_t)e * kEdgeXf; j.n = s.n;
     j.out_idx = c->d_nn_idx + c->cap_off[e]; j.out_d2 = c->d_nn_d2 + c->cap_off[e];
     j.inv = d.grid.inv;
+    j.seed = (c->tile_seed && (int)c->nn_cache_edge.size() == c->E && c->nn_cache_edge[e]) ? 1 : 0;
     jobs.push_back(j);
     max_n = std::max(max_n, s.n);
     nq += s.n;
@@ -354,19 +448,22 @@ int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound) {
   }
   {
     ProfScope ps(c, "nn", 36.0 * nq);  // query read 24 B + result write 12 B; candidate / box bytes come from the census
-    hipLaunchKernelGGL(nn_tile_kernel, dim3((max_n + NT - 1) / NT, (unsigned)jobs.size()), dim3(NT), 0, c->stream, d_jobs, d2_bound, d_stats);
+    const dim3 grid((max_n + NT - 1) / NT, (unsigned)jobs.size());
+    switch (c->tile_waves) {   // waves per SIMD the kernel is compiled for (register budget 512 / n); tuning knob, same results
+      case 4: hipLaunchKernelGGL((nn_tile_kernel<4>), grid, dim3(NT), 0, c->stream, d_jobs, d2_bound, d_stats); break;
+      case 8: hipLaunchKernelGGL((nn_tile_kernel<8>), grid, dim3(NT), 0, c->stream, d_jobs, d2_bound, d_stats); break;
+      case 7: hipLaunchKernelGGL((nn_tile_kernel<7>), grid, dim3(NT), 0, c->stream, d_jobs, d2_bound, d_stats); break;
+      case 5: hipLaunchKernelGGL((nn_tile_kernel<5>), grid, dim3(NT), 0, c->stream, d_jobs, d2_bound, d_stats); break;
+      default: hipLaunchKernelGGL((nn_tile_kernel<6>), grid, dim3(NT), 0, c->stream, d_jobs, d2_bound, d_stats); break;
+    }
   }
   MV_HIP(hipGetLastError());
   if (d_stats) {
-    unsigned long long st[4];
+    if (!c->h_census) MV_HIP(hipHostMalloc((void**)&c->h_census, 4 * sizeof(unsigned long long), hipHostMallocDefault));
+    // counters -> pinned memory, asynchronously; census_resolve() folds them in after the caller's own wait (no extra sync)
     hipLaunchKernelGGL(census_sum_kernel, dim3(64), dim3(256), 0, c->stream, d_stats, slots, d_stats + 4 * slots);
-    MV_HIP(hipMemcpyAsync(st, d_stats + 4 * slots, sizeof(st), hipMemcpyDeviceToHost, c->stream));
-    MV_HIP(hipStreamSynchronize(c->stream));
-    ProfEntry& pe = c->prof["nn"];
-    // memory-side algorithmic bytes: every opened tile is loaded ONCE per wave (24 B xyz + 4 B index per point) and
-    // every tested box once per wave (24 B); the per-lane distance evaluations (st[2]) are served from LDS.
-    pe.bytes += 28.0 * (double)st[0] + 24.0 * (double)st[1];
-    c->nn_candidates += (double)st[2]; c->nn_nodes += (double)st[1]; c->nn_queries += nq;
+    MV_HIP(hipMemcpyAsync(c->h_census, d_stats + 4 * slots, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    c->census_pending = true; c->census_nq = nq; c->census_kind = 2;
   }
   return MVICP_OK;
 }

@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libmvicp_hip.so")
+LIB_PATH = os.environ.get("MVICP_LIB") or os.path.join(os.path.dirname(_HERE), "libmvicp_hip.so")   # MVICP_LIB: tuning builds only
 
 PARAM_EIGEN_QUATERNION, PARAM_ANGLE_AXIS, PARAM_SOPHUS_SE3 = 0, 1, 2
 NN_AUTO, NN_BRUTE, NN_GRID, NN_TILE = 0, 1, 2, 3
