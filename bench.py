@@ -176,8 +176,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    eng.profile(True)
-    eng.set_option("nn_census", 1)  # per-launch candidate / box / cache-hit counts -> algorithmic bytes of every timed NN launch
+    eng.profile(2)   # live HIP-event scopes around the two roofline kernels only ("nn", "linearize"); everything else: replay pass below
     eng.profile_reset()
     log.clear()
     fence()
@@ -191,12 +190,37 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    prof = {k: eng.profile_get(k) for k in ("nn", "compact", "gather", "select", "linearize", "reduce")}
+    timed = {k: eng.profile_get(k) for k in ("nn", "linearize")}
     host = {k: eng.profile_get(k)[0] / args.steps for k in ("host.correspond", "host.corr.setup", "host.corr.nn_launch", "host.corr.post_launch", "host.corr.wait",
                                                             "host.corr.finish", "host.optimize", "host.evaluate")}
+    eng.profile(False)
+    timed_log = list(log)
+    final_poses = poses.copy()
+
+    # Replay pass (UNTIMED): the same rounds again from the same initial poses, now with every profiling scope and the NN
+    # census on (per-launch candidate / box / cache-hit counts = the algorithmic bytes of every NN launch).  The engine is
+    # deterministic, so the replay walks through exactly the same poses and launches as the timed loop (checked below);
+    # keeping the census kernels, their memsets and 20 extra event packets per round out of the timed region.
+    eng.set_graph(pb["src"], pb["dst"])   # forget the NN history (temporal cache, seeds, AUTO state)
+    poses = pb["init"].copy()
+    for _ in range(args.warmup):
+        step()
+    eng.profile(1)
+    eng.set_option("nn_census", 1)
+    eng.profile_reset()
+    for _ in range(args.steps):
+        step()
+    fence()
+    replay = {k: eng.profile_get(k) for k in ("nn", "compact", "gather", "select", "linearize", "reduce")}
     census = eng.nn_census()
     eng.set_option("nn_census", 0)
     eng.profile(False)
+    replay_identical = bool(np.array_equal(poses, final_poses))
+    log[:] = timed_log
+    # time and launch count: live in the timed region; algorithmic bytes: the replay's census
+    prof = dict(replay)
+    prof["nn"] = (timed["nn"][0], timed["nn"][1], replay["nn"][2] if replay["nn"][1] == timed["nn"][1] else float("nan"))
+    prof["linearize"] = timed["linearize"]
 
     def pmc_traffic(name):
         """HBM bytes per launch from the committed rocprofv3 PMC passes of THIS command (tools/profile.sh -> profiles/):
@@ -235,7 +259,9 @@ def main():
             "phase_ms_per_step": {"correspond": float(np.mean([l["nn_ms"] for l in log])), "optimize": float(np.mean([l["lm_ms"] for l in log])),
                                   "lm_iterations": float(np.mean([l["lm_iters"] for l in log])), "device_evaluations": float(np.mean([l["evals"] for l in log])),
                                   "correspondences": float(np.mean([l["corr"] for l in log]))},
-            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
+            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},   # nn, linearize: timed region; the rest: replay pass
+            "replay_pass": {"identical_poses": replay_identical, "nn_ms_per_step": replay["nn"][0] / args.steps,
+                            "note": "untimed re-run of the same rounds with all scopes + NN census on (algorithmic bytes per launch)"},
             "host_ms_per_step": host,
             "nn_census_per_query": {"candidates": census["candidates"] / max(1.0, census["queries"]), "tree_boxes": census["nodes"] / max(1.0, census["queries"]),
                                     "tree_fallback_fraction": census["far"] / max(1.0, census["queries"]),

@@ -146,7 +146,7 @@ int mvicp_lm_solve(int n_frames, int n_edges, const int* src, const int* dst, do
  * nearest after the pose update skips the search (results are bit-identical either way).
  * "nn_census" (0/1): count candidates / boxes / cache hits per launch while profiling (feeds the algorithmic-byte model).
  * "spin_wait" (0/1, default 0): poll the stream for up to 2 ms before blocking on the per-evaluation / per-round waits.
- * "tile_seed" (0/1, default 1): the tile kernel starts from last round's neighbours; "tile_waves" (4..8, default 8):
+ * "tile_seed" (0/1, default 1): the tile kernel starts from last round's neighbours; "tile_waves" (4..8, default 6):
  * occupancy variant of the tile kernel.  Tuning knobs: results are bit-identical for every setting. */
 int mvicp_set_option(mvicp_ctx* ctx, const char* name, double value);
 /* NN census accumulated while profiling and the "nn_census" option are on: out[0..4] = queries, candidate points
@@ -154,6 +154,8 @@ int mvicp_set_option(mvicp_ctx* ctx, const char* name, double value);
 int mvicp_nn_census(mvicp_ctx* ctx, double* out5);
 
 /* ---- profiling (HIP events on the library's own stream) ------------------------------------------ */
+/* on = 0: off; 1: every scope below; 2: only "nn" and "linearize" (fewer event packets between the kernels of a
+ * timed run). */
 int mvicp_profile_enable(mvicp_ctx* ctx, int on);
 int mvicp_profile_reset(mvicp_ctx* ctx);
 /* kernel in {"nn","compact","select","linearize","reduce"}: total ms, launches, algorithmic bytes. */

@@ -58,6 +58,8 @@ int scratch_upload(mvicp_ctx* c, const void* src, size_t bytes, void** dptr) {
 }
 
 ProfScope::ProfScope(mvicp_ctx* ctx, const char* nm, double bytes) : c(ctx), name(nm), on(ctx->profile) {
+  // level 2: only the two roofline scopes (every event pair is two extra queue packets between kernels)
+  if (on && ctx->profile_level >= 2 && std::strcmp(nm, "nn") != 0 && std::strcmp(nm, "linearize") != 0) on = false;
   if (!on) return;
   ProfEntry& pe = c->prof[name];
   auto get = [&]() {
@@ -442,6 +444,7 @@ int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) {
   c->d_rel = c->d_ctl + c->ctl_r2_off; c->d_a = c->d_rel + (size_t)E * kEdgeRel;
   MV_CHECK(dev_alloc(&c->d_nn_idx, cap)); MV_CHECK(dev_alloc(&c->d_nn_d2, cap)); MV_CHECK(dev_alloc(&c->d_nn_lb, cap));
   c->nn_cache_valid = false; c->prev_q.assign((size_t)E * 12, 0.0); c->nn_cache_edge.assign(E, 0);
+  c->auto_prev_dist = 0.0; c->auto_last_method = -1;
   MV_CHECK(dev_alloc(&c->d_first, cap)); MV_CHECK(dev_alloc(&c->d_second, cap)); MV_CHECK(dev_alloc(&c->d_cd2, cap));
   MV_CHECK(dev_alloc(&c->d_stream, 9 * cap));
   MV_CHECK(dev_alloc(&c->d_qpos, cap));
@@ -542,16 +545,24 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   mark("host.corr.setup");
   int method = nn_method;
   if (method == MVICP_NN_AUTO) {
-    // Per-lane hash lookups win once the clouds are aligned to within a fraction of a hash cell; while the typical
-    // NN distance is still comparable to the cell edge (first rounds) nearly every query falls through to the tree
-    // and the wave-cooperative tile kernel is several times faster.  Signal: last round's median distances.
+    // Two exact kernels, two regimes.  While the poses still move by more than the spacing of the points, nearly every
+    // query needs a fresh search and the wave-cooperative tile kernel (seeded with last round's neighbours) is fastest.
+    // Once the registration settles, the hash-grid kernel wins: its temporal cache answers a query whose neighbour provably
+    // did not change with one distance evaluation.  The switch costs one uncached grid round, so it is made when the
+    // median correspondence distance has stopped contracting (last > half of the one before) — or, with a single round
+    // of history, when it is already well inside a hash cell.
     method = MVICP_NN_TILE;
     if (c->have_corr) {
       double dist = 0.0, cell = 0.0;
       int m = 0;
       for (int e = 0; e < E; ++e)
         if (c->h_count[e] > 0) { dist += c->h_weight[e] / 1.5; cell += c->frames[c->edst[e]].grid.cell; ++m; }
-      if (m > 0 && dist < 1.5 * cell) method = MVICP_NN_GRID;  // ICP contracts fast: next round's distances are a fraction of last round's
+      if (m > 0) {
+        dist /= m; cell /= m;
+        const bool settled = c->auto_prev_dist > 0.0 ? dist > c->auto_settle * c->auto_prev_dist : dist < 0.5 * cell;
+        if (dist < 1.5 * cell && (settled || c->auto_last_method == MVICP_NN_GRID)) method = MVICP_NN_GRID;
+        c->auto_prev_dist = dist;
+      }
     }
   }
   if (method == MVICP_NN_GRID || method == MVICP_NN_TILE) {
@@ -574,6 +585,7 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   // only the grid kernel maintains the per-query lower bounds the temporal cache needs; the cutoff must not change either
   c->nn_cache_valid = (method == MVICP_NN_GRID) && !c->nn_tree_only && !c->nn_skip_far;
   c->nn_cache_thresh = thresh;
+  c->auto_last_method = method;
   c->nn_cache_edge.assign(c->active.begin(), c->active.end());
   for (int e = 0; e < E; ++e) c->list_valid[e] = c->active[e];
 
@@ -721,6 +733,7 @@ int mvicp_set_option(mvicp_ctx* c, const char* name, double value) {
   if (std::strcmp(name, "list_reuse") == 0) { c->list_reuse = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "nn_census") == 0) { c->nn_census = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "nn_skip_far") == 0) { c->nn_skip_far = value != 0.0; return MVICP_OK; }
+  if (std::strcmp(name, "auto_settle") == 0) { c->auto_settle = value; return MVICP_OK; }
   if (std::strcmp(name, "tile_seed") == 0) { c->tile_seed = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "tile_waves") == 0) { c->tile_waves = (int)value; return MVICP_OK; }
   if (std::strcmp(name, "spin_wait") == 0) { c->spin_wait = value != 0.0; return MVICP_OK; }
@@ -742,6 +755,7 @@ int mvicp_nn_census(mvicp_ctx* c, double* out4) {
 int mvicp_profile_enable(mvicp_ctx* c, int on) {
   MV_CHECK(bind(c));
   c->profile = on != 0;
+  c->profile_level = on;
   return MVICP_OK;
 }
 int mvicp_profile_reset(mvicp_ctx* c) {

@@ -178,12 +178,13 @@ struct mvicp_ctx {
   bool far_count_clean = false;    // the last grid launch left the counter zeroed (dirty_reduce_kernel)
   bool nn_skip_far = false;        // PROFILING ONLY: leave unresolved queries unresolved (wrong results)
   bool tile_seed = true;           // tile kernel starts from last round's neighbours when there are any
-  int tile_waves = 8;              // nn_tile_kernel variant: waves per SIMD it is compiled for (issue-bound kernel: 8 measured best)
+  int tile_waves = 6;              // nn_tile_kernel variant: waves per SIMD it is compiled for (6 measured best)
+  double auto_prev_dist = 0.0; int auto_last_method = -1; double auto_settle = 0.5;   // MVICP_NN_AUTO policy state (api.cpp)
   double grid_target = 6.0;        // points per occupied cell the cell-edge heuristic aims at
   double nn_candidates = 0, nn_nodes = 0, nn_far = 0, nn_queries = 0, nn_hits = 0;
 
   // profiling
-  bool profile = false;
+  bool profile = false; int profile_level = 0;   // 1: every scope, 2: only "nn" and "linearize"
   std::map<std::string, mvicp::ProfEntry> prof;
 };
 

@@ -94,6 +94,10 @@ __device__ __forceinline__ double wave_min(double v) {
   MVICP_WAVE_REDUCE(double, dpp_d, fmin, v)
   return uniform_d(v, 63);
 }
+__device__ __forceinline__ float wave_max_f(float v) {
+  MVICP_WAVE_REDUCE(float, dpp_f, fmaxf, v)
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 __device__ __forceinline__ float wave_min_f(float v) {
   MVICP_WAVE_REDUCE(float, dpp_f, fminf, v)
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
@@ -104,6 +108,8 @@ __device__ __forceinline__ float bcast(float v, int lane) {
 
 struct Lane {          // per-lane query state
   double qx, qy, qz, best;
+  float qxf, qyf, qzf;   // fp32 copies for the screens
+  float thr;             // fp32 screen threshold, always >= (sqrt(best) + slack)^2 (see leaf_scan)
   int bi;
   bool active;
 };
@@ -112,12 +118,20 @@ struct Group {         // wave-uniform patch description
   float slack;         // fp32 screening guard band (metres)
 };
 
-// exact-order lower bound of the reference distance from q to any point in the box
-__device__ __forceinline__ double box_lb(const Lane& L, float b0, float b1, float b2, float b3, float b4, float b5) {
-  const double g0 = fmax(fmax(__dsub_rn((double)b0, L.qx), __dsub_rn(L.qx, (double)b3)), 0.0);
-  const double g1 = fmax(fmax(__dsub_rn((double)b1, L.qy), __dsub_rn(L.qy, (double)b4)), 0.0);
-  const double g2 = fmax(fmax(__dsub_rn((double)b2, L.qz), __dsub_rn(L.qz, (double)b5)), 0.0);
-  return __dadd_rn(__dadd_rn(__dmul_rn(g0, g0), __dmul_rn(g1, g1)), __dmul_rn(g2, g2));
+// fp32 squared distance from the lane's query to a box.  Same guard-band argument as the point screen in leaf_scan: the
+// nearest point of the box has box coordinates (exact floats) or the query's own, so |sqrt(lb32) - sqrt(true)| <= slack and
+// every box holding a point with d2 <= best satisfies lb32 <= L.thr.
+__device__ __forceinline__ float box_lb32(const Lane& L, float b0, float b1, float b2, float b3, float b4, float b5) {
+  const float g0 = fmaxf(fmaxf(b0 - L.qxf, L.qxf - b3), 0.f);
+  const float g1 = fmaxf(fmaxf(b1 - L.qyf, L.qyf - b4), 0.f);
+  const float g2 = fmaxf(fmaxf(b2 - L.qzf, L.qzf - b5), 0.f);
+  return __builtin_fmaf(g2, g2, __builtin_fmaf(g1, g1, g0 * g0));
+}
+
+// screen threshold for a running best: (sqrt(best) + slack)^2 with 2^-20 relative head-room
+__device__ __forceinline__ float thr_of(double best, float slack) {
+  const float rb = (float)sqrt(best) * 1.000001f + slack;
+  return rb * rb * 1.000002f;
 }
 
 // Scan one leaf tile for the whole wave.  The tile is staged once in LDS as fp64 (exact evaluation) AND fp32
@@ -157,14 +171,10 @@ __device__ __forceinline__ void leaf_scan(const TileView& g, int leaf, Lane& L, 
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  const float qxf = (float)L.qx, qyf = (float)L.qy, qzf = (float)L.qz;
-  const f2v qx2 = {qxf, qxf}, qy2 = {qyf, qyf}, qz2 = {qzf, qzf};
-  // screen threshold: (sqrt(best) + slack)^2 with 2^-20 relative head-room, recomputed when best improves
-  auto thr_of = [&](double best) {
-    const float rb = (float)sqrt(best) * 1.000001f + slack;
-    return rb * rb * 1.000002f;
-  };
-  float thr = thr_of(L.best);
+  const f2v qx2 = {L.qxf, L.qxf}, qy2 = {L.qyf, L.qyf}, qz2 = {L.qzf, L.qzf};
+  // L.thr >= (sqrt(best) + slack)^2 at all times.  When a candidate with screen value d32 becomes the best, sqrt(best) <=
+  // sqrt(d32) + slack, so (sqrt(d32) + 2 slack)^2 is a valid new threshold: one fp32 sqrt instead of an fp64 one per update.
+  float thr = L.thr;
   const float4* X4 = reinterpret_cast<const float4*>(T->fx);
   const float4* Y4 = reinterpret_cast<const float4*>(T->fy);
   const float4* Z4 = reinterpret_cast<const float4*>(T->fz);
@@ -177,6 +187,7 @@ __device__ __forceinline__ void leaf_scan(const TileView& g, int leaf, Lane& L, 
     const f2v db = __builtin_elementwise_fma(gb, gb, __builtin_elementwise_fma(fb, fb, eb * eb));
     const unsigned hit = (da.x <= thr ? 1u : 0u) | (da.y <= thr ? 2u : 0u) | (db.x <= thr ? 4u : 0u) | (db.y <= thr ? 8u : 0u);
     if (hit) {
+      const float d32[4] = {da.x, da.y, db.x, db.y};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int k = 4 * k4 + j;
@@ -185,12 +196,17 @@ __device__ __forceinline__ void leaf_scan(const TileView& g, int leaf, Lane& L, 
           const double d = __dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2));
           if (d <= L.best) {
             const int oi = T->id[k];
-            if (d < L.best || oi < L.bi) { L.best = d; L.bi = oi; thr = thr_of(d); }
+            if (d < L.best || oi < L.bi) {
+              L.best = d; L.bi = oi;
+              const float r = __builtin_amdgcn_sqrtf(d32[j]) * 1.000001f + 2.f * slack;
+              thr = fminf(thr, r * r * 1.000002f);
+            }
           }
         }
       }
     }
   }
+  L.thr = thr;
   *n_cand += (unsigned)cnt;
 }
 
@@ -235,10 +251,11 @@ __device__ void visit(const TileView& g, int first, int nchild, Lane& L, const G
   }
   *n_box += (unsigned)nchild;
   bool pend = lane < nchild;
-  // largest running best of the wave: only shrinks, and only when a tile was scanned below -> refreshed after descents
-  double gmax = wave_max(L.active ? L.best : -1.0);
+  // largest screen threshold of the wave (>= every lane's best): only shrinks, and only when a tile was scanned below ->
+  // refreshed after descents
+  float gmax = wave_max_f(L.active ? L.thr : -1.f);
   while (true) {
-    pend = pend && (double)ddf <= gmax;
+    pend = pend && ddf <= gmax;
     const unsigned long long mask = __ballot(pend);
     if (mask == 0ull) break;
     const float kmin = wave_min_f(pend ? key : inf);
@@ -252,8 +269,8 @@ __device__ void visit(const TileView& g, int first, int nchild, Lane& L, const G
     } else {
       c0 = bcast(b0, c); c1 = bcast(b1, c); c2 = bcast(b2, c); c3 = bcast(b3, c); c4 = bcast(b4, c); c5 = bcast(b5, c);
     }
-    const double lb = box_lb(L, c0, c1, c2, c3, c4, c5);
-    if (__ballot(L.active && lb <= L.best) == 0ull) continue;
+    const float lb = box_lb32(L, c0, c1, c2, c3, c4, c5);
+    if (__ballot(L.active && lb <= L.thr) == 0ull) continue;
     const int child = first + c;
     if (LEVEL == 0) {
       leaf_scan(g, child, L, G.slack, T, n_cand);
@@ -261,7 +278,7 @@ __device__ void visit(const TileView& g, int first, int nchild, Lane& L, const G
       const int cf = child * FAN;
       visit<(LEVEL > 0 ? LEVEL - 1 : 0)>(g, cf, min(FAN, g.cnt[LEVEL > 0 ? LEVEL - 1 : 0] - cf), L, G, T, sbox, n_cand, n_box);
     }
-    gmax = wave_max(L.active ? L.best : -1.0);
+    gmax = wave_max_f(L.active ? L.thr : -1.f);
   }
 }
 
@@ -315,6 +332,8 @@ __global__ __launch_bounds__(NT, WPE) void nn_tile_kernel(const TileJob* __restr
     // per axis: |fl32(q) - q| + |fl32(p) - p| + rounding of the fp32 subtraction <= 3 * 2^-24 * m; x sqrt(3) axes, x2 safety
     G.slack = bcast((float)(m * (3.0 * 1.7320508 * 2.0 / 16777216.0)) + 1e-30f, 0);
   }
+  L.qxf = (float)L.qx; L.qyf = (float)L.qy; L.qzf = (float)L.qz;
+  L.thr = thr_of(L.best, G.slack);
   unsigned int n_cand = 0, n_box = 0;
   const int top = g.levels - 1;
   TileLds* T = &s_tile[wave];

@@ -43,11 +43,13 @@ struct Assembler {
   }
   int n() const { return 6 * nfree; }
 
-  // blocks (E x 91, canonical) at parameters x -> dense H (n x n row-major), g (n), returns cost
-  double assemble(const double* x, const double* blocks, double* H, double* g) {
+  // blocks (E x 91, canonical) at parameters x -> H (n x n row-major; only the LOWER ENVELOPE env[i] <= j <= i of every row
+  // is written and meaningful: the system is block-banded for a turntable graph, and every consumer below stays inside the
+  // envelope, so a solve costs O(n * bandwidth) per pass instead of O(n^2)), g (n); returns cost
+  double assemble(const double* x, const double* blocks, double* H, double* g, const int* env) {
     const int A = se3::ambient(param), nn = n();
     for (int i = 0; i < K; ++i) se3::local_to_canonical(param, x + (size_t)i * A, &M[(size_t)i * 36]);
-    std::fill(H, H + (size_t)nn * nn, 0.0);
+    for (int i = 0; i < nn; ++i) std::fill(H + (size_t)i * nn + env[i], H + (size_t)i * nn + (i / 6) * 6 + 6, 0.0);   // up to the end of the diagonal block
     std::fill(g, g + nn, 0.0);
     double cost = 0.0;
     double Hc[12][12], T[6][6], Hl[6][6];
@@ -67,7 +69,7 @@ struct Assembler {
           g[fr[bi] * 6 + l] += s;
         }
         for (int bj = 0; bj < 2; ++bj) {
-          if (fr[bj] < 0) continue;
+          if (fr[bj] < 0 || fr[bj] > fr[bi]) continue;   // lower block triangle only
           // Hl = Mi^T Hc[bi][bj] Mj
           for (int k = 0; k < 6; ++k)
             for (int l = 0; l < 6; ++l) {
@@ -152,7 +154,13 @@ int lm_solve(int K, int E, const int* src, const int* dst, double* poses, unsign
   auto poses_of = [&](const std::vector<double>& xv, double* P) { for (int i = 0; i < K; ++i) se3::x_to_pose(param, &xv[(size_t)i * A], P + 16 * (size_t)i); };
   auto xnorm = [&](const std::vector<double>& v) { double s = 0; for (int i = 0; i < K; ++i) if (!fixed[i]) for (int a = 0; a < A; ++a) s += v[i * A + a] * v[i * A + a]; return std::sqrt(s); };
 
-  std::vector<double> H((size_t)n * n), g(n), Hn((size_t)n * n), gn(n), scale(n), Hs((size_t)n * n), gs(n), diag(n), Aw, step(n), delta(n);
+  // n x n work matrices live in a per-thread workspace: only their envelope is ever touched, so they are neither zeroed nor
+  // reallocated between solves (an ICP round calls this once)
+  static thread_local std::vector<double> wsH, wsHn, wsHs, wsAw;
+  const size_t n2 = (size_t)n * n;
+  if (wsH.size() < n2) { wsH.resize(n2); wsHn.resize(n2); wsHs.resize(n2); wsAw.resize(n2); }
+  std::vector<double>& H = wsH; std::vector<double>& Hn = wsHn; std::vector<double>& Hs = wsHs; std::vector<double>& Aw = wsAw;
+  std::vector<double> g(n), gn(n), scale(n), gs(n), diag(n), step(n), delta(n);
   // structural envelope of the normal matrix from the pose graph: block row b starts at its lowest-numbered neighbour
   std::vector<int> env(n);
   {
@@ -168,7 +176,7 @@ int lm_solve(int K, int E, const int* src, const int* dst, double* poses, unsign
   poses_of(x, pc.data());
   MV_CHECK(eval(user, pc.data(), blocks.data()));
   sm->evaluations = 1;
-  double cost = as.assemble(x.data(), blocks.data(), H.data(), g.data());
+  double cost = as.assemble(x.data(), blocks.data(), H.data(), g.data(), env.data());
   sm->initial_cost = sm->final_cost = cost;
   auto finish = [&]() { poses_of(x, poses); sm->final_cost = cost; return MVICP_OK; };
   if (n == 0) { sm->termination = 1; return finish(); }
@@ -176,7 +184,7 @@ int lm_solve(int K, int E, const int* src, const int* dst, double* poses, unsign
   auto gmax_of = [&](const std::vector<double>& gv) { double m = 0; for (int i = 0; i < n; ++i) m = std::max(m, std::fabs(gv[i])); return m; };
   for (int i = 0; i < n; ++i) scale[i] = 1.0 / (1.0 + std::sqrt(H[(size_t)i * n + i]));
   auto rescale = [&]() {
-    for (int i = 0; i < n; ++i) { gs[i] = g[i] * scale[i]; for (int j = 0; j < n; ++j) Hs[(size_t)i * n + j] = H[(size_t)i * n + j] * scale[i] * scale[j]; }
+    for (int i = 0; i < n; ++i) { gs[i] = g[i] * scale[i]; for (int j = env[i]; j <= i; ++j) Hs[(size_t)i * n + j] = H[(size_t)i * n + j] * scale[i] * scale[j]; }
   };
   rescale();
   if (gmax_of(g) <= gradient_tolerance) { sm->termination = 1; return finish(); }
@@ -187,19 +195,21 @@ int lm_solve(int K, int E, const int* src, const int* dst, double* poses, unsign
     ++iter;
     sm->iterations = iter;
     if (!reuse_diagonal) for (int i = 0; i < n; ++i) diag[i] = std::min(std::max(Hs[(size_t)i * n + i], min_diag), max_diag);
-    Aw = Hs;
-    for (int i = 0; i < n; ++i) Aw[(size_t)i * n + i] += diag[i] / radius;
+    for (int i = 0; i < n; ++i) {
+      for (int j = env[i]; j <= i; ++j) Aw[(size_t)i * n + j] = Hs[(size_t)i * n + j];
+      Aw[(size_t)i * n + i] += diag[i] / radius;
+    }
     bool valid = cholesky_solve(Aw, n, env.data(), gs.data(), step.data());
     reuse_diagonal = true;
     double model_cost_change = 0.0;
     if (valid) {
       double sg = 0.0, sHs = 0.0;
       for (int i = 0; i < n; ++i) step[i] = -step[i];
-      for (int i = 0; i < n; ++i) {
+      for (int i = 0; i < n; ++i) {   // step^T Hs step from the lower envelope (Hs is symmetric)
         sg += step[i] * gs[i];
         double t = 0.0;
-        for (int j = 0; j < n; ++j) t += Hs[(size_t)i * n + j] * step[j];
-        sHs += step[i] * t;
+        for (int j = env[i]; j < i; ++j) t += Hs[(size_t)i * n + j] * step[j];
+        sHs += step[i] * (2.0 * t + Hs[(size_t)i * n + i] * step[i]);
       }
       model_cost_change = -(sg + 0.5 * sHs);
       valid = model_cost_change > 0.0;
@@ -219,7 +229,7 @@ int lm_solve(int K, int E, const int* src, const int* dst, double* poses, unsign
     poses_of(xc, pc.data());
     MV_CHECK(eval(user, pc.data(), blocks.data()));
     sm->evaluations++;
-    const double cand_cost = as.assemble(xc.data(), blocks.data(), Hn.data(), gn.data());
+    const double cand_cost = as.assemble(xc.data(), blocks.data(), Hn.data(), gn.data(), env.data());
     double sn = 0.0;
     for (int i = 0; i < K; ++i) if (!fixed[i]) for (int a = 0; a < A; ++a) { const double dd = x[i * A + a] - xc[i * A + a]; sn += dd * dd; }
     if (std::sqrt(sn) <= parameter_tolerance * (x_norm + parameter_tolerance)) { sm->termination = 2; break; }

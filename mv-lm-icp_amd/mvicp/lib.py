@@ -270,6 +270,7 @@ class Engine:
 
     # ---- profiling
     def profile(self, on=True):
+        """on: False/0 off, True/1 every scope, 2 only the roofline scopes "nn" and "linearize"."""
         _check(self.lib, self.lib.mvicp_profile_enable(self.h, int(on)))
 
     def profile_reset(self):

@@ -15,7 +15,7 @@ out_dir, tag = sys.argv[1], sys.argv[2]
 warmup = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 
 KERNELS = ("nn_grid_kernel", "nn_far_kernel", "nn_tile_kernel", "nn_brute_kernel", "nn_brute_merge_kernel", "dirty_reduce_kernel", "census_sum_kernel",
-           "linearize_kernel", "reduce_expand_kernel", "gather_kernel", "scatter_kernel", "count_kernel", "scan_kernel", "select_hist_kernel",
+           "linearize_kernel", "reduce_expand_kernel", "gather_kernel", "scatter_kernel", "count_kernel", "scan_kernel", "select_pass_kernel", "select_pick_kernel",
            "select_final_kernel", "normals_kernel")
 NN_SCOPE = ("nn_grid_kernel", "nn_far_kernel", "nn_tile_kernel", "nn_brute_kernel", "nn_brute_merge_kernel", "dirty_reduce_kernel", "census_sum_kernel")
 NN_HEAD = ("nn_grid_kernel", "nn_tile_kernel", "nn_brute_kernel")  # first kernel of an NN stage
