@@ -253,14 +253,19 @@ __global__ __launch_bounds__(NT) void select_pass_kernel(const int* __restrict__
     }
     const unsigned int bin = (unsigned int)(key >> SHIFT) & (kSelBins - 1);
     if (PASS == 0) {
-      // exponent digit: a wave sees a handful of distinct bins -> aggregate equal bins, one LDS atomic per distinct value
-      unsigned long long todo = __ballot(match);
+      // exponent digit: the 64 keys of a wave share a handful of exponents, so plain LDS atomics would serialise on a few
+      // addresses.  Exponent fields 768..1023 (values in [2^-255, 2): every realistic squared distance) are counted in
+      // EIGHT interleaved copies of a 256-bin window, picked by the lane number; anything else (exact zeros, huge cutoffs)
+      // is rare and goes straight to the global histogram, one atomic per distinct value per wave.
       const int lane = threadIdx.x & 63;
+      const bool inwin = match && bin >= 768u && bin < 1024u;
+      if (inwin) atomicAdd(&lh[(bin & 255u) | ((unsigned int)(lane & 7) << 8)], 1u);
+      unsigned long long todo = __ballot(match && !inwin);
       while (todo) {
         const int leader = __ffsll((long long)todo) - 1;
         const unsigned int lbin = (unsigned int)__builtin_amdgcn_readlane((int)bin, leader);
-        const unsigned long long same = __ballot(match && bin == lbin) & todo;
-        if (lane == leader) atomicAdd(&lh[lbin], (unsigned int)__popcll(same));
+        const unsigned long long same = __ballot(match && !inwin && bin == lbin) & todo;
+        if (lane == leader) atomicAdd(&hist[((size_t)PASS * E + e) * kSelBins + lbin], (unsigned int)__popcll(same));
         todo &= ~same;
       }
     } else if (match) {
@@ -280,9 +285,16 @@ __global__ __launch_bounds__(NT) void select_pass_kernel(const int* __restrict__
       if (keys[i] >> 63) out_keys[base + off++] = __longlong_as_double((long long)(keys[i] & ~(1ull << 63)));
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < kSelBins; i += NT) {
-    const unsigned int v = lh[i];
-    if (v) atomicAdd(&hist[((size_t)PASS * E + e) * kSelBins + i], v);
+  if (PASS == 0) {
+    unsigned int v = 0;   // fold the 8 copies of the exponent window
+#pragma unroll
+    for (int cpy = 0; cpy < 8; ++cpy) v += lh[cpy * 256 + threadIdx.x];
+    if (v) atomicAdd(&hist[((size_t)PASS * E + e) * kSelBins + 768 + threadIdx.x], v);
+  } else {
+    for (int i = threadIdx.x; i < kSelBins; i += NT) {
+      const unsigned int v = lh[i];
+      if (v) atomicAdd(&hist[((size_t)PASS * E + e) * kSelBins + i], v);
+    }
   }
 }
 

@@ -497,6 +497,48 @@ def test_empty_edges_and_tiny_cutoff(eng, orc):
     assert np.allclose(P, pb["init"], rtol=0, atol=1e-15) and sm["final_cost"] == 0.0 and sm["iterations"] == 0
 
 
+def _weight_ref(d2, thresh):
+    """frame.cpp:156-176 on the host: keep sqrt(d2) < (double)thresh, upper median, x1.5, to float."""
+    d = np.sqrt(d2)
+    d = d[d < float(np.float32(thresh))]
+    if d.size == 0:
+        return 0, np.float32(0)
+    return d.size, np.float32(np.partition(d, d.size // 2)[d.size // 2] * 1.5)
+
+
+@pytest.mark.parametrize("case", ["all_zero", "half_zero", "near_equal", "one_binade", "wide", "single"])
+def test_median_select_degenerate_key_sets(eng, case):
+    """The radix select (exponent digit -> two compacted refinements -> in-LDS finish) on key sets that stress each stage:
+    all keys equal (compact buffers as long as the list), zeros mixed with normal keys, keys that differ only in their lowest
+    mantissa bits, keys spanning many binades, a single key.  Weight and count must equal the reference rule bit for bit."""
+    rng = np.random.default_rng(11)
+    n = 9001 if case != "single" else 1
+    dst = rng.uniform(-1.0, 1.0, (n, 3))
+    if case == "all_zero":
+        off = np.zeros((n, 3))
+    elif case == "half_zero":
+        off = np.where(rng.random((n, 1)) < 0.5, 0.0, 1.0) * rng.normal(0, 1e-5, (n, 3))
+    elif case == "near_equal":
+        off = np.tile([3e-5, 0.0, 0.0], (n, 1))           # d2 ~ 9e-10 for every pair, low bits differ with the rounding of x + 3e-5
+    elif case == "one_binade":
+        off = rng.uniform(1.0, 1.4, (n, 1)) * np.array([[2e-5, 0.0, 0.0]])
+    elif case == "wide":
+        off = (10.0 ** rng.uniform(-12, -3.5, (n, 1))) * np.array([[1.0, 0.0, 0.0]])
+    else:
+        off = np.array([[1e-4, 0.0, 0.0]])
+    src = dst + off
+    I = np.eye(4)
+    poses = np.stack([I, I])
+    fixed = np.array([1, 0], dtype=np.uint8)
+    eng.set_frames([dst, src], [None, None]); eng.set_graph([1], [0])
+    idx, d2 = eng.nn_query(0, src, L.NN_BRUTE)
+    want_n, want_w = _weight_ref(d2, 0.05)
+    for method in (L.NN_GRID, L.NN_TILE):
+        counts, weights = eng.correspond(poses, fixed, 0.05, method)
+        assert counts[0] == want_n
+        assert weights.dtype == np.float32 and weights[0].tobytes() == want_w.tobytes(), (case, method, weights[0], want_w)
+
+
 def test_full_size_properties_cfg4():
     """BASELINE config 4 size (32 views x 200k points, 62 edges): size-independent properties of the whole round —
     (1) a second search at the same poses (temporal cache + list reuse engaged) returns exactly the first result;
