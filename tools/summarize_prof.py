@@ -2,8 +2,10 @@
 
 Per-kernel table (calls, total, avg, min, max) from the kernel trace; per-kernel PMC averages; and two SCOPES that match
 bench.py's HIP-event scopes: "nn" = every kernel of one mvicp_correspond NN stage (nn_grid phase 1, nn_far, nn_tile,
-dirty_reduce, census) and "linearize" = one linearize_kernel launch.  Scope figures skip the first `warmup` correspond
-calls (bench.py's untimed warm-up steps) so they are per TIMED launch like bench.py's `roofline.achieved`."""
+dirty_reduce, census) and "linearize" = one linearize_kernel launch.  Scope figures cover bench.py's TIMED rounds only:
+the first `warmup` rounds (untimed warm-up steps) are skipped and only the next `steps` rounds are used, which also leaves
+out the untimed replay pass bench.py runs afterwards — so they are per timed launch like bench.py's `roofline.achieved`.
+The per-kernel table above the scopes covers every dispatch of the process (warm-up and replay included)."""
 import csv
 import glob
 import json
@@ -13,6 +15,7 @@ from collections import defaultdict
 
 out_dir, tag = sys.argv[1], sys.argv[2]
 warmup = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+steps = int(sys.argv[4]) if len(sys.argv) > 4 else 19
 
 KERNELS = ("nn_grid_kernel", "nn_far_kernel", "nn_tile_kernel", "nn_brute_kernel", "nn_brute_merge_kernel", "dirty_reduce_kernel", "census_sum_kernel",
            "linearize_kernel", "reduce_expand_kernel", "gather_kernel", "scatter_kernel", "count_kernel", "scan_kernel", "select_pass_kernel", "select_pick_kernel",
@@ -41,17 +44,19 @@ def base(name):
 
 
 def scope_calls(rows, value_of):
-    """rows: dispatches in Dispatch_Id order -> list of per-call sums for the nn scope, and list for linearize launches."""
-    nn_calls, lin = [], []
+    """rows: dispatches in Dispatch_Id order -> per-NN-stage sums of the timed rounds, and the linearize launches of those
+    rounds (a round = one NN stage + the linearize launches up to the next NN stage)."""
+    nn_calls, lin_rounds = [], []
     for r in rows:
         b = base(r["Kernel_Name"])
         if b in NN_HEAD:
-            nn_calls.append(0.0)
+            nn_calls.append(0.0); lin_rounds.append([])
         if b in NN_SCOPE and nn_calls:
             nn_calls[-1] += value_of(r)
-        if b == "linearize_kernel":
-            lin.append(value_of(r))
-    return nn_calls, lin
+        if b == "linearize_kernel" and lin_rounds:
+            lin_rounds[-1].append(value_of(r))
+    sel = slice(warmup, warmup + steps)
+    return nn_calls[sel], [v for rnd in lin_rounds[sel] for v in rnd]
 
 
 lines = []
@@ -73,13 +78,13 @@ if tr:
         lines.append(f"{k:48s} {a[0]:7d} {a[1]:12.1f} {a[1]/a[0]:10.2f} {a[2]:10.2f} {a[3]:10.2f} {100*a[1]/tot:6.2f}")
         kern.setdefault(k, {})["avg_us"] = a[1] / a[0]; kern[k]["calls"] = a[0]
     nn_calls, lin = scope_calls(rows, dur)
-    if len(nn_calls) > warmup:
-        t = nn_calls[warmup:]
+    if nn_calls:
+        t = nn_calls
         scopes["nn"].update(avg_us=sum(t) / len(t), calls=len(t))
     if lin:
         scopes["linearize"].update(avg_us=sum(lin) / len(lin), calls=len(lin))
     lines.append("")
-    lines.append(f"# scopes (bench.py HIP-event scopes; first {warmup} NN stage(s) = warm-up skipped)")
+    lines.append(f"# scopes (bench.py HIP-event scopes; timed rounds only: {warmup} warm-up round(s) skipped, next {steps} rounds used, replay pass excluded)")
     for k, v in scopes.items():
         if v:
             lines.append(f"{k:12s} calls {v['calls']:5d}  avg_us {v['avg_us']:10.2f}")
@@ -99,8 +104,8 @@ for sub, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         lines.append(f"{k:48s} {a[0]:10d} {a[1]/a[0]:14.1f}")
         kern.setdefault(k, {})[ctr + "_KiB"] = a[1] / a[0]
     nn_calls, lin = scope_calls(rows, lambda r: float(r["Counter_Value"]))
-    if len(nn_calls) > warmup:
-        t = nn_calls[warmup:]
+    if nn_calls:
+        t = nn_calls
         scopes["nn"][ctr + "_KiB"] = sum(t) / len(t)
     if lin:
         scopes["linearize"][ctr + "_KiB"] = sum(lin) / len(lin)
@@ -113,7 +118,7 @@ if os.path.exists(p):
         lines.append(json.dumps({k: j[k] for k in ("value", "ms_per_step", "roofline", "roofline_nn", "roofline_linearize", "kernel_ms_per_step") if k in j}))
     except Exception as ex:
         lines.append(f"# bench line unreadable: {ex}")
-json.dump({"tag": tag, "warmup_skipped": warmup, "kernels": kern, "scopes": scopes}, open(os.path.join(out_dir, f"{tag}_kernels.json"), "w"), indent=1, sort_keys=True)
+json.dump({"tag": tag, "warmup_skipped": warmup, "timed_rounds": steps, "kernels": kern, "scopes": scopes}, open(os.path.join(out_dir, f"{tag}_kernels.json"), "w"), indent=1, sort_keys=True)
 txt = "\n".join(lines) + "\n"
 open(os.path.join(out_dir, f"{tag}_summary.txt"), "w").write(txt)
 print(txt)
