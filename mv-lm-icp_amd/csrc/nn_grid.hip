@@ -60,6 +60,7 @@ struct GridJob {
   // "did anything change?" bookkeeping of the edge's compacted list (all null for the raw-query API)
   const int* qpos; const int* second; double* cd2; const int* dirty; int* dirty_slots;  // dirty: host-forced flag; slots: one per NT queries
   double* out_lb;      // per query: lower bound on the distance to every target other than out_idx (null: no cache)
+  int seed;            // out_idx still holds last round's neighbours (from any kernel): a starting candidate for far queries
 };
 
 __host__ __device__ __forceinline__ unsigned long long cell_key(int ix, int iy, int iz) {
@@ -257,6 +258,17 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
     m2 = m > 0.0 ? m * m : 0.0;
     resolved = (m > 0.0) && (best < m2) && (bi != 0x7fffffff);
   }
+  if (!TREE_ONLY && !resolved && bi == 0x7fffffff && job.seed) {
+    // nothing in the block: rather than starting the tree descent from the cutoff bound, start it from last round's
+    // neighbour (an ordinary candidate; phase 2 knows how to meet its own seed again)
+    const int pi = job.out_idx[out];
+    if (pi >= 0 && pi < g.n) {
+      const double2* tp = reinterpret_cast<const double2*>(g.srec + pi);
+      const double2 ta = tp[0], tb = tp[1];
+      const double d = dist2(qx, qy, qz, ta.x, ta.y, tb.x);
+      if (d < best) { best = d; bi = (int)__double_as_longlong(tb.y); }
+    }
+  }
   // provisional (or final) result; phase 2 re-reads it as the seed of the tree descent
   job.out_idx[out] = bi == 0x7fffffff ? -1 : (job.inv ? job.inv[bi] : bi);
   job.out_d2[out] = best;
@@ -447,6 +459,26 @@ inline unsigned long long morton3(unsigned int x, unsigned int y, unsigned int z
   return spread(x) | (spread(y) << 1) | (spread(z) << 2);
 }
 
+// 3-D Hilbert index of a cell (Skilling's transpose algorithm, `bits` per axis).  Consecutive runs of a Hilbert-sorted
+// surface are compact patches without the long jumps of the Z-order curve at power-of-two boundaries, so the boxes of the
+// 32-point tiles / 8-ary tree nodes built over the sorted array are tighter and fewer of them overlap a query patch.
+inline unsigned long long hilbert3(unsigned int x, unsigned int y, unsigned int z, int bits) {
+  unsigned int X[3] = {x, y, z};
+  const unsigned int M = 1u << (bits - 1);
+  for (unsigned int Q = M; Q > 1; Q >>= 1) {
+    const unsigned int P = Q - 1;
+    for (int i = 0; i < 3; ++i) {
+      if (X[i] & Q) X[0] ^= P;
+      else { const unsigned int t = (X[0] ^ X[i]) & P; X[0] ^= t; X[i] ^= t; }
+    }
+  }
+  for (int i = 1; i < 3; ++i) X[i] ^= X[i - 1];
+  unsigned int t = 0;
+  for (unsigned int Q = M; Q > 1; Q >>= 1) if (X[2] & Q) t ^= Q - 1;
+  for (int i = 0; i < 3; ++i) X[i] ^= t;
+  return morton3(X[2], X[1], X[0]);   // interleave, X[0] most significant in every bit triple
+}
+
 struct HostGrid {
   double o[3], h, inv_h;
   int d[3];
@@ -513,12 +545,15 @@ int build_grid(mvicp_ctx* c, FrameDev& f, const double* xyz) {
   }
   make_grid(g, lo, hi, h);
 
-  // sort by (Morton(cell), original index)
+  // sort by (space-filling-curve index of the cell, original index)
   std::vector<unsigned long long> mkey(n), ckey(n);
   int cc[3];
+  int hbits = 1;
+  while ((1 << hbits) < std::max(g.d[0], std::max(g.d[1], g.d[2]))) ++hbits;
   for (int i = 0; i < n; ++i) {
     cell_of(g, xyz + 3 * (size_t)i, cc);
-    mkey[i] = morton3((unsigned)cc[0], (unsigned)cc[1], (unsigned)cc[2]);
+    mkey[i] = c->grid_curve == 0 ? morton3((unsigned)cc[0], (unsigned)cc[1], (unsigned)cc[2])
+                                 : hilbert3((unsigned)cc[0], (unsigned)cc[1], (unsigned)cc[2], hbits);
     ckey[i] = cell_key(cc[0], cc[1], cc[2]);
   }
   std::vector<int> order(n);
@@ -703,6 +738,7 @@ int launch_nn_grid_edges(mvicp_ctx* c, double d2_bound) {
     j.inv = d.grid.inv; j.out_lb = c->d_nn_lb + c->cap_off[e];
     j.qpos = c->d_qpos + c->cap_off[e]; j.second = c->d_second + c->cap_off[e]; j.cd2 = c->d_cd2 + c->cap_off[e]; j.dirty = c->d_dirty + e;
     j.dirty_slots = c->d_dirty_slots + c->dslot_off[e];
+    j.seed = ((int)c->nn_cache_edge.size() == c->E && c->nn_cache_edge[e]) ? 1 : 0;
     jobs.push_back(j);
   }
   return run(c, jobs, d2_bound);
