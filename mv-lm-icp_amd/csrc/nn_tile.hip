@@ -94,13 +94,26 @@ __device__ __forceinline__ double wave_min(double v) {
   MVICP_WAVE_REDUCE(double, dpp_d, fmin, v)
   return uniform_d(v, 63);
 }
-__device__ __forceinline__ float wave_max_f(float v) {
-  MVICP_WAVE_REDUCE(float, dpp_f, fmaxf, v)
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+// fp32 reductions of NON-NEGATIVE values (incl. +inf): their bit patterns order like unsigned integers, so the whole
+// reduction is six v_min_u32 / v_max_u32 with the DPP permutation fused into the operand (the builtin form costs a
+// mov + mov_dpp + op per step).  "s_nop 1": a VALU result needs two wait states before a DPP read of it.
+#define MVICP_DPP_CHAIN(OP)                                                         \
+  "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
+  "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" \
+  "s_nop 1\n\t" OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"     \
+  "s_nop 1\n\t" OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"          \
+  "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"        \
+  "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"        \
+  "s_nop 1"
+__device__ __forceinline__ float wave_max_f(float nonneg) {
+  unsigned int v = (unsigned int)__float_as_int(nonneg);
+  asm volatile(MVICP_DPP_CHAIN("v_max_u32_dpp") : "+v"(v));
+  return __int_as_float(__builtin_amdgcn_readlane((int)v, 63));
 }
-__device__ __forceinline__ float wave_min_f(float v) {
-  MVICP_WAVE_REDUCE(float, dpp_f, fminf, v)
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+__device__ __forceinline__ float wave_min_f(float nonneg) {
+  unsigned int v = (unsigned int)__float_as_int(nonneg);
+  asm volatile(MVICP_DPP_CHAIN("v_min_u32_dpp") : "+v"(v));
+  return __int_as_float(__builtin_amdgcn_readlane((int)v, 63));
 }
 __device__ __forceinline__ float bcast(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
@@ -178,7 +191,7 @@ __device__ __forceinline__ void leaf_scan(const TileView& g, int leaf, Lane& L, 
   const float4* X4 = reinterpret_cast<const float4*>(T->fx);
   const float4* Y4 = reinterpret_cast<const float4*>(T->fy);
   const float4* Z4 = reinterpret_cast<const float4*>(T->fz);
-#pragma unroll 2
+#pragma unroll
   for (int k4 = 0; k4 < LEAF / 4; ++k4) {
     const float4 X = X4[k4], Y = Y4[k4], Z = Z4[k4];
     const f2v xa = {X.x, X.y}, xb = {X.z, X.w}, ya = {Y.x, Y.y}, yb = {Y.z, Y.w}, za = {Z.x, Z.y}, zb = {Z.z, Z.w};
@@ -253,7 +266,7 @@ __device__ void visit(const TileView& g, int first, int nchild, Lane& L, const G
   bool pend = lane < nchild;
   // largest screen threshold of the wave (>= every lane's best): only shrinks, and only when a tile was scanned below ->
   // refreshed after descents
-  float gmax = wave_max_f(L.active ? L.thr : -1.f);
+  float gmax = wave_max_f(L.active ? L.thr : 0.f);
   while (true) {
     pend = pend && ddf <= gmax;
     const unsigned long long mask = __ballot(pend);
@@ -278,7 +291,7 @@ __device__ void visit(const TileView& g, int first, int nchild, Lane& L, const G
       const int cf = child * FAN;
       visit<(LEVEL > 0 ? LEVEL - 1 : 0)>(g, cf, min(FAN, g.cnt[LEVEL > 0 ? LEVEL - 1 : 0] - cf), L, G, T, sbox, n_cand, n_box);
     }
-    gmax = wave_max_f(L.active ? L.thr : -1.f);
+    gmax = wave_max_f(L.active ? L.thr : 0.f);
   }
 }
 
