@@ -733,6 +733,7 @@ int mvicp_set_option(mvicp_ctx* c, const char* name, double value) {
   if (std::strcmp(name, "list_reuse") == 0) { c->list_reuse = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "nn_census") == 0) { c->nn_census = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "nn_skip_far") == 0) { c->nn_skip_far = value != 0.0; return MVICP_OK; }
+  if (std::strcmp(name, "prune_rho") == 0) { c->prune_rho = value; return MVICP_OK; }
   if (std::strcmp(name, "grid_curve") == 0) { c->grid_curve = (int)value; return MVICP_OK; }   // takes effect at the next mvicp_set_frame
   if (std::strcmp(name, "auto_settle") == 0) { c->auto_settle = value; return MVICP_OK; }
   if (std::strcmp(name, "tile_seed") == 0) { c->tile_seed = value != 0.0; return MVICP_OK; }

@@ -154,8 +154,9 @@ __global__ void dirty_reduce_kernel(int E, const int* __restrict__ slot_off, int
 // ---- phase 1: spatial-hash block lookup for every query; queries it cannot prove optimal go to the far list ----
 template <bool TREE_ONLY>
 __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__ jobs, double bound, unsigned long long* __restrict__ stats, int skip_far,
-                                                     int2* __restrict__ far_list, unsigned int* __restrict__ far_count) {
+                                                     int2* __restrict__ far_list, unsigned int* __restrict__ far_count, double prune_rho) {
   __shared__ double sxf[kEdgeXf];
+  __shared__ uint2 s_rng[8][NT];   // per lane: (start, count) of the 8 block cells (written and read by the same thread only)
   const GridJob& job = jobs[blockIdx.y];
   const int i = blockIdx.x * NT + threadIdx.x;
   if (blockIdx.x * NT >= job.n) return;
@@ -164,6 +165,7 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
   __syncthreads();
   if (i >= job.n) return;
   const GridView& g = job.dst;
+  const double prune_rho2 = (prune_rho * g.h) * (prune_rho * g.h);
 
   double qx, qy, qz;
   {
@@ -184,37 +186,44 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
   // away; if the re-evaluated distance to p1 is strictly below that, p1 is still the unique nearest neighbour and its
   // exact squared distance (reference arithmetic) is the answer — no search.  Relative 1e-12 slack covers sqrt rounding.
   const double slack = has_xf ? sxf[24] : -1.0;
-  if (!TREE_ONLY && slack >= 0.0 && job.out_lb != nullptr) {
-    // how far THIS query moved since the last search: |dM p + dv| (exactly, up to the rounding allowance)
-    double eps;
-    {
-      const double p0 = job.q[3 * (size_t)i], p1 = job.q[3 * (size_t)i + 1], p2 = job.q[3 * (size_t)i + 2];
-      const double e0 = sxf[25] * p0 + sxf[28] * p1 + sxf[31] * p2 + sxf[34];
-      const double e1 = sxf[26] * p0 + sxf[29] * p1 + sxf[32] * p2 + sxf[35];
-      const double e2 = sxf[27] * p0 + sxf[30] * p1 + sxf[33] * p2 + sxf[36];
-      eps = sqrt(e0 * e0 + e1 * e1 + e2 * e2) * (1.0 + 1e-9) + slack;
-    }
+  // Last round's neighbour p1 (sorted position in out_idx, left there by whichever kernel ran) serves twice:
+  //  * temporal cache (needs last round's lower bounds, i.e. a grid round): re-evaluate the distance and stop;
+  //  * otherwise its distance bounds the search: the true neighbour lies within |q - p1| of q, so hash cells of the block
+  //    farther than r_p = max(|q - p1|, rho) need not be probed.  Everything in a skipped cell is farther than r_p, which
+  //    enters the lower bound handed to the next round's cache (rho ~ half a point spacing keeps that bound useful).
+  double rp2 = -1.0;   // < 0: scan the whole block
+  if (!TREE_ONLY && job.seed) {
     const int pi = job.out_idx[out];   // sorted position of last round's neighbour
-    if (pi >= 0) {
+    if (pi >= 0 && pi < g.n) {
       const double2* tp = reinterpret_cast<const double2*>(g.srec + pi);
       const double2 ta = tp[0], tb = tp[1];
       const double d = dist2(qx, qy, qz, ta.x, ta.y, tb.x);
-      const double nlb = job.out_lb[out] - eps;
-      if (sqrt(d) * (1.0 + 1e-12) < nlb) {
-        job.out_d2[out] = d;
-        job.out_lb[out] = nlb;
-        if (job.dirty) update_list(job, i, pi, d, bound);
-        if (stats) {
-          unsigned long long c1 = __reduce_add_u64(1ull);
-          const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + (threadIdx.x >> 6);
-          if (__lane0()) atomicAdd(&stats[4 * slot + 3], c1);
+      if (slack >= 0.0 && job.out_lb != nullptr) {
+        // how far THIS query moved since the last search: |dM p + dv| (exactly, up to the rounding allowance)
+        const double p0 = job.q[3 * (size_t)i], p1 = job.q[3 * (size_t)i + 1], p2 = job.q[3 * (size_t)i + 2];
+        const double e0 = sxf[25] * p0 + sxf[28] * p1 + sxf[31] * p2 + sxf[34];
+        const double e1 = sxf[26] * p0 + sxf[29] * p1 + sxf[32] * p2 + sxf[35];
+        const double e2 = sxf[27] * p0 + sxf[30] * p1 + sxf[33] * p2 + sxf[36];
+        const double eps = sqrt(e0 * e0 + e1 * e1 + e2 * e2) * (1.0 + 1e-9) + slack;
+        const double nlb = job.out_lb[out] - eps;
+        if (sqrt(d) * (1.0 + 1e-12) < nlb) {
+          job.out_d2[out] = d;
+          job.out_lb[out] = nlb;
+          if (job.dirty) update_list(job, i, pi, d, bound);
+          if (stats) {
+            unsigned long long c1 = __reduce_add_u64(1ull);
+            const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + (threadIdx.x >> 6);
+            if (__lane0()) atomicAdd(&stats[4 * slot + 3], c1);
+          }
+          return;
         }
-        return;
       }
+      if (prune_rho2 > 0.0) rp2 = fmax(d, prune_rho2) * 1.002;
     }
   }
 
   double m2 = 0.0;
+  double skipped = 1.7976931348623157e308;   // smallest distance bound among the block cells not probed
   if (!TREE_ONLY) {
     // 2x2x2 block of cells nearest to the query, through the spatial hash
     const double cx = (qx - g.ox) * g.inv_h - 0.5, cy = (qy - g.oy) * g.inv_h - 0.5, cz = (qz - g.oz) * g.inv_h - 0.5;
@@ -225,10 +234,20 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
     unsigned long long key[8];
     unsigned int slot[8];
     HashEntry ent[8];
+    // squared distance from q to each cell of the block: per axis 0 on q's side of the block's mid-plane, else the distance
+    // to that plane (0.2 % slack dwarfs the rounding of the cell assignment, like `m` below)
+    const double ax = qx - (g.ox + (bx + 1) * g.h), ay = qy - (g.oy + (by + 1) * g.h), az = qz - (g.oz + (bz + 1) * g.h);
+    const double ax2 = ax * ax * 0.998, ay2 = ay * ay * 0.998, az2 = az * az * 0.998;
+    const int home = (ax >= 0.0 ? 1 : 0) | (ay >= 0.0 ? 2 : 0) | (az >= 0.0 ? 4 : 0);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const int ix = bx + (c & 1), iy = by + ((c >> 1) & 1), iz = bz + (c >> 2);
-      const bool in = !(ix < 0 || iy < 0 || iz < 0 || ix >= g.dx || iy >= g.dy || iz >= g.dz);
+      bool in = !(ix < 0 || iy < 0 || iz < 0 || ix >= g.dx || iy >= g.dy || iz >= g.dz);
+      if (rp2 >= 0.0) {
+        const int df = c ^ home;
+        const double lbc = ((df & 1) ? ax2 : 0.0) + ((df & 2) ? ay2 : 0.0) + ((df & 4) ? az2 : 0.0);
+        if (lbc > rp2) { in = false; skipped = fmin(skipped, lbc); }
+      }
       key[c] = in ? cell_key(ix, iy, iz) : EMPTY;
       slot[c] = hash_slot(key[c], g.shift) & g.mask;
     }
@@ -245,10 +264,33 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
       }
       if (ent[c].key == EMPTY) ent[c].count = 0;
     }
+    // One flattened candidate loop per lane.  Scanning cell after cell would cost, per wave, the SUM over the 8 cells of the
+    // longest run any lane has in that cell; walking each lane's own runs back to back costs the longest TOTAL of any lane
+    // (about half), and lets the cells pruned above actually save time.  The (start, count) pairs go through LDS because
+    // a register array cannot be indexed per lane.
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      scan_range(g, (int)ent[c].start, (int)(ent[c].start + ent[c].count), qx, qy, qz, best, bi, second);
+      s_rng[c][threadIdx.x] = make_uint2(ent[c].start, ent[c].count);
       n_cand += ent[c].count;
+    }
+    {
+      int c = -1;
+      unsigned int j = 0, je = 0;
+      for (;;) {
+        while (j == je && c < 7) { ++c; const uint2 r = s_rng[c][threadIdx.x]; j = r.x; je = r.x + r.y; }
+        if (j == je) break;
+        const double2* p = reinterpret_cast<const double2*>(g.srec + j);  // two 16-B loads per candidate
+        const double2 a = p[0], b = p[1];
+        const double d = dist2(qx, qy, qz, a.x, a.y, b.x);
+        const int oi = (int)__double_as_longlong(b.y);
+        if (d < best || (d == best && oi < bi)) {
+          if (bi != 0x7fffffff) second = fmin(second, best);
+          best = d; bi = oi;
+        } else {
+          second = fmin(second, d);
+        }
+        ++j;
+      }
     }
     // every point outside the block differs from q by at least `m` along some axis (cells are assigned with
     // the same rounded expression; 0.1 % slack dwarfs any rounding in it)
@@ -273,7 +315,7 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
   job.out_idx[out] = bi == 0x7fffffff ? -1 : (job.inv ? job.inv[bi] : bi);
   job.out_d2[out] = best;
   // every other target is either a scanned candidate (>= second) or outside the block (>= m)
-  if (job.out_lb != nullptr) job.out_lb[out] = resolved ? sqrt(fmin(second, m2)) * (1.0 - 1e-12) : 0.0;
+  if (job.out_lb != nullptr) job.out_lb[out] = resolved ? sqrt(fmin(fmin(second, m2), skipped)) * (1.0 - 1e-12) : 0.0;
   if (job.dirty && (resolved || skip_far)) update_list(job, i, bi == 0x7fffffff ? -1 : job.inv[bi], best, bound);
   if (!resolved && !skip_far) {
     // wave-aggregated append: one atomic per wave
@@ -702,9 +744,10 @@ int run(mvicp_ctx* c, const std::vector<GridJob>& jobs, double bound) {
     ProfScope ps(c, "nn", 36.0 * nq);  // query 24 B + result 12 B; the rest comes from the census below (0 if the census is off)
     const dim3 grid((max_n + NT - 1) / NT, (unsigned)jobs.size());
     if (c->nn_tree_only)
-      hipLaunchKernelGGL((nn_grid_kernel<true>), grid, dim3(NT), 0, c->stream, d_jobs, bound, d_stats, 0, (int2*)c->d_far_list, c->d_far_count);
+      hipLaunchKernelGGL((nn_grid_kernel<true>), grid, dim3(NT), 0, c->stream, d_jobs, bound, d_stats, 0, (int2*)c->d_far_list, c->d_far_count, 0.0);
     else
-      hipLaunchKernelGGL((nn_grid_kernel<false>), grid, dim3(NT), 0, c->stream, d_jobs, bound, d_stats, c->nn_skip_far ? 1 : 0, (int2*)c->d_far_list, c->d_far_count);
+      hipLaunchKernelGGL((nn_grid_kernel<false>), grid, dim3(NT), 0, c->stream, d_jobs, bound, d_stats, c->nn_skip_far ? 1 : 0, (int2*)c->d_far_list, c->d_far_count,
+                         c->prune_rho);
     // phase 2: persistent grid-stride launch (the far count is only known on the device)
     const unsigned int far_blocks = (unsigned int)std::min<size_t>(256 * 8, (total_q * 8 + NT - 1) / NT);
     hipLaunchKernelGGL(nn_far_kernel, dim3(far_blocks), dim3(NT), 0, c->stream, d_jobs, (const int2*)c->d_far_list, bound, c->d_far_count, d_stats, slots);
