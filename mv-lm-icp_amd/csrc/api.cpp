@@ -446,7 +446,7 @@ int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) {
   c->nn_cache_valid = false; c->prev_q.assign((size_t)E * 12, 0.0); c->nn_cache_edge.assign(E, 0);
   c->auto_prev_dist = 0.0; c->auto_last_method = -1;
   MV_CHECK(dev_alloc(&c->d_first, cap)); MV_CHECK(dev_alloc(&c->d_second, cap)); MV_CHECK(dev_alloc(&c->d_cd2, cap));
-  MV_CHECK(dev_alloc(&c->d_stream, 9 * cap));
+  MV_CHECK(dev_alloc(&c->d_stream, 10 * cap));
   MV_CHECK(dev_alloc(&c->d_qpos, cap));
   MV_HIP(hipMemset(c->d_qpos, 0xff, sizeof(int) * std::max<size_t>(cap, 1)));
   c->list_valid.assign(E, 0);

@@ -127,7 +127,7 @@ struct mvicp_ctx {
   int* d_dirty = nullptr;           // E: != 0 -> the edge's list (membership or a neighbour) changed this round: re-compact + re-gather
   int* d_dirty_slots = nullptr; int* d_dslot_off = nullptr; std::vector<int> dslot_off; int n_dslots = 0;  // one slot per 256 queries
   std::vector<char> list_valid;     // E: d_qpos / lists describe last round's result of this edge
-  double* d_stream = nullptr;       // 9 x total_cap SoA: px py pz qx qy qz nx ny nz
+  double* d_stream = nullptr;       // 10 x total_cap SoA: p (3) | n (3) | c = n . q | q (3)   (linearize.hip)
   // compaction scratch
   int n_cblocks = 0;                // total compaction blocks over owned edges
   std::vector<int> cblock_off;      // E+1

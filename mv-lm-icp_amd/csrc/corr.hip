@@ -9,8 +9,8 @@
 // distances is the sqrt of the median of d2; the host takes that one sqrt (IEEE, exact).
 //
 // The gather kernel also materialises, once per ICP round, the per-correspondence operand stream the
-// LM evaluations re-read up to ~100 times: SoA px py pz qx qy qz nx ny nz (72 B per correspondence,
-// coalesced) instead of 2 random 24-B gathers per evaluation.
+// LM evaluations re-read up to ~100 times: SoA p (3) | n (3) | c = n . q | q (3), 10 arrays, of which point-to-plane
+// streams 7 (56 B per correspondence) and point-to-point 6 — instead of 2-3 random 24-B gathers per evaluation.
 #include "common.h"
 
 namespace mvicp {
@@ -163,16 +163,19 @@ __global__ __launch_bounds__(NT) void gather_kernel(const int* __restrict__ cblo
     const double2 a0 = pa[0], a1 = pa[1];
     const double2* pb = reinterpret_cast<const double2*>(dp + s);
     const double2 b0 = pb[0], b1 = pb[1];
+    // arrays: 0-2 p | 3-5 n | 6 c = n . q | 7-9 q   (linearize.hip: point-to-plane reads 0..6, point-to-point 0-2 and 7-9)
     stream[0 * total_cap + o] = a0.x;
     stream[1 * total_cap + o] = a0.y;
     stream[2 * total_cap + o] = a1.x;
-    stream[3 * total_cap + o] = b0.x;
-    stream[4 * total_cap + o] = b0.y;
-    stream[5 * total_cap + o] = b1.x;
+    stream[7 * total_cap + o] = b0.x;
+    stream[8 * total_cap + o] = b0.y;
+    stream[9 * total_cap + o] = b1.x;
     if (dn != nullptr) {
-      stream[6 * total_cap + o] = dn[3 * s];
-      stream[7 * total_cap + o] = dn[3 * s + 1];
-      stream[8 * total_cap + o] = dn[3 * s + 2];
+      const double n0 = dn[3 * s], n1 = dn[3 * s + 1], n2 = dn[3 * s + 2];
+      stream[3 * total_cap + o] = n0;
+      stream[4 * total_cap + o] = n1;
+      stream[5 * total_cap + o] = n2;
+      stream[6 * total_cap + o] = n0 * b0.x + n1 * b0.y + n2 * b1.x;
     }
   }
 }

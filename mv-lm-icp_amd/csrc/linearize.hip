@@ -1,6 +1,12 @@
 // K5 — per-correspondence residual + analytic SE(3) Jacobian, robust weighting, block-reduced
 // J^T J / J^T r / cost per edge.  HBM-bandwidth bound: each LM evaluation streams the packed operand
-// stream once (72 B / correspondence point-to-plane, 48 B point-to-point), fully coalesced.
+// stream once (56 B / correspondence point-to-plane, 48 B point-to-point), fully coalesced.
+//
+// Operand stream (SoA, `total_cap` doubles per array, written once per round by the gather kernel, corr.hip):
+//   arrays 0-2 p (source point, src frame) | 3-5 n (dst normal) | 6 c = n . q | 7-9 q (dst point).
+// Point-to-plane needs q only through the scalar c:  r = n . (p~ - q) = n . p~ - c,  so it reads 7 arrays instead
+// of 9 (-22 % bytes on the kernel that dominates the LM phase).  The two forms of r differ by the rounding of two
+// O(|p~|) dot products, ~3e-16 absolute, i.e. ~1e-14 relative in the assembled g: far inside the 1e-11 block tolerance.
 //
 // Replaces what Ceres does with one AutoDiffCostFunction + SoftLOneLoss per correspondence
 // (src/internal/icp-ceres.cpp:270-292,360-378,435-453 on the functors of include/icp-ceres.h:49-316):
@@ -48,12 +54,12 @@ __device__ __forceinline__ double fast_rsqrt(double y) {
 template <bool PLANE, bool ROBUST>
 __device__ __forceinline__ void accumulate(double (&acc)[NACC], const double* __restrict__ A, const double* __restrict__ t, double inv_a2, double a2,
                                            double p0, double p1, double p2, double q0, double q1, double q2, double n0, double n1, double n2) {
+  // PLANE: (q0, q1, q2) = (c, -, -) with c = n . q;  POINT: (n0, n1, n2) unused
   const double x0 = A[0] * p0 + A[3] * p1 + A[6] * p2 + t[0];
   const double x1 = A[1] * p0 + A[4] * p1 + A[7] * p2 + t[1];
   const double x2 = A[2] * p0 + A[5] * p1 + A[8] * p2 + t[2];
-  const double f0 = x0 - q0, f1 = x1 - q1, f2 = x2 - q2;
   if (PLANE) {
-    const double r = n0 * f0 + n1 * f1 + n2 * f2;
+    const double r = (n0 * x0 + n1 * x1 + n2 * x2) - q0;
     double u[6];
     u[0] = n0; u[1] = n1; u[2] = n2;
     u[3] = x1 * n2 - x2 * n1; u[4] = x2 * n0 - x0 * n2; u[5] = x0 * n1 - x1 * n0;
@@ -75,6 +81,7 @@ __device__ __forceinline__ void accumulate(double (&acc)[NACC], const double* __
       acc[21 + i] += wu * r;
     }
   } else {
+    const double f0 = x0 - q0, f1 = x1 - q1, f2 = x2 - q2;
     const double s = f0 * f0 + f1 * f1 + f2 * f2;
     double w = 1.0;
     if (ROBUST) {
@@ -126,7 +133,9 @@ __global__ __launch_bounds__(NT) void linearize_kernel(const int* __restrict__ c
 
   const size_t base = (size_t)cap_off[e];  // multiple of 64 -> 16-B aligned double2 loads
   const double* __restrict__ s0 = stream + base;
-  constexpr int NS = PLANE ? 9 : 6;
+  constexpr int NS = PLANE ? 7 : 6;
+  // register slot j -> stream array: plane p n c = arrays 0..6; point p q = arrays 0-2, 7-9
+  auto arr = [](int j) { return PLANE ? j : (j < 3 ? j : j + 4); };
   // two adjacent correspondences per lane per step (16-B loads); the next step's loads are issued before
   // the current step's arithmetic so two steps of HBM latency overlap.
   int pos = start + 2 * threadIdx.x;
@@ -136,19 +145,26 @@ __global__ __launch_bounds__(NT) void linearize_kernel(const int* __restrict__ c
   auto load = [&](double2 (&v)[9], int at) {
     if (at + 1 < end) {
 #pragma unroll
-      for (int j = 0; j < NS; ++j) v[j] = *reinterpret_cast<const double2*>(s0 + (size_t)j * total_cap + at);
+      for (int j = 0; j < NS; ++j) v[j] = *reinterpret_cast<const double2*>(s0 + (size_t)arr(j) * total_cap + at);
     } else if (at < end) {
 #pragma unroll
-      for (int j = 0; j < NS; ++j) { v[j].x = s0[(size_t)j * total_cap + at]; v[j].y = 0.0; }
+      for (int j = 0; j < NS; ++j) { v[j].x = s0[(size_t)arr(j) * total_cap + at]; v[j].y = 0.0; }
     }
   };
   load(cur, pos);
   while (pos < end) {
     const int npos = pos + 2 * NT;
     load(nxt, npos);
-    accumulate<PLANE, ROBUST>(acc, A, t, inv_a2, a2, cur[0].x, cur[1].x, cur[2].x, cur[3].x, cur[4].x, cur[5].x, cur[6].x, cur[7].x, cur[8].x);
-    if (pos + 1 < end)
-      accumulate<PLANE, ROBUST>(acc, A, t, inv_a2, a2, cur[0].y, cur[1].y, cur[2].y, cur[3].y, cur[4].y, cur[5].y, cur[6].y, cur[7].y, cur[8].y);
+    // slots: plane 0-2 p, 3-5 n, 6 c;  point 0-2 p, 3-5 q
+    if (PLANE) {
+      accumulate<PLANE, ROBUST>(acc, A, t, inv_a2, a2, cur[0].x, cur[1].x, cur[2].x, cur[6].x, 0.0, 0.0, cur[3].x, cur[4].x, cur[5].x);
+      if (pos + 1 < end)
+        accumulate<PLANE, ROBUST>(acc, A, t, inv_a2, a2, cur[0].y, cur[1].y, cur[2].y, cur[6].y, 0.0, 0.0, cur[3].y, cur[4].y, cur[5].y);
+    } else {
+      accumulate<PLANE, ROBUST>(acc, A, t, inv_a2, a2, cur[0].x, cur[1].x, cur[2].x, cur[3].x, cur[4].x, cur[5].x, 0.0, 0.0, 0.0);
+      if (pos + 1 < end)
+        accumulate<PLANE, ROBUST>(acc, A, t, inv_a2, a2, cur[0].y, cur[1].y, cur[2].y, cur[3].y, cur[4].y, cur[5].y, 0.0, 0.0, 0.0);
+    }
 #pragma unroll
     for (int j = 0; j < 9; ++j) cur[j] = nxt[j];
     pos = npos;
@@ -308,7 +324,7 @@ int launch_linearize(mvicp_ctx* c, int plane, int robust) {
   const int chunk = c->lin_chunk;
   if (c->n_chunks > 0) {
     double bytes = 0;
-    for (int e = 0; e < c->E; ++e) if (c->owned[e]) bytes += (plane ? 72.0 : 48.0) * c->h_count[e];
+    for (int e = 0; e < c->E; ++e) if (c->owned[e]) bytes += (plane ? 56.0 : 48.0) * c->h_count[e];
     ProfScope ps(c, "linearize", bytes);
 #define LAUNCH(P, R)                                                                                                                           \
   hipLaunchKernelGGL((linearize_kernel<P, R>), dim3(c->n_chunks), dim3(NT), 0, c->stream, c->d_chunk_edge, c->d_chunk_start, chunk, c->d_count, \
