@@ -459,6 +459,50 @@ def test_temporal_cache_is_bit_identical_to_full_search(orc):
         e.close()
 
 
+@pytest.mark.parametrize("opts", [
+    {"tile_seed": 0}, {"tile_waves": 4}, {"tile_waves": 8}, {"prune_rho": 0.0}, {"prune_rho": 0.6},
+    {"auto_settle": 0.05}, {"auto_settle": 5.0}, {"nn_cache": 0, "list_reuse": 0}, {"spin_wait": 1},
+    {"grid_curve": 0}, {"grid_target": 2.5},
+])
+def test_tuning_options_never_change_results(opts):
+    """Every speed knob (kernel variants, seeding, cell pruning, AUTO hand-over policy, caches) must leave the whole ICP
+    trajectory bit-identical: counts, weights, correspondence lists every round, and the final poses.  The two knobs that
+    change the sorted order of the clouds (curve, cell size) change the summation order of the normal equations, so for
+    them the correspondences are bit-identical at equal poses (round 0) and the trajectory agrees to rounding."""
+    reorders = "grid_curve" in opts or "grid_target" in opts
+    pb = synth.make_problem(5, 5000)
+
+    def run(options):
+        e = mvicp.Engine(0)
+        for k, v in options.items():
+            e.set_option(k, v)
+        e.set_frames(pb["pts"], pb["nor"]); e.set_graph(pb["src"], pb["dst"])
+        poses = pb["init"].copy()
+        trace = []
+        for r in range(7):
+            c, w = e.correspond(poses, pb["fixed"], 0.05, L.NN_AUTO)
+            lists = [e.get_correspondences(k) for k in range(e.E)] if r in (0, 3, 6) else None
+            trace.append((c.copy(), w.copy(), lists))
+            poses, sm = e.optimize(poses, pb["fixed"], L.PARAM_SOPHUS_SE3, 1, True, 50)
+        e.close()
+        return trace, poses
+
+    base_trace, base_poses = run({})
+    trace, poses = run(opts)
+    for r, ((c0, w0, l0), (c1, w1, l1)) in enumerate(zip(base_trace, trace)):
+        if reorders and r > 0:
+            assert np.array_equal(c0, c1) and np.allclose(w0, w1, rtol=1e-6, atol=0), (opts, r)
+            continue
+        assert np.array_equal(c0, c1) and w0.tobytes() == w1.tobytes(), (opts, r)
+        if l0 is not None:
+            for a, b in zip(l0, l1):
+                assert all(np.array_equal(x, y) for x, y in zip(a, b)), (opts, r)
+    if reorders:
+        assert np.allclose(base_poses, poses, rtol=0, atol=1e-12), opts
+    else:
+        assert np.array_equal(base_poses, poses), opts
+
+
 # ---------------------------------------------------------------- error behaviour of the ABI
 def test_abi_error_paths(eng):
     pb = synth.make_problem(2, 500)
