@@ -46,7 +46,7 @@ enum mvicp_nn_method {
   MVICP_NN_AUTO = 0,
   MVICP_NN_BRUTE = 1, /* LDS-tiled exhaustive scan */
   MVICP_NN_GRID = 2,  /* per-query: spatial-hash (uniform grid) lookup with exact AABB-tree fallback */
-  MVICP_NN_TILE = 3   /* per-wave: 64 Morton-adjacent queries share a pruned brute force over LDS-staged 64-point tiles */
+  MVICP_NN_TILE = 3   /* per-wave: 64 curve-adjacent queries share a pruned brute force over LDS-staged 32-point tiles */
 };
 
 const char* mvicp_last_error(void);

@@ -628,7 +628,7 @@ int mvicp_get_correspondences(mvicp_ctx* c, int edge, int cap, int* first, int* 
   if (cap < n) { set_error("capacity %d < count %d", cap, n); return MVICP_ERR_ARG; }
   const size_t off = (size_t)c->cap_off[edge];
   MV_HIP(hipStreamSynchronize(c->stream));
-  // the device lists hold SORTED positions (Morton order of each cloud) in the source's sorted order; hand them back as
+  // the device lists hold SORTED positions (curve order of each cloud) in the source's sorted order; hand them back as
   // the reference builds them: original indices, ascending `first` (frame.cpp:129,158)
   std::vector<int> a(n), b(n);
   std::vector<double> d(n);

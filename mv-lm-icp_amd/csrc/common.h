@@ -44,7 +44,7 @@ struct GridDev {
   double origin[3] = {0, 0, 0};
   double cell = 0.0, inv_cell = 0.0;
   int n_cells = 0;             // occupied cells
-  double* spts = nullptr;      // n x 3 sorted by Morton(cell)
+  double* spts = nullptr;      // n x 3 sorted by the curve index (Hilbert by default) of the cell
   int* sidx = nullptr;         // n: original index of sorted point
   void* srec = nullptr;        // n x 32 B {x, y, z, idx}: the same, packed for the per-lane candidate scans
   double* snor = nullptr;      // n x 3 normals in sorted order (null without normals)

@@ -9,7 +9,7 @@
 //
 // Per cloud, built ONCE at upload (clouds are static in their local frame, like the reference's lazily
 // built tree, frame.cpp:188-193):
-//   * points sorted by the Morton code of their grid cell (cell edge h ~ a few point spacings);
+//   * points sorted by the Hilbert-curve index of their grid cell (cell edge h ~ a few point spacings);
 //     `spts` (sorted xyz) + `sidx` (original index).  The sorted order is also the QUERY order of a source
 //     cloud: neighbouring lanes ask about neighbouring places, so hash slots / point runs / tree nodes are
 //     shared inside a wave and stay in L2.

@@ -4,7 +4,7 @@
 // Frame::getClosestPoint, src/internal/frame.cpp:187-206, metric include/frame.h:70-76, query transform
 // frame.cpp:117-118,131,136; lowest original index wins exact ties).
 //
-// Both clouds are stored sorted by the Morton code of their grid cell (nn_grid.hip).  A WAVE owns 64
+// Both clouds are stored sorted by the Hilbert-curve index of their grid cell (nn_grid.hip).  A WAVE owns 64
 // consecutive sorted source points — a compact surface patch — and answers all 64 queries together:
 //   * the target cloud is cut into leaves of 64 consecutive sorted points; leaf boxes, boxes of 64 leaves,
 //     boxes of 64 of those ... form a 64-wide hierarchy (float AABBs rounded outward, SoA per level) so one
