@@ -147,7 +147,9 @@ int mvicp_lm_solve(int n_frames, int n_edges, const int* src, const int* dst, do
  * "nn_census" (0/1): count candidates / boxes / cache hits per launch while profiling (feeds the algorithmic-byte model).
  * "spin_wait" (0/1, default 0): poll the stream for up to 2 ms before blocking on the per-evaluation / per-round waits.
  * "tile_seed" (0/1, default 1): the tile kernel starts from last round's neighbours; "tile_waves" (4..8, default 6):
- * occupancy variant of the tile kernel.  Tuning knobs: results are bit-identical for every setting. */
+ * occupancy variant of the tile kernel; "sel_bracket" (0/1, default 1): one-pass median select around last round's median
+ * once it has settled; "prune_rho", "auto_settle", "grid_curve": see DESIGN.md.  Tuning knobs: correspondences are
+ * bit-identical for every setting. */
 int mvicp_set_option(mvicp_ctx* ctx, const char* name, double value);
 /* NN census accumulated while profiling and the "nn_census" option are on: out[0..4] = queries, candidate points
  * examined, tree boxes tested, queries that needed the tree fallback, queries answered by the temporal cache. */

@@ -435,12 +435,14 @@ int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) {
   MV_CHECK(dev_alloc(&c->d_esrc, E)); MV_CHECK(dev_alloc(&c->d_edst, E)); MV_CHECK(dev_alloc(&c->d_cap_off, E + 1));
   MV_CHECK(dev_alloc(&c->d_count, E));
   // control block (see common.h): region 1 = xf | nsrc | dirty, region 2 = rel | a
-  c->ctl_r1 = (size_t)E * kEdgeXf + (size_t)E;                 // 2E ints = E doubles
+  c->ctl_r1 = (size_t)E * kEdgeXf + (size_t)E + 2 * (size_t)E;  // xf | 2E ints = E doubles | select brackets (lo, hi) per edge
   c->ctl_r2_off = (c->ctl_r1 + 1) & ~(size_t)1;                // 16-B aligned
   c->ctl_r2 = (size_t)E * (kEdgeRel + 1);
   MV_CHECK(dev_alloc(&c->d_ctl, c->ctl_r2_off + c->ctl_r2));
   MV_HIP(hipMemset(c->d_ctl, 0, sizeof(double) * std::max<size_t>(c->ctl_r2_off + c->ctl_r2, 1)));
   c->d_xf = c->d_ctl; c->d_nsrc = reinterpret_cast<int*>(c->d_ctl + (size_t)E * kEdgeXf); c->d_dirty = c->d_nsrc + E;
+  c->d_sel_lohi = c->d_ctl + (size_t)E * (kEdgeXf + 1);
+  c->sel_med1.assign(E, -1.0); c->sel_med2.assign(E, -1.0);
   c->d_rel = c->d_ctl + c->ctl_r2_off; c->d_a = c->d_rel + (size_t)E * kEdgeRel;
   MV_CHECK(dev_alloc(&c->d_nn_idx, cap)); MV_CHECK(dev_alloc(&c->d_nn_d2, cap)); MV_CHECK(dev_alloc(&c->d_nn_lb, cap));
   c->nn_cache_valid = false; c->prev_q.assign((size_t)E * 12, 0.0); c->nn_cache_edge.assign(E, 0);
@@ -576,8 +578,21 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
     if (method == MVICP_NN_GRID && !c->nn_tree_only && !c->nn_skip_far && c->list_reuse)
       for (int e = 0; e < E; ++e) if (c->active[e] && c->list_valid[e]) dirty[e] = 0;
     std::memcpy(hd, dirty.data(), sizeof(int) * E);
-    MV_HIP(hipMemcpyAsync(c->d_ctl, hx, sizeof(double) * c->ctl_r1, hipMemcpyHostToDevice, c->stream));
   }
+  // One-pass bracket select (corr.hip) instead of the 3-pass radix select: only when EVERY active edge of this rank has a
+  // median that has settled (last two rounds within 0.1 %); the bracket is +-0.6 % in d2 around the last one.
+  bool use_bracket = c->sel_bracket && c->have_corr;
+  {
+    double* lohi = hx + (size_t)E * (kEdgeXf + 1);
+    for (int e = 0; e < E; ++e) {
+      lohi[2 * e] = lohi[2 * e + 1] = 0.0;
+      if (!c->active[e]) continue;
+      const double m1 = c->sel_med1[e], m2 = c->sel_med2[e];
+      if (!(m1 > 0.0 && m2 > 0.0 && std::fabs(m1 - m2) <= 0.001 * m1)) { use_bracket = false; continue; }
+      lohi[2 * e] = m1 * 0.994; lohi[2 * e + 1] = m1 * 1.006;
+    }
+  }
+  MV_HIP(hipMemcpyAsync(c->d_ctl, hx, sizeof(double) * c->ctl_r1, hipMemcpyHostToDevice, c->stream));
   if (method == MVICP_NN_BRUTE) MV_CHECK(launch_nn_brute_edges(c));
   else if (method == MVICP_NN_GRID) MV_CHECK(launch_nn_grid_edges(c, bound));
   else if (method == MVICP_NN_TILE) MV_CHECK(launch_nn_tile_edges(c, bound));
@@ -592,7 +607,7 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   mark("host.corr.nn_launch");
   MV_CHECK(launch_compact(c, bound));
   MV_CHECK(launch_gather_stream(c));
-  MV_CHECK(launch_select_median(c));
+  if (use_bracket) MV_CHECK(launch_select_bracket(c)); else MV_CHECK(launch_select_median(c));
   mark("host.corr.post_launch");
   // (count, median d2) per edge arrive in mapped host memory, written by select_final_kernel;
   // weight = (float)(1.5 * sqrt(median d2))  (frame.cpp:168-176)
@@ -600,6 +615,19 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   census_resolve(c);
   mark("host.corr.wait");
   const double* hr = c->h_pin + c->pin_res_off;
+  if (use_bracket) {
+    bool redo = false;
+    for (int e = 0; e < E; ++e) if (c->owned[e] && c->active[e] && hr[2 * e + 1] < 0.0) redo = true;
+    if (redo) {   // some median left its bracket: full select for everything (rare once the registration has settled)
+      MV_CHECK(launch_select_median(c));
+      MV_CHECK(stream_wait(c));
+    }
+  }
+  for (int e = 0; e < E; ++e) {
+    if (!(c->owned[e] && c->active[e])) { c->sel_med1[e] = c->sel_med2[e] = -1.0; continue; }
+    c->sel_med2[e] = c->sel_med1[e];
+    c->sel_med1[e] = hr[2 * e] > 0 ? hr[2 * e + 1] : -1.0;
+  }
   std::vector<double> pack(2 * (size_t)E, 0.0);
   for (int e = 0; e < E; ++e)
     if (c->owned[e] && c->active[e]) { pack[2 * e] = hr[2 * e]; pack[2 * e + 1] = hr[2 * e] > 0 ? hr[2 * e + 1] : 0.0; }
@@ -673,6 +701,7 @@ int mvicp_set_correspondences(mvicp_ctx* c, int edge, int n, const int* first, c
   }
   c->nn_cache_valid = false;
   c->list_valid[edge] = 0;
+  c->sel_med1[edge] = c->sel_med2[edge] = -1.0;
   const double a = (double)weight;
   MV_HIP(hipMemcpy(c->d_count + edge, &n, sizeof(int), hipMemcpyHostToDevice));
   MV_HIP(hipMemcpy(c->d_a + edge, &a, sizeof(double), hipMemcpyHostToDevice));
@@ -733,6 +762,7 @@ int mvicp_set_option(mvicp_ctx* c, const char* name, double value) {
   if (std::strcmp(name, "list_reuse") == 0) { c->list_reuse = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "nn_census") == 0) { c->nn_census = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "nn_skip_far") == 0) { c->nn_skip_far = value != 0.0; return MVICP_OK; }
+  if (std::strcmp(name, "sel_bracket") == 0) { c->sel_bracket = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "prune_rho") == 0) { c->prune_rho = value; return MVICP_OK; }
   if (std::strcmp(name, "grid_curve") == 0) { c->grid_curve = (int)value; return MVICP_OK; }   // takes effect at the next mvicp_set_frame
   if (std::strcmp(name, "auto_settle") == 0) { c->auto_settle = value; return MVICP_OK; }

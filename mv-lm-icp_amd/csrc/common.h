@@ -135,6 +135,9 @@ struct mvicp_ctx {
   // select scratch
   void* d_sel_state = nullptr; unsigned int* d_sel_hist = nullptr; double* d_median = nullptr;
   int n_sblocks = 0; std::vector<int> sblock_off; int* d_sblock_off = nullptr;   // kSelBlock keys per workgroup
+  double* d_sel_lohi = nullptr;      // view into the control block: per edge the bracket [lo, hi] (d2) of the one-pass select
+  std::vector<double> sel_med1, sel_med2;   // per owned edge: median d2 of the last / the one-before-last round (< 0: unknown)
+  bool sel_bracket = true;           // option: use the one-pass bracket select once the medians have settled
   double* d_sel_keys1 = nullptr; double* d_sel_keys2 = nullptr;                  // compact key buffers of passes B and C (total_cap each)
   // linearize chunks
   int lin_chunk_override = 0;
@@ -204,6 +207,7 @@ void free_grid(GridDev& g);
 int launch_compact(mvicp_ctx* c, double d2_bound);                                    // corr.hip
 int launch_gather_stream(mvicp_ctx* c);
 int launch_select_median(mvicp_ctx* c);
+int launch_select_bracket(mvicp_ctx* c);   // one-pass select around last round's medians (d_sel_lohi); flags edges it cannot answer
 int launch_linearize(mvicp_ctx* c, int plane, int robust);                            // linearize.hip
 int launch_normals(mvicp_ctx* c, FrameDev& f, int k, int* d_knn);                      // normals.hip
 int stream_wait(mvicp_ctx* c);      // api.cpp: wait for the context's stream (spin-polls first)

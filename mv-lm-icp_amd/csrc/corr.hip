@@ -369,6 +369,115 @@ __global__ __launch_bounds__(NT) void select_final_kernel(int E, const int* __re
   }
 }
 
+// ---- bracket select: when the registration has settled, the median of an edge barely moves between rounds.  ONE pass
+// over the keys counts those below a bracket [lo, hi] around last round's median and compacts the few per cent inside it;
+// one workgroup per edge then selects the wanted rank among the compacted keys in LDS.  Exact whenever the rank falls inside
+// the bracket; otherwise the edge's result slot is flagged (median = -1) and the host runs the full radix select.
+__global__ __launch_bounds__(NT) void bracket_pass_kernel(const int* __restrict__ sblock_off, int E, const int* __restrict__ count,
+                                                          const long long* __restrict__ cap_off, const double* __restrict__ keys,
+                                                          const double* __restrict__ lohi, unsigned int* __restrict__ cnt_lt,
+                                                          double* __restrict__ out_keys, unsigned int* __restrict__ out_cnt) {
+  constexpr int SPT = kSelBlock / NT;
+  __shared__ int wave_tot[NT / 64];
+  __shared__ unsigned int sh_base;
+  const int b = blockIdx.x;
+  const int e = find_edge(sblock_off, E, b);
+  const int lb = b - sblock_off[e];
+  const int cnt = count[e];
+  if ((long long)lb * kSelBlock >= cnt) return;
+  const unsigned long long lo = (unsigned long long)__double_as_longlong(lohi[2 * e]), hi = (unsigned long long)__double_as_longlong(lohi[2 * e + 1]);
+  const long long base = cap_off[e];
+  unsigned long long kept[SPT];
+  int nlt = 0, nmid = 0;
+#pragma unroll
+  for (int i = 0; i < SPT; ++i) {
+    const int pos = lb * kSelBlock + i * NT + threadIdx.x;
+    kept[i] = ~0ull;   // not a key (d2 >= 0 has bit 63 clear)
+    if (pos < cnt) {
+      const unsigned long long key = (unsigned long long)__double_as_longlong(keys[base + pos]);
+      if (key < lo) ++nlt;
+      else if (key <= hi) { kept[i] = key; ++nmid; }
+    }
+  }
+  int total_lt, total_mid;
+  block_exclusive_scan(nlt, wave_tot, &total_lt);
+  __syncthreads();
+  int off = block_exclusive_scan(nmid, wave_tot, &total_mid);
+  if (threadIdx.x == 0) {
+    if (total_lt) atomicAdd(&cnt_lt[e], (unsigned int)total_lt);
+    sh_base = total_mid ? atomicAdd(&out_cnt[e], (unsigned int)total_mid) : 0u;
+  }
+  __syncthreads();
+  off += (int)sh_base;
+#pragma unroll
+  for (int i = 0; i < SPT; ++i)
+    if (kept[i] != ~0ull) out_keys[base + off++] = __longlong_as_double((long long)kept[i]);
+}
+
+__global__ __launch_bounds__(NT) void bracket_final_kernel(int E, const int* __restrict__ count, const long long* __restrict__ cap_off,
+                                                           const double* __restrict__ keys1, const unsigned int* __restrict__ cnt_lt,
+                                                           const unsigned int* __restrict__ cnt_mid, double* __restrict__ median,
+                                                           double* __restrict__ host_res) {
+  __shared__ unsigned int lh[kSelBins];
+  __shared__ int wave_tot[NT / 64];
+  __shared__ int sh_pick[2];
+  const int e = blockIdx.x;
+  const int cnt = count[e];
+  double med = 0.0;
+  bool ok = true;
+  if (cnt > 0) {
+    const unsigned int k = (unsigned int)(cnt / 2), nlt = cnt_lt[e], nmid = cnt_mid[e];
+    ok = nlt <= k && k < nlt + nmid;
+    if (ok) {
+      unsigned long long prefix = 0ull;
+      unsigned int rank = k - nlt;
+      const long long base = cap_off[e];
+      // the compacted keys are few (about 1 % of the list): keep them in registers across the 6 digit passes
+      constexpr int KR = 8;
+      const bool in_regs = nmid <= (unsigned int)(KR * NT);
+      unsigned long long kreg[KR];
+#pragma unroll
+      for (int i = 0; i < KR; ++i) {
+        const unsigned int pos = threadIdx.x + i * NT;
+        kreg[i] = (in_regs && pos < nmid) ? (unsigned long long)__double_as_longlong(keys1[base + pos]) : ~0ull;
+      }
+      // 63 key bits, MSB first: 11 + 11 + 11 + 10 + 10 + 10
+      int hi_bit = 63;
+#pragma unroll 1
+      for (int pass = 0; pass < 6; ++pass) {
+        const int bits = pass < 3 ? 11 : 10;
+        const int shift = hi_bit - bits;
+        for (int i = threadIdx.x; i < kSelBins; i += NT) lh[i] = 0u;
+        __syncthreads();
+        if (in_regs) {
+#pragma unroll
+          for (int i = 0; i < KR; ++i) {   // (~0 never matches: bit 63 of the prefix is clear)
+            const unsigned long long key = kreg[i];
+            if ((key >> hi_bit) == (prefix >> hi_bit)) atomicAdd(&lh[(key >> shift) & ((1ull << bits) - 1ull)], 1u);
+          }
+        } else {
+          for (unsigned int pos = threadIdx.x; pos < nmid; pos += NT) {
+            const unsigned long long key = (unsigned long long)__double_as_longlong(keys1[base + pos]);
+            if ((key >> hi_bit) == (prefix >> hi_bit)) atomicAdd(&lh[(key >> shift) & ((1ull << bits) - 1ull)], 1u);
+          }
+        }
+        __syncthreads();
+        int bin; unsigned int below;
+        pick_bin<kSelBins / NT>([&](int i) { return lh[i]; }, rank, wave_tot, sh_pick, bin, below);
+        prefix |= (unsigned long long)bin << shift;
+        rank -= below;
+        hi_bit = shift;
+      }
+      med = __longlong_as_double((long long)prefix);
+    }
+  }
+  if (threadIdx.x == 0) {
+    if (ok) median[e] = med;
+    host_res[2 * e] = (double)(cnt > 0 ? cnt : 0);
+    host_res[2 * e + 1] = ok ? med : -1.0;   // -1: rank outside the bracket -> the host falls back to the full select
+  }
+}
+
 }  // namespace
 
 int launch_compact(mvicp_ctx* c, double d2_bound) {
@@ -401,6 +510,25 @@ int launch_gather_stream(mvicp_ctx* c) {
     hipLaunchKernelGGL(gather_kernel, dim3(c->n_cblocks), dim3(NT), 0, c->stream, c->d_cblock_off, c->E, c->d_count, c->d_cap_off, c->total_cap,
                        c->d_first, c->d_second, (const PointRec* const*)d_tab, (const PointRec* const*)(d_tab + c->E), (const double* const*)(d_tab + 2 * c->E), c->d_stream, c->d_dirty);
   }
+  MV_HIP(hipGetLastError());
+  return MVICP_OK;
+}
+
+int launch_select_bracket(mvicp_ctx* c) {
+  if (c->E == 0) return MVICP_OK;
+  double bytes = 0;
+  for (int e = 0; e < c->E; ++e) if (c->owned[e]) bytes += 8.0 * c->h_count[e];   // one full read of the key list
+  ProfScope ps(c, "select", bytes);
+  const size_t E = (size_t)c->E;
+  unsigned int* cnt_lt = c->d_sel_hist;   // reuses the histogram scratch: cnt_lt [E] | cnt_mid [E]
+  unsigned int* cnt_mid = cnt_lt + E;
+  if (c->n_sblocks) {
+    MV_HIP(hipMemsetAsync(cnt_lt, 0, sizeof(unsigned int) * 2 * E, c->stream));
+    hipLaunchKernelGGL(bracket_pass_kernel, dim3(c->n_sblocks), dim3(NT), 0, c->stream, c->d_sblock_off, c->E, c->d_count, c->d_cap_off, c->d_cd2,
+                       (const double*)c->d_sel_lohi, cnt_lt, c->d_sel_keys1, cnt_mid);
+  }
+  hipLaunchKernelGGL(bracket_final_kernel, dim3(c->E), dim3(NT), 0, c->stream, c->E, c->d_count, c->d_cap_off, c->d_sel_keys1, (const unsigned int*)cnt_lt,
+                     (const unsigned int*)cnt_mid, c->d_median, c->d_res_host);
   MV_HIP(hipGetLastError());
   return MVICP_OK;
 }
