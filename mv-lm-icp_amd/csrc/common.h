@@ -183,7 +183,7 @@ struct mvicp_ctx {
   bool tile_seed = true;           // tile kernel starts from last round's neighbours when there are any
   int tile_waves = 6;              // nn_tile_kernel variant: waves per SIMD it is compiled for (6 measured best)
   double auto_prev_dist = 0.0; int auto_last_method = -1; double auto_settle = 0.5;   // MVICP_NN_AUTO policy state (api.cpp)
-  double prune_rho = 0.25;         // grid kernel: with a seed, skip block cells farther than max(seed distance, prune_rho * cell edge); 0 = off
+  double prune_rho = 0.05;         // grid kernel: with a seed, skip block cells farther than seed distance + prune_rho * cell edge; 0 = off
   int grid_curve = 1;              // cell order of the sorted clouds: 0 Morton (Z-order), 1 Hilbert
   double grid_target = 6.0;        // points per occupied cell the cell-edge heuristic aims at
   double nn_candidates = 0, nn_nodes = 0, nn_far = 0, nn_queries = 0, nn_hits = 0;

@@ -165,7 +165,6 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
   __syncthreads();
   if (i >= job.n) return;
   const GridView& g = job.dst;
-  const double prune_rho2 = (prune_rho * g.h) * (prune_rho * g.h);
 
   double qx, qy, qz;
   {
@@ -189,8 +188,9 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
   // Last round's neighbour p1 (sorted position in out_idx, left there by whichever kernel ran) serves twice:
   //  * temporal cache (needs last round's lower bounds, i.e. a grid round): re-evaluate the distance and stop;
   //  * otherwise its distance bounds the search: the true neighbour lies within |q - p1| of q, so hash cells of the block
-  //    farther than r_p = max(|q - p1|, rho) need not be probed.  Everything in a skipped cell is farther than r_p, which
-  //    enters the lower bound handed to the next round's cache (rho ~ half a point spacing keeps that bound useful).
+  //    farther than r_p = |q - p1| + rho need not be probed.  Everything in a skipped cell is farther than r_p, which
+  //    enters the lower bound handed to the next round's cache: the margin rho (a fraction of the cell edge) is what lets
+  //    that bound survive the next pose update.
   double rp2 = -1.0;   // < 0: scan the whole block
   if (!TREE_ONLY && job.seed) {
     const int pi = job.out_idx[out];   // sorted position of last round's neighbour
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
           return;
         }
       }
-      if (prune_rho2 > 0.0) rp2 = fmax(d, prune_rho2) * 1.002;
+      if (prune_rho > 0.0) { const double rp = sqrt(d) + prune_rho * g.h; rp2 = rp * rp * 1.002; }
     }
   }
 
