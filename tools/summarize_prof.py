@@ -18,7 +18,7 @@ warmup = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 19
 
 KERNELS = ("nn_grid_kernel", "nn_far_kernel", "nn_tile_kernel", "nn_brute_kernel", "nn_brute_merge_kernel", "dirty_reduce_kernel", "census_sum_kernel",
-           "linearize_kernel", "reduce_expand_kernel", "gather_kernel", "scatter_kernel", "count_kernel", "scan_kernel", "select_pass_kernel", "select_pick_kernel",
+           "linearize_kernel", "reduce_expand_kernel", "gather_kernel", "scatter_kernel", "count_kernel", "scan_kernel", "select_pass_kernel", "select_pick_kernel", "bracket_pass_kernel", "bracket_final_kernel",
            "select_final_kernel", "normals_kernel")
 NN_SCOPE = ("nn_grid_kernel", "nn_far_kernel", "nn_tile_kernel", "nn_brute_kernel", "nn_brute_merge_kernel", "dirty_reduce_kernel", "census_sum_kernel")
 NN_HEAD = ("nn_grid_kernel", "nn_tile_kernel", "nn_brute_kernel")  # first kernel of an NN stage
