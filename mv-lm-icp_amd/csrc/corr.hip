@@ -1,4 +1,4 @@
-// K3/K4 — cutoff filter + stable compaction, packed-stream gather, exact median (radix select).
+// K3/K4 — cutoff filter + stable compaction, packed-stream gather, exact median (compacting radix select / bracket select).
 //
 // Replaces the tail of Frame::computeClosestPointsToNeighbours (src/internal/frame.cpp:156-176):
 //   if (sqrt(d2) < thresh) push {k, idx, dist}        -> flag / exclusive scan / scatter, ascending k

@@ -6,18 +6,21 @@
 //
 // Both clouds are stored sorted by the Hilbert-curve index of their grid cell (nn_grid.hip).  A WAVE owns 64
 // consecutive sorted source points — a compact surface patch — and answers all 64 queries together:
-//   * the target cloud is cut into leaves of 64 consecutive sorted points; leaf boxes, boxes of 64 leaves,
+//   * the target cloud is cut into leaves of LEAF = 32 consecutive sorted points; leaf boxes, boxes of 64 leaves,
 //     boxes of 64 of those ... form a 64-wide hierarchy (float AABBs rounded outward, SoA per level) so one
 //     coalesced load hands every lane ONE child box of the current node;
-//   * a child is opened iff at least one lane still needs it: coarse cull = child box vs the patch's own
-//     AABB inflated by the largest running best (all children tested in parallel, one per lane), then an
-//     exact per-lane test `lb(q_lane, box) <= best_lane` (ballot).  lb uses the same rounded operations as the
-//     point distance, every rounding is monotone, hence lb <= d2 for every point inside: pruning is exact;
-//   * an opened leaf is staged once into LDS (coalesced) and every lane scans its 64 points from LDS
-//     (broadcast reads, conflict-free) keeping its running (d2, index) minimum — the K1 inner loop on a
-//     culled candidate set.  Children are opened nearest-first (wave arg-min by shuffles) so the running
-//     minima tighten before the siblings are tested.
-// No per-lane pointer chasing, no divergence between "near" and "far" queries: the round-1 regime
+//   * a child is opened iff at least one lane still needs it: coarse cull = child box vs the patch's own AABB
+//     against the largest per-lane threshold of the wave (all children tested in parallel, one per lane), then a
+//     per-lane fp32 test of the box against the lane's own threshold (ballot).  Thresholds carry a rigorous guard
+//     band for the fp32 conversions (see leaf_scan), so a box or point is only ever skipped when it is provably
+//     farther than the lane's running best; whatever passes is re-evaluated in the reference's fp64 arithmetic;
+//   * an opened leaf is staged once into LDS (coalesced) and every lane screens its 32 points from LDS (broadcast
+//     reads, conflict-free, four candidates per step in packed fp32), confirming the few that pass in fp64 and
+//     keeping its running (d2, index) minimum.  Children are opened nearest-first (wave arg-min on the DPP network)
+//     so the running minima tighten before the siblings are tested;
+//   * from the second round on every lane starts from last round's neighbour (an ordinary candidate).
+// The kernel is VALU-issue bound (not memory bound): its design minimises wave instructions per opened tile.
+// No per-lane pointer chasing, no divergence between "near" and "far" queries: the first-round regime
 // (centimetre misalignment) and the converged regime run the same code, the former just opens more leaves.
 #include <algorithm>
 #include <cmath>
