@@ -146,7 +146,7 @@ int mvicp_lm_solve(int n_frames, int n_edges, const int* src, const int* dst, do
  * nearest after the pose update skips the search (results are bit-identical either way).
  * "nn_census" (0/1): count candidates / boxes / cache hits per launch while profiling (feeds the algorithmic-byte model).
  * "spin_wait" (0/1, default 0): poll the stream for up to 2 ms before blocking on the per-evaluation / per-round waits.
- * "tile_seed" (0/1, default 1): the tile kernel starts from last round's neighbours; "tile_waves" (4..8, default 6):
+ * "tile_seed" (0/1, default 1): the tile kernel starts from last round's neighbours; "tile_waves" (0 = auto, 4..8):
  * occupancy variant of the tile kernel; "sel_bracket" (0/1, default 1): one-pass median select around last round's median
  * once it has settled; "prune_rho", "auto_settle", "grid_curve": see DESIGN.md.  Tuning knobs: correspondences are
  * bit-identical for every setting. */

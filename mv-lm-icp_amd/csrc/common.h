@@ -181,7 +181,7 @@ struct mvicp_ctx {
   bool far_count_clean = false;    // the last grid launch left the counter zeroed (dirty_reduce_kernel)
   bool nn_skip_far = false;        // PROFILING ONLY: leave unresolved queries unresolved (wrong results)
   bool tile_seed = true;           // tile kernel starts from last round's neighbours when there are any
-  int tile_waves = 6;              // nn_tile_kernel variant: waves per SIMD it is compiled for (6 measured best)
+  int tile_waves = 0;              // nn_tile_kernel variant: waves per SIMD it is compiled for (0 = the measured best for the depth)
   double auto_prev_dist = 0.0; int auto_last_method = -1; double auto_settle = 0.5;   // MVICP_NN_AUTO policy state (api.cpp)
   double prune_rho = 0.05;         // grid kernel: with a seed, skip block cells farther than seed distance + prune_rho * cell edge; 0 = off
   int grid_curve = 1;              // cell order of the sorted clouds: 0 Morton (Z-order), 1 Hilbert

@@ -298,7 +298,9 @@ __device__ void visit(const TileView& g, int first, int nchild, Lane& L, const G
   }
 }
 
-template <int WPE>
+// TOP >= 0: every target of the launch has exactly TOP + 1 hierarchy levels (the common case: clouds of similar size), so
+// only that traversal is compiled in; TOP = -1: generic (per-job switch over the depth).
+template <int WPE, int TOP>
 __global__ __launch_bounds__(NT, WPE) void nn_tile_kernel(const TileJob* __restrict__ jobs, double bound, unsigned long long* __restrict__ stats) {
   __shared__ TileLds s_tile[NT / 64];
   __shared__ float2 s_box[NT / 64][2 * 3 * FAN];   // levels 1 and 2: 64 child boxes x 24 B each, per wave
@@ -354,7 +356,8 @@ __global__ __launch_bounds__(NT, WPE) void nn_tile_kernel(const TileJob* __restr
   const int top = g.levels - 1;
   TileLds* T = &s_tile[wave];
   float2* sbox = s_box[wave];
-  switch (top) {
+  if (TOP >= 0) visit<(TOP >= 0 ? TOP : 0)>(g, 0, g.cnt[TOP >= 0 ? TOP : 0], L, G, T, sbox, &n_cand, &n_box);
+  else switch (top) {
     case 0: visit<0>(g, 0, g.cnt[0], L, G, T, sbox, &n_cand, &n_box); break;
     case 1: visit<1>(g, 0, g.cnt[1], L, G, T, sbox, &n_cand, &n_box); break;
     case 2: visit<2>(g, 0, g.cnt[2], L, G, T, sbox, &n_cand, &n_box); break;
@@ -484,13 +487,21 @@ int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound) {
   {
     ProfScope ps(c, "nn", 36.0 * nq);  // query read 24 B + result write 12 B; candidate / box bytes come from the census
     const dim3 grid((max_n + NT - 1) / NT, (unsigned)jobs.size());
-    switch (c->tile_waves) {   // waves per SIMD the kernel is compiled for (register budget 512 / n); tuning knob, same results
-      case 4: hipLaunchKernelGGL((nn_tile_kernel<4>), grid, dim3(NT), 0, c->stream, d_jobs, d2_bound, d_stats); break;
-      case 8: hipLaunchKernelGGL((nn_tile_kernel<8>), grid, dim3(NT), 0, c->stream, d_jobs, d2_bound, d_stats); break;
-      case 7: hipLaunchKernelGGL((nn_tile_kernel<7>), grid, dim3(NT), 0, c->stream, d_jobs, d2_bound, d_stats); break;
-      case 5: hipLaunchKernelGGL((nn_tile_kernel<5>), grid, dim3(NT), 0, c->stream, d_jobs, d2_bound, d_stats); break;
-      default: hipLaunchKernelGGL((nn_tile_kernel<6>), grid, dim3(NT), 0, c->stream, d_jobs, d2_bound, d_stats); break;
+    int top = jobs[0].dst.levels - 1;   // same depth everywhere -> the traversal specialised for it
+    for (const TileJob& j : jobs) if (j.dst.levels - 1 != top) top = -1;
+#define MVICP_TILE_LAUNCH(W, T) hipLaunchKernelGGL((nn_tile_kernel<W, T>), grid, dim3(NT), 0, c->stream, d_jobs, d2_bound, d_stats)
+    const int waves = c->tile_waves;   // 0 = pick: measured best is 8 waves per SIMD for the depth-3 build, 6 otherwise
+    if (top == 2 && (waves == 0 || waves == 8)) MVICP_TILE_LAUNCH(8, 2);
+    else if (top == 2 && waves == 7) MVICP_TILE_LAUNCH(7, 2);
+    else if (top == 2 && waves == 6) MVICP_TILE_LAUNCH(6, 2);
+    else if (top == 1 && (waves == 0 || waves == 6)) MVICP_TILE_LAUNCH(6, 1);
+    else switch (waves) {   // generic depth: waves per SIMD the kernel is compiled for (register budget 512 / n); tuning knob, same results
+      case 4: MVICP_TILE_LAUNCH(4, -1); break;
+      case 8: MVICP_TILE_LAUNCH(8, -1); break;
+      case 5: MVICP_TILE_LAUNCH(5, -1); break;
+      default: MVICP_TILE_LAUNCH(6, -1); break;
     }
+#undef MVICP_TILE_LAUNCH
   }
   MV_HIP(hipGetLastError());
   if (d_stats) {
