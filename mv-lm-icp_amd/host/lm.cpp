@@ -48,11 +48,33 @@ struct Assembler {
   // envelope, so a solve costs O(n * bandwidth) per pass instead of O(n^2)), g (n); returns cost
   double assemble(const double* x, const double* blocks, double* H, double* g, const int* env) {
     const int A = se3::ambient(param), nn = n();
-    for (int i = 0; i < K; ++i) se3::local_to_canonical(param, x + (size_t)i * A, &M[(size_t)i * 36]);
+    if (param != MVICP_PARAM_SOPHUS_SE3) for (int i = 0; i < K; ++i) se3::local_to_canonical(param, x + (size_t)i * A, &M[(size_t)i * 36]);
     for (int i = 0; i < nn; ++i) std::fill(H + (size_t)i * nn + env[i], H + (size_t)i * nn + (i / 6) * 6 + 6, 0.0);   // up to the end of the diagonal block
     std::fill(g, g + nn, 0.0);
     double cost = 0.0;
     double Hc[12][12], T[6][6], Hl[6][6];
+    if (param == MVICP_PARAM_SOPHUS_SE3) {
+      // M = I for every pose: the canonical blocks ARE the local ones (packed upper triangle of the 12x12, row by row)
+      for (int e = 0; e < E; ++e) {
+        const double* b = blocks + (size_t)e * MVICP_EDGE_BLOCK;
+        cost += b[90];
+        const int fr[2] = {fidx[src[e]], fidx[dst[e]]};
+        for (int bi = 0; bi < 2; ++bi)
+          if (fr[bi] >= 0) for (int l = 0; l < 6; ++l) g[fr[bi] * 6 + l] += b[78 + bi * 6 + l];
+        int o = 0;
+        for (int i = 0; i < 12; ++i)
+          for (int j = i; j < 12; ++j, ++o) {
+            const int bi = i / 6, bj = j / 6;
+            if (fr[bi] < 0 || fr[bj] < 0) continue;
+            const int r = fr[bi] * 6 + i % 6, c2 = fr[bj] * 6 + j % 6;
+            // lower block triangle; inside a diagonal block both triangles are kept (the factorisation reads the lower one)
+            if (fr[bi] > fr[bj]) H[(size_t)r * nn + c2] += b[o];
+            else if (fr[bi] < fr[bj]) H[(size_t)c2 * nn + r] += b[o];
+            else { H[(size_t)r * nn + c2] += b[o]; if (r != c2) H[(size_t)c2 * nn + r] += b[o]; }
+          }
+      }
+      return cost;
+    }
     for (int e = 0; e < E; ++e) {
       const double* b = blocks + (size_t)e * MVICP_EDGE_BLOCK;
       cost += b[90];
@@ -149,7 +171,9 @@ int lm_solve(int K, int E, const int* src, const int* dst, double* poses, unsign
   const int A = se3::ambient(param);
   Assembler as(K, E, src, dst, fixed, param);
   const int n = as.n();
-  std::vector<double> x((size_t)K * A), xc((size_t)K * A), pc((size_t)K * 16), blocks((size_t)std::max(E, 1) * MVICP_EDGE_BLOCK);
+  static thread_local std::vector<double> ws_x, ws_xc, ws_pc, ws_blocks;   // reused across solves (no allocation / zeroing per ICP round)
+  ws_x.resize((size_t)K * A); ws_xc.resize((size_t)K * A); ws_pc.resize((size_t)K * 16); ws_blocks.resize((size_t)std::max(E, 1) * MVICP_EDGE_BLOCK);
+  std::vector<double>& x = ws_x; std::vector<double>& xc = ws_xc; std::vector<double>& pc = ws_pc; std::vector<double>& blocks = ws_blocks;
   for (int i = 0; i < K; ++i) se3::pose_to_x(param, poses + 16 * (size_t)i, &x[(size_t)i * A]);
   auto poses_of = [&](const std::vector<double>& xv, double* P) { for (int i = 0; i < K; ++i) se3::x_to_pose(param, &xv[(size_t)i * A], P + 16 * (size_t)i); };
   auto xnorm = [&](const std::vector<double>& v) { double s = 0; for (int i = 0; i < K; ++i) if (!fixed[i]) for (int a = 0; a < A; ++a) s += v[i * A + a] * v[i * A + a]; return std::sqrt(s); };
