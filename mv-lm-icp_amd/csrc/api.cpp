@@ -466,6 +466,14 @@ int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) {
   MV_CHECK(dev_alloc(&c->d_sblock_off, (size_t)E + 1));
   MV_HIP(hipMemcpy(c->d_sblock_off, c->sblock_off.data(), sizeof(int) * (E + 1), hipMemcpyHostToDevice));
   MV_CHECK(dev_alloc(&c->d_sel_keys1, cap)); MV_CHECK(dev_alloc(&c->d_sel_keys2, cap));
+  // the grid kernel's far-query list (worst case every query): allocated here, not lazily inside the first grid launch — a
+  // 100 MB hipMalloc in the middle of an ICP loop costs milliseconds
+  if (cap > c->far_cap) {
+    if (c->d_far_list) MV_HIP(hipFree(c->d_far_list));
+    c->d_far_list = nullptr; c->far_cap = 0;
+    MV_HIP(hipMalloc(&c->d_far_list, sizeof(int) * 2 * cap));
+    c->far_cap = cap;
+  }
   MV_CHECK(dev_alloc(&c->d_median, E));
   MV_CHECK(dev_alloc(&c->d_chunk_edge, (size_t)c->n_chunks)); MV_CHECK(dev_alloc(&c->d_chunk_start, (size_t)c->n_chunks));
   MV_CHECK(dev_alloc(&c->d_chunk_first, E + 1));

@@ -164,18 +164,18 @@ __global__ __launch_bounds__(NT) void gather_kernel(const int* __restrict__ cblo
     const double2* pb = reinterpret_cast<const double2*>(dp + s);
     const double2 b0 = pb[0], b1 = pb[1];
     // arrays: 0-2 p | 3-5 n | 6 c = n . q | 7-9 q   (linearize.hip: point-to-plane reads 0..6, point-to-point 0-2 and 7-9)
-    stream[0 * total_cap + o] = a0.x;
-    stream[1 * total_cap + o] = a0.y;
-    stream[2 * total_cap + o] = a1.x;
-    stream[7 * total_cap + o] = b0.x;
-    stream[8 * total_cap + o] = b0.y;
-    stream[9 * total_cap + o] = b1.x;
+    __builtin_nontemporal_store(a0.x, &stream[0 * total_cap + o]);
+    __builtin_nontemporal_store(a0.y, &stream[1 * total_cap + o]);
+    __builtin_nontemporal_store(a1.x, &stream[2 * total_cap + o]);
+    __builtin_nontemporal_store(b0.x, &stream[7 * total_cap + o]);
+    __builtin_nontemporal_store(b0.y, &stream[8 * total_cap + o]);
+    __builtin_nontemporal_store(b1.x, &stream[9 * total_cap + o]);
     if (dn != nullptr) {
       const double n0 = dn[3 * s], n1 = dn[3 * s + 1], n2 = dn[3 * s + 2];
-      stream[3 * total_cap + o] = n0;
-      stream[4 * total_cap + o] = n1;
-      stream[5 * total_cap + o] = n2;
-      stream[6 * total_cap + o] = n0 * b0.x + n1 * b0.y + n2 * b1.x;
+      __builtin_nontemporal_store(n0, &stream[3 * total_cap + o]);
+      __builtin_nontemporal_store(n1, &stream[4 * total_cap + o]);
+      __builtin_nontemporal_store(n2, &stream[5 * total_cap + o]);
+      __builtin_nontemporal_store(n0 * b0.x + n1 * b0.y + n2 * b1.x, &stream[6 * total_cap + o]);
     }
   }
 }
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(NT) void select_pass_kernel(const int* __restrict__
     bool match = pos < n_in;
     unsigned long long key = 0ull;
     if (match) {
-      key = (unsigned long long)__double_as_longlong(in_keys[base + pos]);
+      key = (unsigned long long)__double_as_longlong(__builtin_nontemporal_load(&in_keys[base + pos]));
       if (PASS > 0) match = (key >> (SHIFT + 11)) == (st.prefix >> (SHIFT + 11));
     }
     const unsigned int bin = (unsigned int)(key >> SHIFT) & (kSelBins - 1);
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(NT) void bracket_pass_kernel(const int* __restrict_
     const int pos = lb * kSelBlock + i * NT + threadIdx.x;
     kept[i] = ~0ull;   // not a key (d2 >= 0 has bit 63 clear)
     if (pos < cnt) {
-      const unsigned long long key = (unsigned long long)__double_as_longlong(keys[base + pos]);
+      const unsigned long long key = (unsigned long long)__double_as_longlong(__builtin_nontemporal_load(&keys[base + pos]));
       if (key < lo) ++nlt;
       else if (key <= hi) { kept[i] = key; ++nmid; }
     }

