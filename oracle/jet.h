@@ -33,7 +33,9 @@ template <int N> inline Jet<N> operator*(const Jet<N>& f, const Jet<N>& g) {
 template <int N> inline Jet<N> operator/(const Jet<N>& f, const Jet<N>& g) {
   // ceres/jet.h: h = f/g ; h.v = (f.v - h.a * g.v) / g.a
   Jet<N> h; const double ginv = 1.0 / g.a; h.a = f.a * ginv;
-  for (int i = 0; i < N; ++i) h.v[i] = (f.v[i] - h.a * g.v[i]) * ginv; return h; }
+  for (int i = 0; i < N; ++i) h.v[i] = (f.v[i] - h.a * g.v[i]) * ginv;
+  return h;
+}
 template <int N> inline Jet<N> operator+(const Jet<N>& f, double s) { Jet<N> h = f; h.a += s; return h; }
 template <int N> inline Jet<N> operator+(double s, const Jet<N>& f) { Jet<N> h = f; h.a += s; return h; }
 template <int N> inline Jet<N> operator-(const Jet<N>& f, double s) { Jet<N> h = f; h.a -= s; return h; }
@@ -44,7 +46,9 @@ template <int N> inline Jet<N> operator*(double s, const Jet<N>& f) { return f *
 template <int N> inline Jet<N> operator/(const Jet<N>& f, double s) { return f * (1.0 / s); }
 template <int N> inline Jet<N> operator/(double s, const Jet<N>& g) {
   Jet<N> h; h.a = s / g.a; const double m = -s / (g.a * g.a);
-  for (int i = 0; i < N; ++i) h.v[i] = g.v[i] * m; return h; }
+  for (int i = 0; i < N; ++i) h.v[i] = g.v[i] * m;
+  return h;
+}
 template <int N> inline Jet<N>& operator+=(Jet<N>& f, const Jet<N>& g) { f = f + g; return f; }
 template <int N> inline Jet<N>& operator-=(Jet<N>& f, const Jet<N>& g) { f = f - g; return f; }
 template <int N> inline Jet<N>& operator*=(Jet<N>& f, const Jet<N>& g) { f = f * g; return f; }
@@ -59,17 +63,25 @@ template <int N> inline bool operator<=(const Jet<N>& f, double s) { return f.a 
 
 template <int N> inline Jet<N> sqrt(const Jet<N>& f) {
   Jet<N> h; h.a = std::sqrt(f.a); const double k = 1.0 / (2.0 * h.a);
-  for (int i = 0; i < N; ++i) h.v[i] = f.v[i] * k; return h; }
+  for (int i = 0; i < N; ++i) h.v[i] = f.v[i] * k;
+  return h;
+}
 template <int N> inline Jet<N> sin(const Jet<N>& f) {
   Jet<N> h; h.a = std::sin(f.a); const double c = std::cos(f.a);
-  for (int i = 0; i < N; ++i) h.v[i] = c * f.v[i]; return h; }
+  for (int i = 0; i < N; ++i) h.v[i] = c * f.v[i];
+  return h;
+}
 template <int N> inline Jet<N> cos(const Jet<N>& f) {
   Jet<N> h; h.a = std::cos(f.a); const double s = -std::sin(f.a);
-  for (int i = 0; i < N; ++i) h.v[i] = s * f.v[i]; return h; }
+  for (int i = 0; i < N; ++i) h.v[i] = s * f.v[i];
+  return h;
+}
 template <int N> inline Jet<N> atan2(const Jet<N>& g, const Jet<N>& f) {
   // d atan2(g,f) = (f dg - g df) / (f^2 + g^2)
   Jet<N> h; h.a = std::atan2(g.a, f.a); const double k = 1.0 / (f.a * f.a + g.a * g.a);
-  for (int i = 0; i < N; ++i) h.v[i] = (f.a * g.v[i] - g.a * f.v[i]) * k; return h; }
+  for (int i = 0; i < N; ++i) h.v[i] = (f.a * g.v[i] - g.a * f.v[i]) * k;
+  return h;
+}
 
 inline double sqrt(double x) { return std::sqrt(x); }
 inline double sin(double x) { return std::sin(x); }
