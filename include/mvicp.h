@@ -3,7 +3,8 @@
  * This is the drop-in boundary.  The reference (adrelino/mv-lm-icp) has no FFI: its
  * seams are plain C++ members/free functions.  Each entry point below names the reference interface
  * it replaces (file:line relative to the reference tree).  Plain pointers and sizes only; every call
- * returns 0 on success or a negative mvicp_status, and mvicp_last_error() holds the message.  The
+ * returns 0 on success or a negative mvicp_status (one exception, stated at its declaration: mvicp_get_correspondences
+ * returns the number of triples it wrote, >= 0), and mvicp_last_error() holds the message.  Test `< 0` for failure.  The
  * library owns all device memory; the caller owns every host buffer it passes.  One context drives
  * one GPU (one process per GPU; see mvicp_set_shard / mvicp_comm_init for the multi-GPU path).
  *
@@ -67,7 +68,9 @@ int mvicp_set_frame(mvicp_ctx* ctx, int frame, const double* xyz, const double* 
 /* Replaces Frame::recomputeNormals() (include/frame.h:49, src/internal/frame.cpp:244-255; on by default in the reference,
  * main_multiview.cpp:49,68-70): normal of every point = eigenvector of the smallest eigenvalue of the covariance of its
  * k nearest points INCLUDING itself (reference k = 10), flipped so n_z <= 0 (include/common.h:331-346).  Overwrites the
- * frame's device normals; nrm_out (n x 3) and knn_out (n x k original indices, nearest first) may be NULL. */
+ * frame's device normals; nrm_out (n x 3) and knn_out (n x k original indices, nearest first) may be NULL.  May be called
+ * at any time: correspondence lists that point into this frame are re-gathered with the new normals (the reference reads
+ * dstCloud.nor when it builds the problem, icp-ceres.cpp:270-292). */
 int mvicp_recompute_normals(mvicp_ctx* ctx, int frame, int k, double* nrm_out, int* knn_out);
 
 /* Pose graph = all Frame::neighbours[j].neighbourIdx (frame.cpp:67-89 builds it; main_multiview.cpp:
@@ -101,7 +104,9 @@ int mvicp_comm_set_callback(mvicp_ctx* ctx, mvicp_allreduce_fn fn, void* user);
  *            (float)(1.5 * upper median distance) (frame.cpp:166-176).  weight of an empty edge = 0. */
 int mvicp_correspond(mvicp_ctx* ctx, const double* poses, const unsigned char* fixed, float thresh, int nn_method,
                      int* counts, float* weights);
-/* Copy edge e's list back as Frame::neighbours[j].correspondances (frame.h:18-22): ascending `first`. */
+/* Copy edge e's list back as Frame::neighbours[j].correspondances (frame.h:18-22): ascending `first`.
+ * RETURNS THE NUMBER OF TRIPLES WRITTEN (>= 0, = counts[e] of the last mvicp_correspond) or a negative mvicp_status;
+ * cap is the capacity of the three output arrays (each may be NULL to skip that field). */
 int mvicp_get_correspondences(mvicp_ctx* ctx, int edge, int cap, int* first, int* second, double* dist);
 /* Install an explicit list (pairwise known-correspondence case, main_pairwise.cpp:60-61; tests). */
 int mvicp_set_correspondences(mvicp_ctx* ctx, int edge, int n, const int* first, const int* second, float weight);
@@ -121,7 +126,9 @@ int mvicp_linearize(mvicp_ctx* ctx, const double* poses, int point_to_plane, int
 /* ---- S2: the LM solve ----------------------------------------------------------------------------
  * Replaces ICP_Ceres::ceresOptimizer / _ceresAngleAxis / _sophusSE3 (frames, pointToPlane, robust)
  * (include/icp-ceres.h:40-42; caller main_multiview.cpp:158-161).  poses in/out (frames[i]->pose).
- * fixed[0] is forced to 1 like icp-ceres.cpp:244,341,417. */
+ * fixed[0] is forced to 1 like icp-ceres.cpp:244,341,417.  Edges whose SOURCE frame is fixed contribute nothing (no cost, no
+ * normal-equation terms), whatever correspondences they hold: the reference adds no residual blocks for them
+ * (`if(srcCloud.fixed) continue;` icp-ceres.cpp:255,351,426).  An edge with a fixed DESTINATION keeps its residuals. */
 typedef struct mvicp_summary {
   double initial_cost, final_cost;
   int iterations;        /* LM iterations after the initial evaluation (<= max_iterations) */
@@ -138,6 +145,15 @@ int mvicp_optimize(mvicp_ctx* ctx, double* poses, unsigned char* fixed, int para
 typedef int (*mvicp_eval_fn)(void* user, const double* poses, double* blocks);
 int mvicp_lm_solve(int n_frames, int n_edges, const int* src, const int* dst, double* poses, unsigned char* fixed, int param,
                    int max_iterations, mvicp_eval_fn eval, void* user, mvicp_summary* summary);
+
+/* ---- closed-form pairwise solvers (host only; no GPU touched) ----------------------------------------
+ * Replace ICP_Closedform::pointToPoint / pointToPlane (include/icp-closedform.h:10-11, src/internal/icp-closedform.cpp:9-26,
+ * 30-54): the reference's comparison baselines in main_pairwise.cpp:74-76,93-95 and an independent check of the
+ * point-to-point / point-to-plane normal equations.  Index-aligned pairs (src[i], dst[i]) (and nor[i], the normal at dst[i]);
+ * pose_out = the src -> dst transform, 16 doubles column-major.  point_to_point: the least-squares rigid transform (exact);
+ * point_to_plane: one linearised step from identity with R = Rx Ry Rz of the three solved angles (icp-closedform.cpp:47-51). */
+int mvicp_closedform_point_to_point(const double* src, const double* dst, int n, double* pose_out);
+int mvicp_closedform_point_to_plane(const double* src, const double* dst, const double* nor, int n, double* pose_out);
 
 /* Tuning / test switches.  "nn_tree_only" (0/1): skip the hash-grid fast path and answer every query with the
  * exact AABB-tree descent (same results; used by the parity tests to exercise the fallback on every query).

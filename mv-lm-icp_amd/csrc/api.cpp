@@ -358,6 +358,20 @@ int mvicp_recompute_normals(mvicp_ctx* c, int frame, int k, double* nrm_out, int
     if (e != hipSuccess) { set_error("recompute_normals: %s", hipGetErrorString(e)); st = MVICP_ERR_HIP; }
   }
   dev_free(d_knn);
+  if (st == MVICP_OK && c->E > 0) {
+    // The packed operand stream bakes the dst normals in (n and c = n . q, gathered at correspond time) while the reference
+    // reads dstCloud.nor when it builds the problem (icp-ceres.cpp:270-292): every list that points INTO this frame is stale.
+    // Re-gather those edges now and never reuse their lists unchecked.
+    bool any = false;
+    std::vector<int> dirty(c->E, 0);
+    for (int e = 0; e < c->E; ++e)
+      if (c->owned[e] && c->edst[e] == frame) { c->list_valid[e] = 0; if (c->have_corr && c->h_count[e] > 0) { dirty[e] = 1; any = true; } }
+    if (any) {
+      MV_HIP(hipMemcpy(c->d_dirty, dirty.data(), sizeof(int) * c->E, hipMemcpyHostToDevice));
+      MV_CHECK(launch_gather_stream(c));
+      MV_HIP(hipStreamSynchronize(c->stream));
+    }
+  }
   if (c->profile) prof_collect(c);
   return st;
 }

@@ -88,6 +88,7 @@ inline std::string poseDiff(const Isometry3d& P1, const Isometry3d& P2) {
   double a, b;
   poseDiffValues(P1, P2, &a, &b);
   std::stringstream ss;
+  ss.precision(std::cout.precision());
   ss << "\t diff_tra:" << a << "\t diff_rot_degrees:" << b << std::endl;
   return ss.str();
 }

@@ -20,9 +20,23 @@ Session& Session::get() {
 
 void Session::reset() {
   if (ctx) mvicp_destroy(ctx);
-  ctx = nullptr;
+  if (side_ctx) mvicp_destroy(side_ctx);
+  ctx = nullptr; side_ctx = nullptr; side_owner = nullptr;
   frames_key = nullptr;
+  frame_keys.clear();
   last_poses.clear();
+}
+
+void Session::invalidate() {
+  frames_key = nullptr;
+  frame_keys.clear();
+  last_poses.clear();
+  side_owner = nullptr;
+}
+
+int Session::frame_index(const Frame* f) const {
+  for (size_t i = 0; i < frame_keys.size(); ++i) if (frame_keys[i].f == f) return (int)i;
+  return -1;
 }
 
 void Session::bind(std::vector<std::shared_ptr<Frame>>& frames) {
@@ -30,7 +44,12 @@ void Session::bind(std::vector<std::shared_ptr<Frame>>& frames) {
   std::vector<int> s, d;
   for (size_t i = 0; i < frames.size(); ++i)
     for (const OutgoingEdge& e : frames[i]->neighbours) { s.push_back((int)i); d.push_back(e.neighbourIdx); }
-  if (ctx && frames_key == (const void*)&frames && s == esrc && d == edst) return;
+  std::vector<FrameKey> keys(frames.size());
+  for (size_t i = 0; i < frames.size(); ++i) {
+    const Frame& f = *frames[i];
+    keys[i] = FrameKey{&f, f.pts.empty() ? nullptr : (const void*)f.pts[0].data(), f.pts.size(), f.nor.empty() ? nullptr : (const void*)f.nor[0].data(), f.version};
+  }
+  if (ctx && frames_key == (const void*)&frames && s == esrc && d == edst && keys == frame_keys) return;
   if (!ctx) check(mvicp_create(device, &ctx));
   check(mvicp_set_num_frames(ctx, (int)frames.size()));
   for (size_t i = 0; i < frames.size(); ++i) {
@@ -41,6 +60,7 @@ void Session::bind(std::vector<std::shared_ptr<Frame>>& frames) {
   check(mvicp_set_graph(ctx, (int)s.size(), s.data(), d.data()));
   esrc = s; edst = d;
   frames_key = (const void*)&frames;
+  frame_keys = keys;
   last_poses.clear();
 }
 
@@ -49,12 +69,13 @@ void Session::correspond(std::vector<std::shared_ptr<Frame>>& frames, float thre
   std::vector<double> P(16 * frames.size());
   std::vector<unsigned char> fx(frames.size());
   for (size_t i = 0; i < frames.size(); ++i) { std::memcpy(&P[16 * i], frames[i]->pose.data(), 128); fx[i] = frames[i]->fixed; }
-  if (P == last_poses && thresh == last_thresh) return;  // same round: the batched result is still valid
+  if (P == last_poses && thresh == last_thresh && fx == last_fixed) return;  // same round: the batched result is still valid
   counts.assign(esrc.size(), 0);
   weights.assign(esrc.size(), 0.f);
   check(mvicp_correspond(ctx, P.data(), fx.data(), thresh, nn_method, counts.data(), weights.data()));
   last_poses = P;
   last_thresh = thresh;
+  last_fixed = fx;
 }
 
 void Session::optimize(std::vector<std::shared_ptr<Frame>>& frames, int param, bool pointToPlane, bool robust, mvicp_summary* out) {
@@ -121,25 +142,30 @@ void Frame::recomputeNormals() {
   if (st == MVICP_OK) st = mvicp_recompute_normals(c, 0, 10, nor[0].data(), nullptr);
   mvicp_destroy(c);
   check(st);
+  ++version;   // a bound session re-uploads this cloud (new normals) at its next bind
 }
 
 double Frame::getClosestPoint(const Vector3d& q, size_t& ret_index) {
+  // frame.cpp:187-206.  The reference builds this frame's KD-tree lazily on first use; here the frame's structure already
+  // lives in the bound session (uploaded by computeClosestPointsToNeighbours / ceresOptimizer*), found by frame index.  A frame
+  // that is not part of the bound vector gets a one-cloud side context owned by the session (built on first use, like the
+  // reference's lazy tree; rebuilt when the cloud changes).
   Session& S = Session::get();
-  if (!S.ctx) throw std::runtime_error("mvicp: bind the frames first (computeClosestPointsToNeighbours / ceresOptimizer*)");
-  // locate this frame in the session by pointer scan is not possible without the vector; single-cloud fallback:
-  // callers use the batched API; this entry serves one-off queries through a private context.
-  static mvicp_ctx* own = nullptr;
-  static const Frame* owner = nullptr;
-  if (owner != this) {
-    if (own) mvicp_destroy(own);
-    check(mvicp_create(S.device, &own));
-    check(mvicp_set_num_frames(own, 1));
-    check(mvicp_set_frame(own, 0, pts[0].data(), nullptr, (int)pts.size()));
-    owner = this;
-  }
+  if (pts.empty()) throw std::runtime_error("mvicp: getClosestPoint on an empty cloud (nanoflann throws here: nanoflann.hpp:904)");
   int idx = -1;
   double d2 = 0.0;
-  check(mvicp_nn_query(own, 0, q.data(), 1, MVICP_NN_AUTO, &idx, &d2));
+  const int fi = S.ctx ? S.frame_index(this) : -1;
+  if (fi >= 0 && S.frame_keys[fi].pts == (const void*)pts[0].data() && S.frame_keys[fi].n == pts.size()) {
+    check(mvicp_nn_query(S.ctx, fi, q.data(), 1, MVICP_NN_AUTO, &idx, &d2));
+  } else {
+    if (S.side_owner != this || S.side_version != version || !S.side_ctx) {
+      if (!S.side_ctx) check(mvicp_create(S.device, &S.side_ctx));
+      check(mvicp_set_num_frames(S.side_ctx, 1));
+      check(mvicp_set_frame(S.side_ctx, 0, pts[0].data(), nullptr, (int)pts.size()));
+      S.side_owner = this; S.side_version = version;
+    }
+    check(mvicp_nn_query(S.side_ctx, 0, q.data(), 1, MVICP_NN_AUTO, &idx, &d2));
+  }
   ret_index = (size_t)idx;
   return d2;
 }
@@ -194,3 +220,19 @@ Isometry3d pointToPlane_CeresAngleAxis(std::vector<Vector3d>& s, std::vector<Vec
 Isometry3d pointToPlane_SophusSE3(std::vector<Vector3d>& s, std::vector<Vector3d>& d, std::vector<Vector3d>& n, bool) { return pairwise(s, d, &n, MVICP_PARAM_SOPHUS_SE3); }
 
 }  // namespace ICP_Ceres
+
+namespace ICP_Closedform {
+static void check(int st) { if (st < 0) throw std::runtime_error(std::string("mvicp: ") + mvicp_last_error()); }
+Isometry3d pointToPoint(std::vector<Vector3d>& src, std::vector<Vector3d>& dst) {
+  if (src.size() != dst.size() || src.empty()) throw std::runtime_error("mvicp: closed form needs equally sized, non-empty clouds");
+  Isometry3d T;
+  check(mvicp_closedform_point_to_point(src[0].data(), dst[0].data(), (int)src.size(), T.data()));
+  return T;
+}
+Isometry3d pointToPlane(std::vector<Vector3d>& src, std::vector<Vector3d>& dst, std::vector<Vector3d>& nor) {
+  if (src.size() != dst.size() || src.size() != nor.size() || src.empty()) throw std::runtime_error("mvicp: closed form needs equally sized, non-empty clouds");
+  Isometry3d T;
+  check(mvicp_closedform_point_to_plane(src[0].data(), dst[0].data(), nor[0].data(), (int)src.size(), T.data()));
+  return T;
+}
+}  // namespace ICP_Closedform

@@ -33,6 +33,7 @@ class Frame {
   Isometry3d pose;
   Isometry3d poseGroundTruth;
   std::vector<OutgoingEdge> neighbours;
+  unsigned long long version = 0;   // bumped by recomputeNormals(): the session re-uploads the cloud when it changes
 
   // frame.cpp:67-89 (host; tiny)
   void computePoseNeighboursKnn(std::vector<std::shared_ptr<Frame>>* frames, int i, int k);
@@ -54,9 +55,18 @@ struct Session {
   bool copy_back = true;  // fill Frame::neighbours[].correspondances after the search (off: device-only, faster)
   int nn_method = MVICP_NN_AUTO;
   const void* frames_key = nullptr;
+  // what the device copy was built from: per frame {Frame*, pts data, size, nor data, normals version}; any difference
+  // (a re-loaded cloud, recomputeNormals(), an edited point vector) triggers a fresh upload at the next bind
+  struct FrameKey { const Frame* f; const void* pts; size_t n; const void* nor; unsigned long long version;
+                    bool operator==(const FrameKey& o) const { return f == o.f && pts == o.pts && n == o.n && nor == o.nor && version == o.version; } };
+  std::vector<FrameKey> frame_keys;
   std::vector<int> esrc, edst;
   std::vector<double> last_poses;
+  std::vector<unsigned char> last_fixed;
   float last_thresh = -1.f;
+  mvicp_ctx* side_ctx = nullptr; const Frame* side_owner = nullptr; unsigned long long side_version = 0;  // getClosestPoint on an unbound frame
+  int frame_index(const Frame* f) const;   // position of f in the bound vector, or -1
+  void invalidate();                       // forget the device copy (forces re-upload + fresh search); for in-place edits of pts/nor data
   std::vector<int> counts;
   std::vector<float> weights;
   void bind(std::vector<std::shared_ptr<Frame>>& frames);      // upload + graph (idempotent)
@@ -83,3 +93,11 @@ Isometry3d pointToPlane_EigenQuaternion(std::vector<Vector3d>& src, std::vector<
 Isometry3d pointToPlane_CeresAngleAxis(std::vector<Vector3d>& src, std::vector<Vector3d>& dst, std::vector<Vector3d>& nor);
 Isometry3d pointToPlane_SophusSE3(std::vector<Vector3d>& src, std::vector<Vector3d>& dst, std::vector<Vector3d>& nor, bool automaticDiffLocalParam = true);
 }  // namespace ICP_Ceres
+
+namespace ICP_Closedform {
+using mvicp::Isometry3d;
+using mvicp::Vector3d;
+// include/icp-closedform.h:10-11 (host only): comparison baselines of main_pairwise.cpp:74-76,93-95
+Isometry3d pointToPlane(std::vector<Vector3d>& src, std::vector<Vector3d>& dst, std::vector<Vector3d>& nor);
+Isometry3d pointToPoint(std::vector<Vector3d>& src, std::vector<Vector3d>& dst);
+}  // namespace ICP_Closedform

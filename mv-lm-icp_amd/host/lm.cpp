@@ -56,6 +56,7 @@ struct Assembler {
     if (param == MVICP_PARAM_SOPHUS_SE3) {
       // M = I for every pose: the canonical blocks ARE the local ones (packed upper triangle of the 12x12, row by row)
       for (int e = 0; e < E; ++e) {
+        if (fidx[src[e]] < 0) continue;   // icp-ceres.cpp:255,351,426: a fixed SOURCE contributes no residual blocks at all
         const double* b = blocks + (size_t)e * MVICP_EDGE_BLOCK;
         cost += b[90];
         const int fr[2] = {fidx[src[e]], fidx[dst[e]]};
@@ -76,6 +77,7 @@ struct Assembler {
       return cost;
     }
     for (int e = 0; e < E; ++e) {
+      if (fidx[src[e]] < 0) continue;   // fixed source: edge excluded (see above)
       const double* b = blocks + (size_t)e * MVICP_EDGE_BLOCK;
       cost += b[90];
       int o = 0;

@@ -2,8 +2,11 @@
 //   loadFrames (:53-100) -> frames[0]->fixed = true (:141) -> computePoseNeighbours (:104-117, once) ->
 //   20 x { computeClosestPoints (:119-127) ; ceresOptimizer* (:158-161) }
 // Extra flags: --rounds (20), --out DIR (write final poses as pose_<i>.txt, 4x4 row-major), --device, --copyback,
-// --keep_phantom_row (reproduce the reference's loadXYZ trailing element), --quiet.
+// --keep_phantom_row (reproduce the reference's loadXYZ trailing element), --quiet, --dump_corr DIR (after the LAST round's search
+// write every Frame::neighbours[j] as corr_<src>_<j>.txt: a header line `dst weight count`, then `first second dist` rows),
+// --check_nn N (re-ask Frame::getClosestPoint for the first N correspondences of every edge and report disagreements).
 #include <chrono>
+#include <fstream>
 #include <iomanip>
 #include <iostream>
 
@@ -65,6 +68,35 @@ int main(int argc, char** argv) {
       const auto t0 = std::chrono::steady_clock::now();
       for (auto& f : frames) f->computeClosestPointsToNeighbours(&frames, cutoff);
       const auto t1 = std::chrono::steady_clock::now();
+      if (r == rounds - 1 && !F.s("dump_corr", "").empty()) {
+        for (size_t i = 0; i < frames.size(); ++i)
+          for (size_t j = 0; j < frames[i]->neighbours.size(); ++j) {
+            const OutgoingEdge& e = frames[i]->neighbours[j];
+            std::ofstream f((F.s("dump_corr", "") + "/corr_" + std::to_string(i) + "_" + std::to_string(j) + ".txt").c_str());
+            f.precision(17);
+            f << e.neighbourIdx << " " << e.weight << " " << e.correspondances.size() << "\n";
+            for (const Correspondance& c : e.correspondances) f << c.first << " " << c.second << " " << c.dist << "\n";
+          }
+      }
+      if (r == rounds - 1 && F.i("check_nn", 0) > 0) {
+        // S1' through the Frame mirror: q = dst.pose^-1 * (src.pose * p) (frame.cpp:131,136) -> dst.getClosestPoint(q) must give
+        // the correspondence's neighbour and distance
+        long checked = 0, bad = 0;
+        for (size_t i = 0; i < frames.size(); ++i)
+          for (const OutgoingEdge& e : frames[i]->neighbours) {
+            Frame& d = *frames[e.neighbourIdx];
+            const Isometry3d M = d.pose.inverse() * frames[i]->pose;
+            const int n = std::min<int>(F.i("check_nn", 0), (int)e.correspondances.size());
+            for (int k = 0; k < n; ++k) {
+              const Correspondance& c = e.correspondances[k];
+              size_t idx = 0;
+              const double d2 = d.getClosestPoint(M * frames[i]->pts[c.first], idx);
+              ++checked;
+              if ((int)idx != c.second || std::fabs(std::sqrt(d2) - c.dist) > 1e-12) ++bad;
+            }
+          }
+        std::cout << "getClosestPoint check: " << checked << " queries, " << bad << " mismatches" << std::endl;
+      }
       if (sophusSE3) ICP_Ceres::ceresOptimizer_sophusSE3(frames, pointToPlane, robust);
       else if (angleAxis) ICP_Ceres::ceresOptimizer_ceresAngleAxis(frames, pointToPlane, robust);
       else ICP_Ceres::ceresOptimizer(frames, pointToPlane, robust);

@@ -1,6 +1,7 @@
 // Headless counterpart of the reference's src/main_pairwise.cpp:29-134: load one cloud, apply a known noisy transform,
 // recover it with each parameterization from index-aligned pairs, print timings and poseDiff.  Flags: --pointToPlane
-// (false), --cloud FILE (../samples/Bunny_RealData/cloudXYZ_0.xyz), --device.
+// (false), --cloud FILE (../samples/Bunny_RealData/cloudXYZ_0.xyz), --device, --dump_P FILE (write the ground-truth
+// transform P of this run, 4x4 row-major), --precision N.
 #include <chrono>
 #include <iostream>
 
@@ -31,7 +32,13 @@ int main(int argc, char** argv) {
   for (size_t i = 0; i < pts.size(); ++i) { ptsTra[i] = P * pts[i]; norTra[i] = P.rotate(nor[i]); }
   struct Run { const char* name; Isometry3d out; double ms; };
   std::vector<Run> runs;
+  if (!F.s("dump_P", "").empty()) saveMatrix4d(F.s("dump_P", ""), P);   // the ground-truth transform of this run (tests)
   try {
+    {  // main_pairwise.cpp:74-76,93-95: closed form first
+      const auto t0 = std::chrono::steady_clock::now();
+      const Isometry3d out = pointToPlane ? ICP_Closedform::pointToPlane(pts, ptsTra, norTra) : ICP_Closedform::pointToPoint(pts, ptsTra);
+      runs.push_back(Run{"closed form      ", out, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()});
+    }
     auto timed = [&](const char* name, Isometry3d (*fn)(std::vector<Vector3d>&, std::vector<Vector3d>&, std::vector<Vector3d>&, bool)) {
       const auto t0 = std::chrono::steady_clock::now();
       const Isometry3d out = fn(pts, ptsTra, norTra, pointToPlane);
@@ -50,6 +57,8 @@ int main(int argc, char** argv) {
   std::cout << "=====  TIMINGS ====" << std::endl;
   for (const Run& r : runs) std::cout << r.name << ":\t" << r.ms / 1e3 << std::endl;
   std::cout << std::endl << "=====  Accurracy ====" << std::endl;
+  std::cout.precision(F.i("precision", 6));
   for (const Run& r : runs) std::cout << r.name << poseDiff(P, r.out) << std::endl;
+  Session::get().reset();
   return 0;
 }

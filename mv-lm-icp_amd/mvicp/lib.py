@@ -16,6 +16,7 @@ SYMBOLS = [
     "mvicp_recompute_normals", "mvicp_set_graph", "mvicp_set_shard", "mvicp_edge_owner", "mvicp_comm_unique_id", "mvicp_comm_init", "mvicp_comm_set_callback", "mvicp_correspond",
     "mvicp_get_correspondences", "mvicp_set_correspondences", "mvicp_nn_query", "mvicp_linearize", "mvicp_optimize",
     "mvicp_lm_solve", "mvicp_set_option", "mvicp_nn_census", "mvicp_profile_enable", "mvicp_profile_reset", "mvicp_profile_get", "mvicp_stream", "mvicp_sync",
+    "mvicp_closedform_point_to_point", "mvicp_closedform_point_to_plane",
 ]
 
 
@@ -75,6 +76,8 @@ def load_library(path=None):
     lib.mvicp_stream.argtypes = [vp]
     lib.mvicp_stream.restype = vp
     lib.mvicp_sync.argtypes = [vp]
+    lib.mvicp_closedform_point_to_point.argtypes = [dp, dp, C.c_int, dp]
+    lib.mvicp_closedform_point_to_plane.argtypes = [dp, dp, dp, C.c_int, dp]
     if path is None:
         _lib = lib
     return lib
@@ -110,6 +113,24 @@ def edge_owner(n_src, world):
     owner = np.zeros(len(n_src), dtype=np.int32)
     _check(lib, lib.mvicp_edge_owner(len(n_src), _ip(n_src), world, _ip(owner)))
     return owner
+
+
+def closedform_point_to_point(src, dst):
+    """ICP_Closedform::pointToPoint (icp-closedform.cpp:9-26): least-squares rigid transform src -> dst.  Host only."""
+    lib = load_library()
+    a = np.ascontiguousarray(src, dtype=np.float64); b = np.ascontiguousarray(dst, dtype=np.float64)
+    out = np.zeros(16)
+    _check(lib, lib.mvicp_closedform_point_to_point(_dp(a), _dp(b), len(a), _dp(out)))
+    return poses_from_c(out)[0]
+
+
+def closedform_point_to_plane(src, dst, nor):
+    """ICP_Closedform::pointToPlane (icp-closedform.cpp:30-54): one linearised point-to-plane step from identity.  Host only."""
+    lib = load_library()
+    a = np.ascontiguousarray(src, dtype=np.float64); b = np.ascontiguousarray(dst, dtype=np.float64); c = np.ascontiguousarray(nor, dtype=np.float64)
+    out = np.zeros(16)
+    _check(lib, lib.mvicp_closedform_point_to_plane(_dp(a), _dp(b), _dp(c), len(a), _dp(out)))
+    return poses_from_c(out)[0]
 
 
 def lm_solve_host(n_frames, src, dst, poses, fixed, param, eval_callback, max_iterations=50):

@@ -22,8 +22,10 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <random>
 #include <vector>
 
 #include "geometry.h"
@@ -352,6 +354,7 @@ struct Evaluator {
     double cost = 0.0;
     for (int e = 0; e < pb.E; ++e) {
       const int s = pb.esrc[e], d = pb.edst[e];
+      if (pb.fixed[s]) continue;   // icp-ceres.cpp:255,351,426: `if(srcCloud.fixed) continue;` — no residual blocks from a fixed source
       const double* xs = x + (size_t)s * A;
       const double* xd = x + (size_t)d * A;
       const double* spts = pb.pts + 3 * (size_t)pb.foff[s];
@@ -480,6 +483,7 @@ static void lm_solve(const Problem& pb, double* x /* K x ambient, in/out */, int
 
   Evaluator ev(pb);
   const int n = ev.n(), A = pb.ambient(), K = pb.K;
+  const bool trace = std::getenv("ORC_LM_TRACE") != NULL;   // per-iteration log on stderr (debugging aid)
   std::memset(sm, 0, sizeof(*sm));
   if (n == 0) { sm->initial_cost = sm->final_cost = ev.evaluate(x, NULL, NULL); sm->termination = 1; return; }
   std::vector<double> H((size_t)n * n), g(n), scale(n), Hs((size_t)n * n), gs(n), diag(n), Aw((size_t)n * n), step(n), delta(n), xc((size_t)K * A);
@@ -539,6 +543,7 @@ static void lm_solve(const Problem& pb, double* x /* K x ambient, in/out */, int
     double sn = 0.0;
     for (int i = 0; i < K; ++i) if (!pb.fixed[i]) for (int a = 0; a < A; ++a) { const double dd = x[i * A + a] - xc[i * A + a]; sn += dd * dd; }
     const double step_norm = std::sqrt(sn);
+    if (trace) std::fprintf(stderr, "[orc lm] it %d cost %.6e cand %.6e step_norm %.3e x_norm %.3e radius %.3e model_change %.3e\n", iter, cost, cand_cost, step_norm, x_norm, radius, model_cost_change);
     if (step_norm <= parameter_tolerance * (x_norm + parameter_tolerance)) { sm->termination = 2; break; }
     const double cost_change = cost - cand_cost;
     if (std::fabs(cost_change) <= function_tolerance * cost) { sm->termination = 3; break; }
@@ -622,6 +627,28 @@ void orc_optimize(const orc_problem* p, double* poses, int max_iterations, orc_s
   out->initial_cost = sm.initial_cost; out->final_cost = sm.final_cost; out->iterations = sm.iterations;
   out->successful_steps = sm.successful_steps; out->termination = sm.termination;
   out->jacobian_evals = sm.jacobian_evals; out->cost_evals = sm.cost_evals;
+}
+
+// common.h:36-67 addNoise: file-scope DEFAULT-SEEDED std::mt19937 + std::normal_distribution<double>(0,1) (a fresh
+// distribution object per call, so no cached second variate survives a call); draw order w (3) then t (3);
+// noisyPose = pose * Exp(sigma w), translation += sigmat t.  The reference is built with libstdc++ (README targets
+// Ubuntu/g++), whose mt19937 is the standard-mandated sequence and whose normal_distribution is the Marsaglia polar
+// method: compiled here with the same g++ <random>, this IS the reference's pose noise.  reset != 0 re-seeds the generator to
+// its default state first (= a fresh process: main_pairwise.cpp calls addNoise exactly once, main_multiview.cpp once per
+// non-first frame in file order).
+static std::mt19937 g_noise_generator;
+void orc_add_noise(const double* pose16, double sigma, double sigmat, int reset, double* out16) {
+  if (reset) g_noise_generator = std::mt19937();
+  std::normal_distribution<double> normal(0.0, 1.0);
+  double w[3] = {normal(g_noise_generator), normal(g_noise_generator), normal(g_noise_generator)};
+  for (int i = 0; i < 3; ++i) w[i] *= sigma;
+  double Rw[9];
+  AngleAxisToRotationMatrix(w, Rw);   // column-major, = Sophus::SO3d::exp(w).matrix()
+  for (int k = 0; k < 16; ++k) out16[k] = pose16[k];
+  for (int j = 0; j < 3; ++j)
+    for (int i = 0; i < 3; ++i) out16[i + 4 * j] = pose16[i + 4 * 0] * Rw[0 + 3 * j] + pose16[i + 4 * 1] * Rw[1 + 3 * j] + pose16[i + 4 * 2] * Rw[2 + 3 * j];
+  double t[3] = {normal(g_noise_generator), normal(g_noise_generator), normal(g_noise_generator)};
+  for (int i = 0; i < 3; ++i) out16[12 + i] = pose16[12 + i] + t[i] * sigmat;
 }
 
 // common.h:259-282 poseDiff: ||t1 - t2|| and acos(2 <q1,q2>^2 - 1) in degrees.

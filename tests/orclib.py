@@ -153,6 +153,12 @@ class Oracle:
         self.lib.orc_local_plus(param, _p(x), _p(d), _p(out))
         return out
 
+    def add_noise(self, pose, sigma, sigmat, reset=False):
+        """common.h:36-67 with the reference's default-seeded std::mt19937 stream (libstdc++)."""
+        out = np.zeros(16)
+        self.lib.orc_add_noise(_p(to_c([pose])[0]), C.c_double(sigma), C.c_double(sigmat), C.c_int(1 if reset else 0), _p(out))
+        return from_c(out)[0]
+
     def pose_diff(self, P1, P2):
         a, b = C.c_double(), C.c_double()
         self.lib.orc_pose_diff(_p(to_c([P1])[0]), _p(to_c([P2])[0]), C.byref(a), C.byref(b))

@@ -46,13 +46,38 @@ def test_multiview_driver_matches_engine_loop(tmp_path, flags, param, plane):
 
 
 def test_correspondence_copy_back_through_frame_api(tmp_path):
-    """Frame::neighbours[].correspondances filled by the driver-side adaptor equal the engine's lists (ascending src index)."""
+    """Frame::neighbours[].correspondances / .weight filled by the driver-side adaptor (frame.cpp:110,158,176 semantics) equal the
+    engine's lists at the same poses, triple for triple; and Frame::getClosestPoint (S1', through the bound session) returns each
+    correspondence's neighbour."""
     pb = synth.make_problem(3, 2000)
     d = tmp_path / "data"; o = tmp_path / "out"
     d.mkdir(); o.mkdir()
     write_dataset(str(d), pb)
-    subprocess.check_call([os.path.join(BIN, "multiview"), "--dir", str(d), "--out", str(o), "--step", "1", "--rounds", "1", "--quiet", "--copyback"])
-    assert os.path.exists(os.path.join(str(o), "pose_2.txt"))
+    out = subprocess.check_output([os.path.join(BIN, "multiview"), "--dir", str(d), "--out", str(o), "--step", "1", "--rounds", "1", "--quiet", "--copyback",
+                                   "--norecomputeNormals", "--dump_corr", str(o), "--check_nn", "300"]).decode()
+    m = re.search(r"getClosestPoint check: (\d+) queries, (\d+) mismatches", out)
+    assert m and int(m.group(1)) >= 1000 and int(m.group(2)) == 0, out
+    src, dst = synth.pose_graph_knn(pb["init"], 2, skip_fixed0=False)
+    eng = mvicp.Engine(0)
+    eng.set_frames(pb["pts"], pb["nor"]); eng.set_graph(src, dst)
+    counts, weights = eng.correspond(pb["init"], pb["fixed"], 0.05)
+    e = 0
+    for i in range(3):
+        for j in range(2):
+            path = os.path.join(str(o), f"corr_{i}_{j}.txt")
+            with open(path) as f:
+                hdr = f.readline().split()
+            assert int(hdr[0]) == dst[e]
+            if i == 0:   # fixed frame: never searched (frame.cpp:93) -> list stays empty, weight stays the pose distance of the graph build
+                assert int(hdr[2]) == 0 and counts[e] == 0
+            else:
+                rows = np.loadtxt(path, skiprows=1).reshape(-1, 3)
+                gf, gs, gd = eng.get_correspondences(e)
+                assert int(hdr[2]) == counts[e] == len(rows)
+                assert np.array_equal(rows[:, 0].astype(np.int32), gf) and np.array_equal(rows[:, 1].astype(np.int32), gs) and np.array_equal(rows[:, 2], gd)
+                assert np.float32(hdr[1]) == weights[e]
+            e += 1
+    eng.close()
 
 
 def test_multiview_driver_default_flags_recompute_normals(tmp_path):
@@ -77,12 +102,21 @@ def test_multiview_driver_default_flags_recompute_normals(tmp_path):
 
 
 def test_pairwise_driver_recovers_known_transform(tmp_path):
-    G = np.load(os.path.join(ROOT, "tests", "golden", "bunny_nn.npz"))
+    """bin/pairwise on the reference's own input (all rows of cloudXYZ_0 written back in its .xyz format): the transform it draws is
+    the golden P (default-seeded std::mt19937, common.h:36-67) and every solver recovers it — README.md:141-150: Ceres variants
+    6-8e-11 / 1.7e-6 deg, closed form 6.6e-15.  Bars: see test_pairwise_known_answer_on_gpu."""
+    K = np.load(os.path.join(ROOT, "tests", "golden", "pairwise_kat.npz"))
     cloud = tmp_path / "cloud.xyz"
-    np.savetxt(str(cloud), np.hstack([G["dst"], G["dst_nor"]]), fmt="%.17g")
+    np.savetxt(str(cloud), np.hstack([K["pts"], K["nor"]]), fmt="%.17g")
     for extra in ([], ["--pointToPlane"]):
-        out = subprocess.check_output([os.path.join(BIN, "pairwise"), "--cloud", str(cloud)] + extra).decode()
-        vals = re.findall(r"diff_tra:([0-9.e+-]+)\s+diff_rot_degrees:([0-9.e+-]+)", out)
-        assert len(vals) == 3, out
-        for t, r in vals:
-            assert float(t) < 1e-8 and float(r) < 1e-5, out  # README.md:141-146: ~1e-10 m, 1.7e-6 deg (acos floor)
+        pfile = tmp_path / "P.txt"
+        out = subprocess.check_output([os.path.join(BIN, "pairwise"), "--cloud", str(cloud), "--dump_P", str(pfile), "--precision", "12"] + extra).decode()
+        assert np.allclose(np.loadtxt(str(pfile)), K["P"], rtol=0, atol=1e-15)
+        vals = re.findall(r"(closed form|ceres \w+)\s+diff_tra:([0-9.e+-]+)\s+diff_rot_degrees:([0-9.e+-]+)", out)
+        assert [v[0] for v in vals] == ["closed form", "ceres CeresAngleAxis", "ceres EigenQuaternion", "ceres SophusSE3"], out
+        for name, t, r in vals:
+            if name == "closed form":
+                if not extra:
+                    assert float(t) < 1e-13 and float(r) < 3e-6, out      # README.md:148: 6.6e-15, 2.4e-6 deg (acos floor)
+                continue   # point-to-plane closed form = ONE linearised step from identity (icp-closedform.cpp:30-54): not exact for this P
+            assert float(t) <= 1e-9 and float(r) <= 2e-6, out

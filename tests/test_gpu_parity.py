@@ -254,22 +254,98 @@ def test_full_icp_loop_matches_oracle(eng, orc, param, plane):
         assert e1 < 0.6 * e0, (e0, e1)
 
 
-def test_pairwise_known_answer_on_gpu(eng):
-    """main_pairwise.cpp:44-61,117-133 through the device path (S3 = a 2-frame graph with index-aligned pairs):
-    every parameterization recovers P; README.md:141-146 quotes diff_tra <~ 1e-10."""
-    pts, nrm = G["dst"], G["dst_nor"]
-    P = synth.add_noise(np.eye(4), 0.3, 0.1, np.random.default_rng(1))
+KAT = np.load(os.path.join(os.path.dirname(__file__), "golden", "pairwise_kat.npz"))
+
+
+@pytest.mark.parametrize("plane", [0, 1])
+def test_pairwise_known_answer_on_gpu(eng, orc, plane):
+    """The reference's only known-answer test on its own inputs (main_pairwise.cpp:34-61,117-133: all rows of cloudXYZ_0, P from the
+    default-seeded std::mt19937) through the device path (S3 = a 2-frame graph with index-aligned pairs).  README.md:141-146 quotes
+    diff_tra 6-8e-11 / diff_rot 1.7e-6 deg; the solve ends on the parameter tolerance without taking the last step, so the error is
+    the size of that step (< 1e-8 |x|): bar = one decade above the README sample, same termination, and the GPU trajectory equal
+    to the oracle's (same iteration count, poses within 1e-11)."""
+    pts, nrm, P = KAT["pts"], KAT["nor"], KAT["P"]
     dstp = pts @ P[:3, :3].T + P[:3, 3]
     dstn = nrm @ P[:3, :3].T
     n = len(pts)
+    ids = np.arange(n, dtype=np.int32)
     eng.set_frames([dstp, pts], [dstn, nrm])
     eng.set_graph([1], [0])
-    eng.set_correspondences(0, np.arange(n, dtype=np.int32), np.arange(n, dtype=np.int32), 0.0)
+    eng.set_correspondences(0, ids, ids, 0.0)
     for param in (0, 1, 2):
-        for plane in (0, 1):
-            Pout, sm = eng.optimize(np.array([np.eye(4), np.eye(4)]), [1, 0], param, plane, False, 50)
-            dt, dr = synth.pose_diff(P, Pout[1])
-            assert dt < 1e-8 and dr < 1e-7, (param, plane, dt, dr, sm)  # README.md:141-146 quotes ~1e-10 m after Ceres' own trajectory
+        Pout, sm = eng.optimize(np.array([np.eye(4), np.eye(4)]), [1, 0], param, plane, False, 50)
+        dt, dr_deg = orc.pose_diff(P, Pout[1])            # the reference's poseDiff (acos form, degrees)
+        assert sm["termination"] == 2, sm
+        assert dt <= 1e-9 and dr_deg <= 2e-6, (param, plane, dt, dr_deg, sm)
+        prob = orc.make_problem([dstp, pts], [dstn, nrm], [1, 0], [1], [0], [(ids, ids)], [0.0], param, plane, 0)
+        Pref, smr = orc.optimize(prob, np.array([np.eye(4), np.eye(4)]), 50)
+        assert sm["iterations"] == smr["iterations"], (sm, smr)
+        dt, dr = synth.pose_diff(Pout[1], Pref[1])
+        assert dt < 1e-11 and dr < 1e-11, (param, plane, dt, dr)
+
+
+def test_point_to_point_block_against_kabsch(eng):
+    """Row f4: the closed-form point-to-point solution (icp-closedform.cpp:9-26, here SVD in numpy AND the library's host solver)
+    is the exact minimiser of sum |R p + t - q|^2, so it must be a stationary point of the GPU's point-to-point normal equations
+    (non-robust): g = 0 there, and the LM solve from identity must end next to it."""
+    rng = np.random.default_rng(21)
+    pts, P = KAT["pts"][::2], KAT["P"]
+    dstp = pts @ P[:3, :3].T + P[:3, 3] + rng.normal(0, 1e-3, pts.shape)
+    pm, qm = pts.mean(0), dstp.mean(0)
+    U, S, Vt = np.linalg.svd((dstp - qm).T @ (pts - pm))
+    R = U @ Vt
+    assert np.linalg.det(R) > 0
+    Tk = np.eye(4); Tk[:3, :3] = R; Tk[:3, 3] = qm - R @ pm
+    Th = L.closedform_point_to_point(pts, dstp)
+    assert np.allclose(Th, Tk, atol=1e-12)
+    ids = np.arange(len(pts), dtype=np.int32)
+    eng.set_frames([dstp, pts], None); eng.set_graph([1], [0])
+    eng.set_correspondences(0, ids, ids, 0.0)
+    H, g, cost = L.unpack_block(eng.linearize(np.array([np.eye(4), Tk]), 0, 0)[0])
+    assert np.isclose(cost, 0.5 * np.sum((pts @ R.T + Tk[:3, 3] - dstp) ** 2), rtol=1e-12)
+    gscale = np.sqrt(np.diag(H)[:6]) * np.sqrt(2 * cost)           # |J_col| |r|: the size each gradient entry would have off-optimum
+    assert np.all(np.abs(g[:6]) < 1e-9 * gscale), (g[:6], gscale)
+    for param in (0, 1, 2):
+        Pout, sm = eng.optimize(np.array([np.eye(4), np.eye(4)]), [1, 0], param, 0, False, 50)
+        dt, dr = synth.pose_diff(Pout[1], Tk)
+        assert dt < 1e-5 and dr < 1e-5, (param, dt, dr, sm)       # function tolerance 1e-6 on a non-zero-residual problem
+
+
+def test_recompute_normals_after_correspond_regathers(eng):
+    """normals recomputed AFTER the search must reach the next evaluation (the operand stream bakes n and n.q in)."""
+    pb = synth.make_problem(3, 3000)
+    eng.set_frames(pb["pts"], pb["nor"]); eng.set_graph(pb["src"], pb["dst"])
+    eng.correspond(pb["init"], pb["fixed"], 0.05)
+    nor = [eng.recompute_normals(i, 10) for i in range(3)]       # overwrites the analytic normals on the device
+    got = eng.linearize(pb["init"], 1, 1)
+    fresh = mvicp.Engine(0)
+    fresh.set_frames(pb["pts"], nor); fresh.set_graph(pb["src"], pb["dst"])
+    fresh.correspond(pb["init"], pb["fixed"], 0.05)
+    want = fresh.linearize(pb["init"], 1, 1)
+    fresh.close()
+    assert np.array_equal(got, want)
+    # and the next round (lists unchanged, so they would be reused) still sees the new normals
+    eng.correspond(pb["init"], pb["fixed"], 0.05)
+    assert np.array_equal(eng.linearize(pb["init"], 1, 1), want)
+
+
+def test_fixed_source_edges_are_excluded_from_the_solve(eng, orc):
+    """ADVICE r1 / icp-ceres.cpp:255,351,426: correspond() with NO fixed mask fills the edges out of frame 0 too; the solve
+    (which forces fixed[0]) must ignore them like the reference does."""
+    pb = synth.make_problem(4, 3000)
+    src, dst = synth.pose_graph_knn(pb["init"], 2, skip_fixed0=False)
+    eng.set_frames(pb["pts"], pb["nor"]); eng.set_graph(src, dst)
+    counts, weights = eng.correspond(pb["init"], np.zeros(4, np.uint8), 0.05)
+    assert all(counts[e] > 0 for e in range(len(src)))            # edges out of frame 0 were searched
+    corr = [eng.get_correspondences(e)[:2] for e in range(eng.E)]
+    P, sm = eng.optimize(pb["init"], np.zeros(4, np.uint8), L.PARAM_SOPHUS_SE3, 1, True, 50)
+    keep = [e for e in range(len(src)) if src[e] != 0]
+    prob = orc.make_problem(pb["pts"], pb["nor"], pb["fixed"], src[keep], dst[keep], [corr[e] for e in keep], weights[keep], orclib.PARAM_SOPHUS, 1, 1)
+    P_ref, sm_ref = orc.optimize(prob, pb["init"], 50)
+    assert sm["iterations"] == sm_ref["iterations"]
+    for k in range(4):
+        dt, dr = synth.pose_diff(P[k], P_ref[k])
+        assert dt < 1e-9 and dr < 1e-9, (k, dt, dr)
 
 
 # ---------------------------------------------------------------- size-independent properties at full size

@@ -57,3 +57,36 @@ def test_evaluator_error_propagates():
         raise ValueError("boom")
     with pytest.raises(ValueError):
         L.lm_solve_host(2, [1], [0], np.array([np.eye(4)] * 2), [1, 0], 2, bad, 5)
+
+
+@pytest.mark.parametrize("param", PARAMS)
+def test_edges_from_a_fixed_source_are_excluded(orc, param):
+    """icp-ceres.cpp:255,351,426 `if(srcCloud.fixed) continue;`: a graph that lists edges out of frame 0 (and out of a second
+    fixed frame) must optimise exactly the objective without them — whatever their blocks contain."""
+    rng = np.random.default_rng(8)
+    pb = synth.make_problem(4, 400)
+    src, dst = synth.pose_graph_knn(pb["init"], 2, skip_fixed0=False)   # frame 0 is a source here
+    fixed = np.array([0, 0, 1, 0], dtype=np.uint8)                      # fixed[0] is forced by the solver; frame 2 is fixed by the caller
+    corr, w = [], []
+    for s, d in zip(src, dst):
+        f, sec, dist, wt, _, _ = orc.correspond_edge(pb["pts"][s], pb["init"][s], pb["pts"][d], pb["init"][d], 0.05)
+        corr.append((f, sec)); w.append(float(wt))
+    keep = [e for e, s in enumerate(src) if s not in (0, 2)]
+    prob_all = orc.make_problem(pb["pts"], pb["nor"], [1, 0, 1, 0], src, dst, corr, w, param, 1, 1)
+    prob_kept = orc.make_problem(pb["pts"], pb["nor"], [1, 0, 1, 0], src[keep], dst[keep], [corr[e] for e in keep], [w[e] for e in keep], param, 1, 1)
+    P_all, sm_all = orc.optimize(prob_all, pb["init"], 50)
+    P_kept, sm_kept = orc.optimize(prob_kept, pb["init"], 50)
+    assert np.array_equal(P_all, P_kept) and sm_all == sm_kept   # the oracle itself follows the reference rule
+
+    def evaluator(poses):
+        blk = orc.edge_blocks(pb["pts"], pb["nor"], src, dst, corr, w, poses, 1, 1)
+        for e, s in enumerate(src):
+            if s in (0, 2):
+                blk[e] = rng.normal(0, 1e3, 91)   # must never be read
+        return blk
+
+    P, sm = L.lm_solve_host(4, src, dst, pb["init"], fixed, param, evaluator, 50)
+    assert sm["iterations"] == sm_kept["iterations"] and sm["termination"] == sm_kept["termination"]
+    for k in range(4):
+        dt, dr = synth.pose_diff(P[k], P_kept[k])
+        assert dt < 1e-9 and dr < 1e-9, (k, dt, dr)

@@ -115,3 +115,97 @@ def test_pairwise_known_answer(orc, plane):
         Pout, sm = orc.optimize(prob, np.array([np.eye(4), np.eye(4)]), 50)
         dt, dr = orc.pose_diff(P, Pout[1])
         assert dt < 1e-9 and dr < 1e-5, (param, dt, dr, sm)
+
+
+# ---------------------------------------------------------------- the reference's known-answer test on its exact inputs
+KAT = None
+
+
+def kat():
+    global KAT
+    if KAT is None:
+        import os
+        KAT = np.load(os.path.join(os.path.dirname(__file__), "golden", "pairwise_kat.npz"))
+    return KAT
+
+
+def test_kat_inputs_match_the_readme_listing(orc):
+    """README.md:105-114 prints the first rows of cloudXYZ_0.xyz as loaded by main_pairwise.cpp:34-39 (6 significant digits);
+    the golden's P is what common.h:36-67 produces from a default-seeded std::mt19937 (regenerated here through compiled C++)."""
+    K = kat()
+    assert K["pts"].shape == (16264, 3)
+    assert np.allclose(K["pts"][0], [-0.076899, -0.081785, 0.421], atol=5e-7) and np.allclose(K["nor"][0], [-0.226502, -0.628639, -0.743983], atol=5e-7)
+    assert np.allclose(K["pts"][9], [-0.076168, -0.074065, 0.417], atol=5e-7) and np.allclose(K["nor"][9], [-0.437831, -0.405047, -0.802647], atol=5e-7)
+    P = orc.add_noise(K["Pclean"], 0.1, 0.1, reset=True)
+    assert np.array_equal(P, K["P"])
+    assert np.allclose(P[:3, :3] @ P[:3, :3].T, np.eye(3), atol=1e-15)
+    # std::mt19937 default seed 5489: the 10000th output is 4123659995 (C++ standard, [rand.predef]); the noise really is N(0,1)-sized
+    w = K["Pclean"][:3, :3].T @ P[:3, :3]
+    assert 0.01 < np.arccos((np.trace(w) - 1) / 2) < 0.5 and 0.01 < np.linalg.norm(P[:3, 3] - K["Pclean"][:3, 3]) < 0.5
+
+
+@pytest.mark.parametrize("plane", [0, 1])
+@pytest.mark.parametrize("param", PARAMS)
+def test_pairwise_known_answer_reference_inputs(orc, param, plane):
+    """main_pairwise.cpp:44-61,117-133 on its own inputs (all 16 264 rows of cloudXYZ_0, the default-seeded P).  README.md:141-146:
+    diff_tra 6.3e-11 .. 7.8e-11, diff_rot 1.7e-6 deg (poseDiff's acos floor) for the three Ceres variants (point-to-point).
+    The solve ends on Ceres' parameter tolerance WITHOUT taking the last step, so the answer's error is the size of that
+    untaken step: anywhere below 1e-8 * |x|; here it lands at 3e-10 .. 8e-10 (point-to-point) and 5e-11 .. 2e-10 (point-to-plane),
+    the README's sample at 6e-11 .. 8e-11.  Bar: one decade above the README figure, same termination type."""
+    K = kat()
+    pts, nrm, P = K["pts"], K["nor"], K["P"]
+    dstp = pts @ P[:3, :3].T + P[:3, 3]
+    dstn = nrm @ P[:3, :3].T
+    N = len(pts)
+    corr = [(np.arange(N, dtype=np.int32), np.arange(N, dtype=np.int32))]
+    prob = orc.make_problem([dstp, pts], [dstn, nrm], [1, 0], [1], [0], corr, [0.0], param, plane, 0)
+    Pout, sm = orc.optimize(prob, np.array([np.eye(4), np.eye(4)]), 50)
+    dt, dr_deg = orc.pose_diff(P, Pout[1])       # the reference's own poseDiff (acos form, degrees)
+    assert sm["termination"] == 2 and 5 <= sm["iterations"] <= 10, sm
+    assert dt <= 1e-9 and dr_deg <= 2e-6, (param, plane, dt, dr_deg)
+    assert synth.pose_diff(P, Pout[1])[1] <= 3e-9   # radians, atan2 form (no acos floor)
+
+
+def test_closed_form_point_to_point_is_kabsch():
+    """ICP_Closedform::pointToPoint (icp-closedform.cpp:9-26) through the host-only C ABI: on the KAT it returns P (README.md:148:
+    diff_tra 6.6e-15); on noisy pairs it equals the SVD (Kabsch) solution the reference computes."""
+    from mvicp import lib as L
+    K = kat()
+    pts, P = K["pts"], K["P"]
+    dstp = pts @ P[:3, :3].T + P[:3, 3]
+    T = L.closedform_point_to_point(pts, dstp)
+    dt, dr = synth.pose_diff(P, T)
+    assert dt < 1e-13 and dr < 1e-13, (dt, dr)
+    rng = np.random.default_rng(7)
+    noisy = dstp + rng.normal(0, 2e-3, dstp.shape)
+    T = L.closedform_point_to_point(pts, noisy)
+    pm, qm = pts.mean(0), noisy.mean(0)
+    Kc = (noisy - qm).T @ (pts - pm)                      # icp-closedform.cpp:19
+    U, S, Vt = np.linalg.svd(Kc)
+    R = U @ Vt
+    if np.linalg.det(R) < 0:
+        R = U @ np.diag([1, 1, -1]) @ Vt
+    assert np.allclose(T[:3, :3], R, atol=1e-12) and np.allclose(T[:3, 3], qm - R @ pm, atol=1e-13)
+    with pytest.raises(Exception):
+        L.closedform_point_to_point(pts[:2], dstp[:2])
+
+
+def test_closed_form_point_to_plane_matches_the_6x6_system():
+    """ICP_Closedform::pointToPlane (icp-closedform.cpp:30-54): C x = d with rows [p x n ; n], R = Rx Ry Rz of the solved angles."""
+    from mvicp import lib as L
+    K = kat()
+    pts, nrm = K["pts"][::4], K["nor"][::4]
+    small = np.eye(4); small[:3, :3] = synth.so3_exp(np.array([0.01, -0.02, 0.015])); small[:3, 3] = [0.002, -0.001, 0.003]
+    dstp = pts @ small[:3, :3].T + small[:3, 3]
+    dstn = nrm @ small[:3, :3].T
+    T = L.closedform_point_to_plane(pts, dstp, dstn)
+    u = np.hstack([np.cross(pts, dstn), dstn])
+    r = np.sum((pts - dstp) * dstn, axis=1)
+    x = np.linalg.solve(u.T @ u, -(u.T @ r))
+    c, s = np.cos, np.sin
+    Rx = np.array([[1, 0, 0], [0, c(x[0]), -s(x[0])], [0, s(x[0]), c(x[0])]])
+    Ry = np.array([[c(x[1]), 0, s(x[1])], [0, 1, 0], [-s(x[1]), 0, c(x[1])]])
+    Rz = np.array([[c(x[2]), -s(x[2]), 0], [s(x[2]), c(x[2]), 0], [0, 0, 1]])
+    assert np.allclose(T[:3, :3], Rx @ Ry @ Rz, atol=1e-12) and np.allclose(T[:3, 3], x[3:], atol=1e-12)
+    dt, dr = synth.pose_diff(small, T)
+    assert dt < 2e-4 and dr < 1e-3   # one linearised step from identity: first-order accurate (README.md:148 lists the p2p variant only)
