@@ -92,17 +92,26 @@ def add_noise(T, sigma, sigmat, rng):
     return out
 
 
-def make_problem(K, N, sigma=0.02, sigmat=0.01, knn=2, seed_base=1000, pose_seed=5489):
-    pts, nor, gt = [], [], []
-    for k in range(K):
-        p, n = make_view(k, K, N, seed_base)
-        pts.append(p); nor.append(n); gt.append(gt_pose(k, K))
+def make_poses(K, sigma=0.02, sigmat=0.01, knn=2, pose_seed=5489):
+    """Ground-truth / initial poses, pose graph and fixed mask of a K-view problem — everything of make_problem except the
+    clouds (which are independent streams, seed_base + k per view), so a test can build a few views of a large config."""
+    gt = [gt_pose(k, K) for k in range(K)]
     rng = np.random.Generator(np.random.PCG64(pose_seed))
     init = [gt[0].copy()] + [add_noise(gt[k], sigma, sigmat, rng) for k in range(1, K)]
     src, dst = pose_graph_knn(np.array(init), knn)
     fixed = np.zeros(K, dtype=np.uint8)
     fixed[0] = 1
-    return {"pts": pts, "nor": nor, "gt": np.array(gt), "init": np.array(init), "src": src, "dst": dst, "fixed": fixed}
+    return {"gt": np.array(gt), "init": np.array(init), "src": src, "dst": dst, "fixed": fixed}
+
+
+def make_problem(K, N, sigma=0.02, sigmat=0.01, knn=2, seed_base=1000, pose_seed=5489):
+    pts, nor = [], []
+    for k in range(K):
+        p, n = make_view(k, K, N, seed_base)
+        pts.append(p); nor.append(n)
+    pb = make_poses(K, sigma, sigmat, knn, pose_seed)
+    pb["pts"] = pts; pb["nor"] = nor
+    return pb
 
 
 def pose_graph_knn(poses, knn, skip_fixed0=True):

@@ -1,0 +1,233 @@
+"""-m gpu: parity AT THE BASELINE SIZES (BASELINE.json configs 3, 4, 5) — the sizes the bench line is measured at.
+
+Reference for the NN half = the REAL vendored nanoflann (oracle/_ref, built from /root/reference/include/nanoflann.hpp by
+oracle/Makefile; the prebuilt .so travels to the GPU box) fed with the oracle's query transform, followed by the oracle's
+cutoff / upper-median rule (frame.cpp:129-176).  Everything is compared bit for bit: counts, float weights, (first, second,
+dist) triples.  Reference for the LM half = the oracle's Jet-based Ceres restatement (tolerance stated per assertion)."""
+import time
+
+import numpy as np
+import pytest
+
+import mvicp
+import orclib
+from mvicp import lib as L
+from mvicp import synth
+
+pytestmark = pytest.mark.gpu
+CUTOFF = 0.05
+
+
+def reference_edge(orc, ref, pts_s, P_s, pts_d, P_d, cutoff=CUTOFF):
+    """frame.cpp:117-176 for one edge with the real nanoflann: -> (first, second, dist, weight)."""
+    q = orc.query_transform(P_s, P_d, pts_s)
+    idx, d2 = ref.query(pts_d, q)
+    return orc.filter_median(idx, d2, cutoff)
+
+
+def reference_edges(orc, ref, pts, poses, edges):
+    """reference_edge for a list of (src, dst) pairs on a thread pool (the ctypes calls release the GIL; each call builds its own tree)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=max(1, min(16, os.cpu_count() or 1))) as ex:
+        return list(ex.map(lambda sd: reference_edge(orc, ref, pts[sd[0]], poses[sd[0]], pts[sd[1]], poses[sd[1]]), edges))
+
+
+def assert_edge_equal(eng, e, counts, weights, want, tag):
+    f, s, d, w = want
+    gf, gs, gd = eng.get_correspondences(e)
+    assert counts[e] == len(f), (tag, e, counts[e], len(f))
+    assert np.array_equal(gf, f) and np.array_equal(gs, s), (tag, e, "indices")
+    assert np.array_equal(gd, d), (tag, e, "distances")
+    assert weights[e].tobytes() == np.float32(w).tobytes(), (tag, e, weights[e], w)
+
+
+# ------------------------------------------------------------------------------------------------ cfg3: 8 x 100k, angle-axis
+def test_cfg3_full_size_vs_nanoflann_and_oracle_lm(orc, refnn):
+    """BASELINE config 3 (8 views x 100 000 points, E = 14, point-to-plane, angle-axis) at full size, two ICP rounds:
+    correspondences of ALL 14 edges vs the real nanoflann at the initial poses and of 5 edges at the second round's poses
+    (bit-exact), both LM solves vs the oracle on the same 1.4 M residuals (same iteration count / termination; poses <= 1e-9
+    after the first solve, <= 1e-8 after the second; north-star bar 1e-5)."""
+    assert refnn is not None, "oracle/_ref/libref_nanoflann.so missing (built by oracle/Makefile where /root/reference exists)"
+    pb = synth.make_problem(8, 100_000)
+    edges = list(zip(pb["src"], pb["dst"]))
+    eng = mvicp.Engine(0)
+    eng.set_frames(pb["pts"], pb["nor"]); eng.set_graph(pb["src"], pb["dst"])
+    poses_g = pb["init"].copy()
+    poses_o = pb["init"].copy()
+    for rnd in range(2):
+        counts, weights = eng.correspond(poses_g, pb["fixed"], CUTOFF)
+        want_o = reference_edges(orc, refnn, pb["pts"], poses_o, edges)          # what the CPU path works on
+        if np.array_equal(poses_g, poses_o):
+            for e in range(len(edges)):
+                assert_edge_equal(eng, e, counts, weights, want_o[e], f"cfg3 round {rnd}")
+        else:
+            sample = [0, 3, 6, 10, 13]
+            want_g = reference_edges(orc, refnn, pb["pts"], poses_g, [edges[e] for e in sample])
+            for e, w in zip(sample, want_g):
+                assert_edge_equal(eng, e, counts, weights, w, f"cfg3 round {rnd}")
+        poses_g, sm = eng.optimize(poses_g, pb["fixed"], L.PARAM_ANGLE_AXIS, 1, True, 50)
+        prob = orc.make_problem(pb["pts"], pb["nor"], pb["fixed"], pb["src"], pb["dst"], [w[:2] for w in want_o], [w[3] for w in want_o], orclib.PARAM_ANGLEAXIS, 1, 1)
+        poses_o, sm_o = orc.optimize(prob, poses_o, 50)
+        assert sm["iterations"] == sm_o["iterations"] and sm["termination"] == sm_o["termination"], (rnd, sm, sm_o)
+        tol = 1e-9 if rnd == 0 else 1e-8
+        for k in range(8):
+            dt, dr = synth.pose_diff(poses_g[k], poses_o[k])
+            assert dt < tol and dr < tol, (rnd, k, dt, dr)
+    e0 = max(synth.pose_diff(pb["init"][k], pb["gt"][k])[0] for k in range(8))
+    e1 = max(synth.pose_diff(poses_g[k], pb["gt"][k])[0] for k in range(8))
+    assert e1 < 0.6 * e0, (e0, e1)
+    eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ cfg4: 32 x 200k
+@pytest.fixture(scope="module")
+def cfg4():
+    return synth.make_problem(32, 200_000)
+
+
+def test_cfg4_full_size_vs_nanoflann(orc, refnn, cfg4):
+    """BASELINE config 4 (32 views x 200 000 points, E = 62): the product path (AUTO: tile kernel first, grid kernel + temporal
+    cache + list reuse later) against the real nanoflann on every edge at the initial poses, and on 8 sampled edges after 3 and
+    after 7 rounds (the hand-over / cached regime that produces the bench number)."""
+    assert refnn is not None
+    pb = cfg4
+    eng = mvicp.Engine(0)
+    eng.set_frames(pb["pts"], pb["nor"]); eng.set_graph(pb["src"], pb["dst"])
+    poses = pb["init"].copy()
+    E = len(pb["src"])
+    sample = sorted(set(np.linspace(0, E - 1, 8).astype(int).tolist()))
+    for rnd in range(8):
+        counts, weights = eng.correspond(poses, pb["fixed"], CUTOFF)
+        edges = list(range(E)) if rnd == 0 else (sample if rnd in (3, 7) else [])
+        want = reference_edges(orc, refnn, pb["pts"], poses, [(pb["src"][e], pb["dst"][e]) for e in edges])
+        for e, w in zip(edges, want):
+            assert_edge_equal(eng, e, counts, weights, w, f"cfg4 round {rnd}")
+        poses, sm = eng.optimize(poses, pb["fixed"], L.PARAM_SOPHUS_SE3, 1, True, 50)
+    eng.close()
+
+
+def test_cfg4_moving_rounds_cache_and_list_reuse_are_bit_identical(cfg4):
+    """Full-size twin of test_temporal_cache_is_bit_identical_to_full_search: two engines on config 4, one with the temporal NN
+    cache + list reuse + bracket select (the product defaults), one with all three off, walked through the SAME poses:
+    8 rounds of the real ICP trajectory from the noisy initial poses, then 5 rounds of injected pose motion from a few point
+    spacings down to 1e-6 m (partial cache hits, partially reused lists).  Every round: identical counts and weights on all 62
+    edges, bit-identical normal-equation blocks (a checksum of every list and operand stream: the sums are order-deterministic),
+    identical (first, second, dist) lists on sampled edges."""
+    pb = cfg4
+    engs = []
+    for on in (1, 0):
+        e = mvicp.Engine(0)
+        e.set_option("nn_cache", on); e.set_option("list_reuse", on); e.set_option("sel_bracket", on)
+        e.set_frames(pb["pts"], pb["nor"]); e.set_graph(pb["src"], pb["dst"])
+        engs.append(e)
+    a, b = engs
+    a.profile(True); a.set_option("nn_census", 1)
+    E = len(pb["src"])
+    sample = [0, 13, 30, 47, 61]
+    rng = np.random.default_rng(77)
+    poses = pb["init"].copy()
+    hit_fracs = []
+    schedule = [("icp", 0.0)] * 8 + [("jolt", 2e-3), ("jolt", 3e-4), ("jolt", 5e-5), ("jolt", 8e-6), ("jolt", 1e-6)]
+    for rnd, (kind, mag) in enumerate(schedule):
+        if kind == "jolt":   # move every free pose by a random rigid motion of size ~mag (metres at the cloud, and radians * 0.4 m)
+            for k in range(1, len(poses)):
+                T = np.eye(4); T[:3, :3] = synth.so3_exp(rng.normal(0, mag / 0.4, 3)); T[:3, 3] = rng.normal(0, mag, 3)
+                poses[k] = poses[k] @ T
+        a.profile_reset()
+        method = L.NN_AUTO if kind == "icp" else L.NN_GRID
+        ca, wa = a.correspond(poses, pb["fixed"], CUTOFF, method)
+        cb, wb = b.correspond(poses, pb["fixed"], CUTOFF, method)
+        cs = a.nn_census()
+        hit_fracs.append(cs["hits"] / max(1.0, cs["queries"]))
+        assert np.array_equal(ca, cb) and wa.tobytes() == wb.tobytes(), rnd
+        ba = a.linearize(poses, 1, 1); bb = b.linearize(poses, 1, 1)
+        assert np.array_equal(ba, bb), (rnd, np.abs(ba - bb).max())
+        for e in sample:
+            la, lb = a.get_correspondences(e), b.get_correspondences(e)
+            assert all(np.array_equal(x, y) for x, y in zip(la, lb)), (rnd, e)
+        if kind == "icp":
+            pa, sma = a.optimize(poses, pb["fixed"], L.PARAM_SOPHUS_SE3, 1, True, 50)
+            pbb, smb = b.optimize(poses, pb["fixed"], L.PARAM_SOPHUS_SE3, 1, True, 50)
+            assert np.array_equal(pa, pbb) and sma == smb, rnd
+            poses = pa
+    # the cache really was exercised in the partial-hit regime, not only at 0 % / 100 %
+    partial = [h for h in hit_fracs if 0.02 < h < 0.98]
+    assert len(partial) >= 2 and max(hit_fracs) > 0.9, hit_fracs
+    for e in engs:
+        e.close()
+
+
+# ------------------------------------------------------------------------------------------------ cfg5: 64 x 1M
+def test_cfg5_edges_at_one_million_points_vs_nanoflann(orc, refnn):
+    """BASELINE config 5 geometry (64 views x 1 000 000 points, SophusSE3): four views of that problem (its poses, its pose
+    graph restricted to them, 1 M points each) through every NN kernel of the product path against the real nanoflann, at the
+    noisy initial poses and after two ICP rounds."""
+    assert refnn is not None
+    K, N = 64, 1_000_000
+    pp = synth.make_poses(K)
+    views = [9, 10, 11, 12]
+    t0 = time.time()
+    pts, nor = zip(*[synth.make_view(k, K, N) for k in views])
+    loc = {k: i for i, k in enumerate(views)}
+    keep = [e for e, (s, d) in enumerate(zip(pp["src"], pp["dst"])) if s in loc and d in loc]
+    src = np.array([loc[pp["src"][e]] for e in keep], dtype=np.int32); dst = np.array([loc[pp["dst"][e]] for e in keep], dtype=np.int32)
+    assert len(src) >= 4
+    poses = np.array([pp["init"][k] for k in views])
+    fixed = np.zeros(len(views), dtype=np.uint8)   # none of these views is frame 0: the solver will pin local frame 0 (icp-ceres.cpp:417)
+    eng = mvicp.Engine(0)
+    eng.set_frames(list(pts), list(nor)); eng.set_graph(src, dst)
+    t_setup = time.time() - t0
+    check = [0, len(src) - 1]
+    for rnd in range(3):
+        counts, weights = eng.correspond(poses, fixed, CUTOFF)
+        if rnd in (0, 2):
+            want = reference_edges(orc, refnn, pts, poses, [(src[e], dst[e]) for e in check])
+            for e, w in zip(check, want):
+                assert_edge_equal(eng, e, counts, weights, w, f"cfg5 round {rnd}")
+        if rnd == 0:   # the other kernels on the same poses (grid = hash + far list; tile = wave-cooperative)
+            lists = [eng.get_correspondences(e) for e in check]
+            for m in (L.NN_GRID, L.NN_TILE):
+                c2, w2 = eng.correspond(poses, fixed, CUTOFF, m)
+                assert np.array_equal(c2, counts) and w2.tobytes() == weights.tobytes(), m
+                for e, want in zip(check, lists):
+                    assert all(np.array_equal(x, y) for x, y in zip(eng.get_correspondences(e), want)), (m, e)
+        poses, sm = eng.optimize(poses, fixed, L.PARAM_SOPHUS_SE3, 1, True, 50)
+    eng.close()
+    print(f"cfg5 4-view setup {t_setup:.1f} s")
+
+
+def test_cfg5_whole_problem_runs_and_is_self_consistent(orc, refnn):
+    """The WHOLE config 5 (64 x 1 M points, E = 126, ~10 GB operand stream, SophusSE3) on one GPU: two ICP rounds; two edges of
+    round 2 against the real nanoflann; all-edge properties (counts checksum: at 5 cm every query has a partner on this scene;
+    ascending source index; sharded halves sum to the unsharded blocks bit for bit)."""
+    assert refnn is not None
+    K, N = 64, 1_000_000
+    t0 = time.time()
+    pb = synth.make_problem(K, N)
+    t_gen = time.time() - t0
+    t0 = time.time()
+    eng = mvicp.Engine(0)
+    eng.set_frames(pb["pts"], pb["nor"]); eng.set_graph(pb["src"], pb["dst"])
+    t_set = time.time() - t0
+    E = len(pb["src"])
+    assert E == 126
+    poses = pb["init"].copy()
+    for rnd in range(2):
+        counts, weights = eng.correspond(poses, pb["fixed"], CUTOFF)
+        assert int(counts.sum()) == E * N
+        if rnd == 1:
+            want = reference_edges(orc, refnn, pb["pts"], poses, [(pb["src"][e], pb["dst"][e]) for e in (5, 120)])
+            for e, w in zip((5, 120), want):
+                assert_edge_equal(eng, e, counts, weights, w, "cfg5 whole")
+            blocks = eng.linearize(poses, 1, 1)
+        poses, sm = eng.optimize(poses, pb["fixed"], L.PARAM_SOPHUS_SE3, 1, True, 50)
+        assert sm["final_cost"] < sm["initial_cost"]
+    f, s, d = eng.get_correspondences(77)
+    assert np.all(np.diff(f) > 0) and len(f) == N
+    e0 = max(synth.pose_diff(pb["init"][k], pb["gt"][k])[0] for k in range(K))
+    e1 = max(synth.pose_diff(poses[k], pb["gt"][k])[0] for k in range(K))
+    assert e1 < 0.5 * e0, (e0, e1)
+    print(f"cfg5 whole: generate {t_gen:.1f} s, set_frames + set_graph {t_set:.1f} s")
+    eng.close()
+    assert np.isfinite(blocks).all()
