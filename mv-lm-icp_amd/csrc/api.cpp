@@ -584,7 +584,11 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
       if (m > 0) {
         dist /= m; cell /= m;
         const bool settled = c->auto_prev_dist > 0.0 ? dist > c->auto_settle * c->auto_prev_dist : dist < 0.5 * cell;
-        if (dist < 1.5 * cell && (settled || c->auto_last_method == MVICP_NN_GRID)) method = MVICP_NN_GRID;
+        if (c->nn_cell) {
+          // cell-staging grid kernel: its cost follows the seed distance (cells per ball), not the cache hit rate, so it takes over
+          // as soon as the last median distance is within ~a cell and a half — no hand-over round to wait for
+          if (dist < c->auto_switch * cell || c->auto_last_method == MVICP_NN_GRID) method = MVICP_NN_GRID;
+        } else if (dist < 1.5 * cell && (settled || c->auto_last_method == MVICP_NN_GRID)) method = MVICP_NN_GRID;
         c->auto_prev_dist = dist;
       }
     }
@@ -788,6 +792,8 @@ int mvicp_set_option(mvicp_ctx* c, const char* name, double value) {
   if (std::strcmp(name, "prune_rho") == 0) { c->prune_rho = value; return MVICP_OK; }
   if (std::strcmp(name, "grid_curve") == 0) { c->grid_curve = (int)value; return MVICP_OK; }   // takes effect at the next mvicp_set_frame
   if (std::strcmp(name, "auto_settle") == 0) { c->auto_settle = value; return MVICP_OK; }
+  if (std::strcmp(name, "auto_switch") == 0) { c->auto_switch = value; return MVICP_OK; }
+  if (std::strcmp(name, "nn_cell") == 0) { c->nn_cell = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "tile_seed") == 0) { c->tile_seed = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "tile_waves") == 0) { c->tile_waves = (int)value; return MVICP_OK; }
   if (std::strcmp(name, "spin_wait") == 0) { c->spin_wait = value != 0.0; return MVICP_OK; }

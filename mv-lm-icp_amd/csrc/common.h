@@ -62,6 +62,9 @@ struct GridDev {
   int wide_cnt[6] = {0, 0, 0, 0, 0, 0};
   long long wide_off[6] = {0, 0, 0, 0, 0, 0};
   double struct_bytes = 0.0;
+  // dense brick map over the cells (nn_grid.hip, nn_cell_kernel): brick = 4x4x4 cells -> {occupancy mask, row of the cell table};
+  // cell table row = 64 x {start, count} of the cell runs in the sorted array.  Null when the grid is too large for a dense map.
+  void* bricks = nullptr; void* celltab = nullptr; int bdims[3] = {0, 0, 0};
 };
 
 struct PointRec { double x, y, z; long long idx; };  // 32-B aligned sorted point + original index
@@ -183,6 +186,8 @@ struct mvicp_ctx {
   bool tile_seed = true;           // tile kernel starts from last round's neighbours when there are any
   int tile_waves = 0;              // nn_tile_kernel variant: waves per SIMD it is compiled for (0 = the measured best for the depth)
   double auto_prev_dist = 0.0; int auto_last_method = -1; double auto_settle = 0.5;   // MVICP_NN_AUTO policy state (api.cpp)
+  bool nn_cell = true;             // grid method: wave-cooperative cell staging kernel for seeded rounds (0: per-lane hash kernel everywhere)
+  double auto_switch = 1.5;        // AUTO: hand over from the tile kernel to the grid method once the median distance is below this many hash cells
   double prune_rho = 0.05;         // grid kernel: with a seed, skip block cells farther than seed distance + prune_rho * cell edge; 0 = off
   int grid_curve = 1;              // cell order of the sorted clouds: 0 Morton (Z-order), 1 Hilbert
   double grid_target = 5.0;        // points per occupied cell the cell-edge heuristic aims at (4-6 measure the same within 2 %)

@@ -42,12 +42,15 @@ constexpr unsigned long long EMPTY = ~0ull;
 
 struct HashEntry { unsigned long long key; unsigned int start, count; };
 
+struct BrickEntry { unsigned long long mask; unsigned int tab; unsigned int pad; };   // 4x4x4 cells: bit (x&3) | (y&3)<<2 | (z&3)<<4
+
 struct GridView {  // device view of one cloud's structure
   const double* spts; const int* sidx; const PointRec* srec; int n;
   const HashEntry* table; unsigned int mask; int shift;
   double ox, oy, oz, h, inv_h;
   int dx, dy, dz;
   const float* oct; int oct_depth; long long oct_first_leaf;   // implicit 8-ary box tree (32-B boxes), phase 2
+  const BrickEntry* bricks; const uint2* celltab; int bx, by, bz;   // dense brick map (null: none), nn_cell_kernel
 };
 
 struct GridJob {
@@ -338,6 +341,229 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
   }
 }
 
+
+// ---- phase 1, seeded rounds: WAVE-COOPERATIVE CELL STAGING ---------------------------------------------------------------
+// From the second search on every query knows last round's neighbour.  After the pose update that neighbour sits at distance
+// d_seed from the query, so the true nearest neighbour lies inside the ball B(q, d_seed): only the grid cells that intersect that
+// ball (a handful once the registration moves by less than a cell) can hold it.  nn_grid_kernel answers this per lane from
+// global memory — ~40 divergent 16-B loads per lane (8 hash probes + two loads per candidate record), which is what bounds it
+// (the texture addresser handles about one distinct cache line per cycle).  The 64 queries of a wave are curve-adjacent source
+// points, so their balls overlap the SAME few dozen cells.  Here the wave cooperates:
+//   1. every lane enumerates the cells its ball touches (exact cell lower bounds; empty cells are dropped with the dense
+//      brick occupancy masks) and inserts them into a small hash SET in LDS (64-bit atomicCAS);
+//   2. the distinct cells (typically 30-60 per wave instead of 64 x 8) are looked up ONCE — brick entry -> cell table
+//      {start, count} — and their point runs are copied into LDS;
+//   3. every lane scans its own cells from LDS in the reference's fp64 arithmetic with the (d2, original index) total order.
+// A lane is resolved by construction: every target outside the cells it scanned is provably outside its ball.  The ball is
+// d_seed + rho * h so that the lower bound handed to the temporal cache keeps a margin (same role as in nn_grid_kernel).
+// Lanes without a usable seed, with a ball wider than CELL_SPAN cells, or that do not fit the wave's LDS budget join the far
+// list with their best candidate so far and are finished by nn_far_kernel — exactness never depends on the budget.
+constexpr int CELL_HS = 128;     // hash-set slots per wave
+constexpr int CELL_CAP = 240;    // staged points per wave (3 x 8 B each)
+constexpr int CELL_SPAN = 6;     // widest per-lane cell box, per axis
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Squared distance from q to the cell (ix, iy, iz), shrunk by `tol` per axis: a point whose cell index was rounded across a
+// boundary (the assignment floor((p - o) * inv_h) carries a relative 1e-16 error, i.e. < 1e-9 h) still satisfies d2 >= lb2.
+__device__ __forceinline__ double cell_lb2(const GridView& g, int ix, int iy, int iz, double qx, double qy, double qz, double tol) {
+  const double lx = g.ox + ix * g.h, ly = g.oy + iy * g.h, lz = g.oz + iz * g.h;
+  const double gx = fmax(fmax(lx - qx, qx - (lx + g.h)) - tol, 0.0);
+  const double gy = fmax(fmax(ly - qy, qy - (ly + g.h)) - tol, 0.0);
+  const double gz = fmax(fmax(lz - qz, qz - (lz + g.h)) - tol, 0.0);
+  return (gx * gx + gy * gy + gz * gz) * 0.999999;
+}
+
+__global__ __launch_bounds__(NT, 5) void nn_cell_kernel(const GridJob* __restrict__ jobs, double bound, unsigned long long* __restrict__ stats,
+                                                        int2* __restrict__ far_list, unsigned int* __restrict__ far_count, double prune_rho) {
+  __shared__ double sxf[kEdgeXf];
+  __shared__ unsigned long long s_hkey[NT / 64][CELL_HS];
+  __shared__ unsigned int s_hval[NT / 64][CELL_HS];      // (LDS offset << 16) | count, or 0xffffffff: did not fit
+  __shared__ unsigned int s_hstart[NT / 64][CELL_HS];    // sorted position of the cell's first point
+  __shared__ double s_x[NT / 64][CELL_CAP], s_y[NT / 64][CELL_CAP], s_z[NT / 64][CELL_CAP];
+  __shared__ unsigned int s_cnt[NT / 64];
+  const GridJob& job = jobs[blockIdx.y];
+  if (blockIdx.x * NT >= job.n) return;
+  if (threadIdx.x < kEdgeXf) sxf[threadIdx.x] = job.xf[threadIdx.x];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  unsigned long long* hk = s_hkey[wave];
+  unsigned int* hv = s_hval[wave];
+  unsigned int* hs = s_hstart[wave];
+  double* sx = s_x[wave]; double* sy = s_y[wave]; double* sz = s_z[wave];
+  hk[lane] = EMPTY; hk[lane + 64] = EMPTY;
+  if (lane == 0) s_cnt[wave] = 0u;
+  __syncthreads();
+  const int i = blockIdx.x * NT + threadIdx.x;
+  const bool active = i < job.n;
+  const GridView& g = job.dst;
+  const double big = 1.7976931348623157e308;
+
+  double qx = 0.0, qy = 0.0, qz = 0.0, p0 = 0.0, p1 = 0.0, p2 = 0.0;
+  if (active) {
+    p0 = job.q[3 * (size_t)i]; p1 = job.q[3 * (size_t)i + 1]; p2 = job.q[3 * (size_t)i + 2];
+    xf_point(sxf, p0, p1, p2, qx, qy, qz);
+  }
+  double best = bound;       // nothing at or beyond the cutoff bound needs resolving (frame.cpp:156)
+  int bpos = -1;             // SORTED position of the running best (-1: none)
+  double second = big;       // smallest d2 among the scanned targets other than the running best
+  double skipped = big;      // smallest lower bound among the cells not scanned because they cannot beat the running best
+  double Rball = 0.0, R2 = 0.0;
+  bool hit = false, need = false, ovf = false;
+  unsigned int n_cand = 0;
+  int cx0 = 0, cx1 = -1, cy0 = 0, cy1 = -1, cz0 = 0, cz1 = -1;
+  const double tol = 1e-7 * g.h;
+  if (active) {
+    const int pi = job.seed ? job.out_idx[i] : -1;   // sorted position of last round's neighbour
+    if (pi >= 0 && pi < g.n) {
+      const double* tp = g.spts + 3 * (size_t)pi;
+      const double d = dist2(qx, qy, qz, tp[0], tp[1], tp[2]);
+      const double slack = sxf[24];
+      if (slack >= 0.0 && job.out_lb != nullptr) {
+        // temporal cache (see nn_grid_kernel): how far THIS query moved since the last search is |dM p + dv|
+        const double e0 = sxf[25] * p0 + sxf[28] * p1 + sxf[31] * p2 + sxf[34];
+        const double e1 = sxf[26] * p0 + sxf[29] * p1 + sxf[32] * p2 + sxf[35];
+        const double e2 = sxf[27] * p0 + sxf[30] * p1 + sxf[33] * p2 + sxf[36];
+        const double eps = sqrt(e0 * e0 + e1 * e1 + e2 * e2) * (1.0 + 1e-9) + slack;
+        const double nlb = job.out_lb[i] - eps;
+        if (sqrt(d) * (1.0 + 1e-12) < nlb) {
+          job.out_d2[i] = d;
+          job.out_lb[i] = nlb;
+          if (job.dirty) update_list(job, i, pi, d, bound);
+          hit = true;
+        }
+      }
+      if (!hit && d < bound) {
+        best = d; bpos = pi;
+        Rball = sqrt(d) * (1.0 + 1e-12) + prune_rho * g.h;
+        const double Rs = Rball * (1.0 + 1e-9) + tol;
+        R2 = Rs * Rs;
+        const double lim = 2.0e6;
+        cx0 = (int)floor(fmin(fmax((qx - Rs - g.ox) * g.inv_h, -lim), lim)); cx1 = (int)floor(fmin(fmax((qx + Rs - g.ox) * g.inv_h, -lim), lim));
+        cy0 = (int)floor(fmin(fmax((qy - Rs - g.oy) * g.inv_h, -lim), lim)); cy1 = (int)floor(fmin(fmax((qy + Rs - g.oy) * g.inv_h, -lim), lim));
+        cz0 = (int)floor(fmin(fmax((qz - Rs - g.oz) * g.inv_h, -lim), lim)); cz1 = (int)floor(fmin(fmax((qz + Rs - g.oz) * g.inv_h, -lim), lim));
+        // cells outside the grid hold nothing (the grid covers the cloud's bounding box)
+        cx0 = max(cx0, 0); cy0 = max(cy0, 0); cz0 = max(cz0, 0);
+        cx1 = min(cx1, g.dx - 1); cy1 = min(cy1, g.dy - 1); cz1 = min(cz1, g.dz - 1);
+        need = (cx1 - cx0 < CELL_SPAN) && (cy1 - cy0 < CELL_SPAN) && (cz1 - cz0 < CELL_SPAN);
+      }
+    }
+  }
+  // lanes that neither hit the cache nor take part below are finished by phase 2 from their provisional result
+
+  if (__ballot(need) != 0ull) {
+    // ---- 1. occupied cells of every ball -> hash set
+    if (need) {
+      long long last_b = -1;
+      BrickEntry be; be.mask = 0ull; be.tab = 0u; be.pad = 0u;
+      for (int iz = cz0; iz <= cz1; ++iz)
+        for (int iy = cy0; iy <= cy1; ++iy)
+          for (int ix = cx0; ix <= cx1; ++ix) {
+            if (cell_lb2(g, ix, iy, iz, qx, qy, qz, tol) > R2) continue;
+            const long long b = ((long long)(iz >> 2) * g.by + (iy >> 2)) * g.bx + (ix >> 2);
+            if (b != last_b) { be = g.bricks[b]; last_b = b; }
+            const int bit = (ix & 3) | ((iy & 3) << 2) | ((iz & 3) << 4);
+            if (!((be.mask >> bit) & 1ull)) continue;
+            const unsigned long long key = cell_key(ix, iy, iz);
+            unsigned int s = hash_slot(key, 64 - 7) & (CELL_HS - 1);
+            int probe = 0;
+            for (; probe < 24; ++probe) {
+              const unsigned long long old = atomicCAS(&hk[s], EMPTY, key);
+              if (old == EMPTY || old == key) break;
+              s = (s + 1) & (CELL_HS - 1);
+            }
+            if (probe == 24) ovf = true;   // set (nearly) full: this lane is finished by phase 2
+          }
+    }
+    wave_sync();
+    // ---- 2. each distinct cell is looked up and staged once per wave
+    for (int s = lane; s < CELL_HS; s += 64) {
+      const unsigned long long key = hk[s];
+      if (key == EMPTY) continue;
+      const int ix = (int)(key & 0x1fffffull), iy = (int)((key >> 21) & 0x1fffffull), iz = (int)((key >> 42) & 0x1fffffull);
+      const long long b = ((long long)(iz >> 2) * g.by + (iy >> 2)) * g.bx + (ix >> 2);
+      const unsigned int tab = g.bricks[b].tab;
+      const int bit = (ix & 3) | ((iy & 3) << 2) | ((iz & 3) << 4);
+      const uint2 run = g.celltab[(size_t)tab * 64 + bit];
+      const unsigned int off = atomicAdd(&s_cnt[wave], run.y);
+      if (off + run.y > (unsigned int)CELL_CAP) { hv[s] = 0xffffffffu; continue; }
+      hv[s] = (off << 16) | run.y;
+      hs[s] = run.x;
+      const double* src = g.spts + 3 * (size_t)run.x;
+      for (unsigned int k = 0; k < run.y; ++k) { sx[off + k] = src[3 * k]; sy[off + k] = src[3 * k + 1]; sz[off + k] = src[3 * k + 2]; }
+    }
+    wave_sync();
+    // ---- 3. every lane scans its own cells from LDS (reference arithmetic, (d2, original index) order)
+    if (need && !ovf) {
+      long long last_b = -1;
+      BrickEntry be; be.mask = 0ull; be.tab = 0u; be.pad = 0u;
+      for (int iz = cz0; iz <= cz1 && !ovf; ++iz)
+        for (int iy = cy0; iy <= cy1 && !ovf; ++iy)
+          for (int ix = cx0; ix <= cx1; ++ix) {
+            const double lb2 = cell_lb2(g, ix, iy, iz, qx, qy, qz, tol);
+            if (lb2 > R2) continue;
+            const long long b = ((long long)(iz >> 2) * g.by + (iy >> 2)) * g.bx + (ix >> 2);
+            if (b != last_b) { be = g.bricks[b]; last_b = b; }
+            const int bit = (ix & 3) | ((iy & 3) << 2) | ((iz & 3) << 4);
+            if (!((be.mask >> bit) & 1ull)) continue;
+            if (lb2 > best) { skipped = fmin(skipped, lb2); continue; }   // ties are still visited (index rule)
+            const unsigned long long key = cell_key(ix, iy, iz);
+            unsigned int s = hash_slot(key, 64 - 7) & (CELL_HS - 1);
+            int probe = 0;
+            for (; probe < 24; ++probe) {
+              if (hk[s] == key) break;
+              s = (s + 1) & (CELL_HS - 1);
+            }
+            if (probe == 24) { ovf = true; break; }
+            const unsigned int v = hv[s];
+            if (v == 0xffffffffu) { ovf = true; break; }
+            const unsigned int off = v >> 16, cnt = v & 0xffffu;
+            const int start = (int)hs[s];
+            for (unsigned int k = 0; k < cnt; ++k) {
+              const int pos = start + (int)k;
+              if (pos == bpos) continue;   // the running best met again (the seed is an ordinary target of its cell)
+              const double d = dist2(qx, qy, qz, sx[off + k], sy[off + k], sz[off + k]);
+              if (d < best) {
+                second = fmin(second, best);
+                best = d; bpos = pos;
+              } else {
+                second = fmin(second, d);
+                if (d == best && g.sidx[pos] < g.sidx[bpos]) bpos = pos;   // exact tie: lowest ORIGINAL index (rare: two global loads)
+              }
+            }
+            n_cand += cnt;
+          }
+    }
+  }
+
+  const bool resolved = need && !ovf;
+  if (active && !hit) {
+    job.out_idx[i] = bpos;
+    job.out_d2[i] = best;
+    // every target that was not scanned lies outside the ball (>= Rball) or in a cell whose lower bound exceeded the running best
+    if (job.out_lb != nullptr) job.out_lb[i] = resolved ? sqrt(fmin(fmin(second, skipped), Rball * Rball * (1.0 - 1e-9))) * (1.0 - 1e-12) : 0.0;
+    if (resolved) {
+      if (job.dirty) update_list(job, i, bpos, best, bound);
+    } else {
+      const unsigned long long mask = __ballot(1);
+      const int leader = __ffsll((long long)mask) - 1;
+      const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+      unsigned int base = 0;
+      if (lane == leader) base = atomicAdd(far_count, (unsigned int)__popcll(mask));
+      base = __shfl(base, leader, 64);
+      far_list[base + rank] = make_int2((int)blockIdx.y, i);
+    }
+  }
+  if (stats && active) {
+    unsigned long long c = __reduce_add_u64((unsigned long long)n_cand), fr = __reduce_add_u64((hit || resolved) ? 0ull : 1ull), hh = __reduce_add_u64(hit ? 1ull : 0ull);
+    const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + (threadIdx.x >> 6);
+    if (__lane0()) { atomicAdd(&stats[4 * slot], c); atomicAdd(&stats[4 * slot + 2], fr); atomicAdd(&stats[4 * slot + 3], hh); }
+  }
+}
+
 // ---- phase 2: exact branch-and-bound for the compacted far list, EIGHT LANES PER QUERY over an implicit 8-ary
 // box tree (children of heap node id are 8 id + 1 .. 8 id + 8; leaf j = sorted points [j n / 8^D, (j+1) n / 8^D)).
 // A lane octet loads the 8 child boxes of a node in one coalesced 256-B access (one 32-B box per lane), ranks them by
@@ -623,6 +849,32 @@ int build_grid(mvicp_ctx* c, FrameDev& f, const double* xyz) {
     table[s] = r;
   }
 
+  // dense brick map (nn_cell_kernel): 4x4x4-cell bricks -> occupancy mask + row of the cell table; cell table = {start, count} of
+  // every cell run.  Only built when the dense array stays small (a surface scan at a few points per cell: ~1e5..1e6 bricks).
+  {
+    const long long bd[3] = {(g.d[0] + 3) / 4, (g.d[1] + 3) / 4, (g.d[2] + 3) / 4};
+    const long long nb = bd[0] * bd[1] * bd[2];
+    const bool capped = g.d[0] >= (1 << 21) - 1 || g.d[1] >= (1 << 21) - 1 || g.d[2] >= (1 << 21) - 1;
+    if (!capped && nb <= (1ll << 24) && n < (1 << 30)) {
+      std::vector<BrickEntry> bricks((size_t)nb, BrickEntry{0ull, 0xffffffffu, 0u});
+      std::vector<uint2> celltab;
+      unsigned int n_tab = 0;
+      for (const HashEntry& r : runs) {
+        const int ix = (int)(r.key & 0x1fffffull), iy = (int)((r.key >> 21) & 0x1fffffull), iz = (int)((r.key >> 42) & 0x1fffffull);
+        BrickEntry& be = bricks[(size_t)(((long long)(iz >> 2) * bd[1] + (iy >> 2)) * bd[0] + (ix >> 2))];
+        if (be.tab == 0xffffffffu) { be.tab = n_tab++; celltab.resize((size_t)n_tab * 64, make_uint2(0u, 0u)); }
+        const int bit = (ix & 3) | ((iy & 3) << 2) | ((iz & 3) << 4);
+        be.mask |= 1ull << bit;
+        celltab[(size_t)be.tab * 64 + bit] = make_uint2(r.start, r.count);
+      }
+      MV_HIP(hipMalloc((void**)&G.bricks, sizeof(BrickEntry) * (size_t)nb));
+      MV_HIP(hipMemcpy(G.bricks, bricks.data(), sizeof(BrickEntry) * (size_t)nb, hipMemcpyHostToDevice));
+      MV_HIP(hipMalloc((void**)&G.celltab, sizeof(uint2) * std::max<size_t>(celltab.size(), 1)));
+      MV_HIP(hipMemcpy(G.celltab, celltab.data(), sizeof(uint2) * celltab.size(), hipMemcpyHostToDevice));
+      G.bdims[0] = (int)bd[0]; G.bdims[1] = (int)bd[1]; G.bdims[2] = (int)bd[2];
+    }
+  }
+
   const float finf = std::numeric_limits<float>::infinity();
   auto down = [](double v) { float f = (float)v; if ((double)f > v) f = std::nextafterf(f, -std::numeric_limits<float>::infinity()); return f; };
   auto up = [](double v) { float f = (float)v; if ((double)f < v) f = std::nextafterf(f, std::numeric_limits<float>::infinity()); return f; };
@@ -690,6 +942,8 @@ void free_grid(GridDev& g) {
   if (g.table) (void)hipFree(g.table);
   if (g.wide) (void)hipFree(g.wide);
   if (g.oct) (void)hipFree(g.oct);
+  if (g.bricks) (void)hipFree(g.bricks);
+  if (g.celltab) (void)hipFree(g.celltab);
   g = GridDev();
 }
 
@@ -702,6 +956,7 @@ GridView view_of(const FrameDev& f) {
   v.ox = g.origin[0]; v.oy = g.origin[1]; v.oz = g.origin[2]; v.h = g.cell; v.inv_h = g.inv_cell;
   v.dx = g.dims[0]; v.dy = g.dims[1]; v.dz = g.dims[2];
   v.oct = g.oct; v.oct_depth = g.oct_depth; v.oct_first_leaf = g.oct_first_leaf;
+  v.bricks = (const BrickEntry*)g.bricks; v.celltab = (const uint2*)g.celltab; v.bx = g.bdims[0]; v.by = g.bdims[1]; v.bz = g.bdims[2];
   return v;
 }
 
@@ -743,8 +998,14 @@ int run(mvicp_ctx* c, const std::vector<GridJob>& jobs, double bound) {
   {
     ProfScope ps(c, "nn", 36.0 * nq);  // query 24 B + result 12 B; the rest comes from the census below (0 if the census is off)
     const dim3 grid((max_n + NT - 1) / NT, (unsigned)jobs.size());
+    // seeded rounds on clouds with a brick map: the wave-cooperative cell-staging kernel; otherwise (first search of an edge,
+    // raw queries, profiling switches) the per-lane hash kernel
+    bool use_cell = c->nn_cell && !c->nn_tree_only && !c->nn_skip_far && edge_path;
+    for (const GridJob& j : jobs) if (!j.seed || j.dst.bricks == nullptr || j.xf == nullptr) use_cell = false;
     if (c->nn_tree_only)
       hipLaunchKernelGGL((nn_grid_kernel<true>), grid, dim3(NT), 0, c->stream, d_jobs, bound, d_stats, 0, (int2*)c->d_far_list, c->d_far_count, 0.0);
+    else if (use_cell)
+      hipLaunchKernelGGL(nn_cell_kernel, grid, dim3(NT), 0, c->stream, d_jobs, bound, d_stats, (int2*)c->d_far_list, c->d_far_count, c->prune_rho);
     else
       hipLaunchKernelGGL((nn_grid_kernel<false>), grid, dim3(NT), 0, c->stream, d_jobs, bound, d_stats, c->nn_skip_far ? 1 : 0, (int2*)c->d_far_list, c->d_far_count,
                          c->prune_rho);
