@@ -585,9 +585,13 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
         dist /= m; cell /= m;
         const bool settled = c->auto_prev_dist > 0.0 ? dist > c->auto_settle * c->auto_prev_dist : dist < 0.5 * cell;
         if (c->nn_cell) {
-          // cell-staging grid kernel: its cost follows the seed distance (cells per ball), not the cache hit rate, so it takes over
-          // as soon as the last median distance is within ~a cell and a half — no hand-over round to wait for
-          if (dist < c->auto_switch * cell || c->auto_last_method == MVICP_NN_GRID) method = MVICP_NN_GRID;
+          // cell-staging grid kernel: it resolves a query whose neighbour is within about a cell of it (home block + ball) at a cost
+          // that follows that distance, not the cache hit rate — so it takes over as soon as the queries are EXPECTED to land that
+          // close: the smaller of last round's median distance and the residual the LM solve has just left (RMS over all
+          // correspondences, with a floor of a fraction of a cell for the sampling of the surface)
+          double pred = dist;
+          if (c->last_rms >= 0.0) pred = std::min(pred, std::sqrt(c->last_rms * c->last_rms + 0.09 * cell * cell));
+          if (pred < c->auto_switch * cell || c->auto_last_method == MVICP_NN_GRID) method = MVICP_NN_GRID;
         } else if (dist < 1.5 * cell && (settled || c->auto_last_method == MVICP_NN_GRID)) method = MVICP_NN_GRID;
         c->auto_prev_dist = dist;
       }
@@ -624,6 +628,7 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   else if (method == MVICP_NN_TILE) MV_CHECK(launch_nn_tile_edges(c, bound));
   else { set_error("unknown nn_method %d", nn_method); return MVICP_ERR_ARG; }
   // only the grid kernel maintains the per-query lower bounds the temporal cache needs; the cutoff must not change either
+  c->last_rms = -1.0;   // consumed: only a solve that follows THIS search may predict the next one
   c->nn_cache_valid = (method == MVICP_NN_GRID) && !c->nn_tree_only && !c->nn_skip_far;
   c->nn_cache_thresh = thresh;
   c->auto_last_method = method;

@@ -186,8 +186,9 @@ struct mvicp_ctx {
   bool tile_seed = true;           // tile kernel starts from last round's neighbours when there are any
   int tile_waves = 0;              // nn_tile_kernel variant: waves per SIMD it is compiled for (0 = the measured best for the depth)
   double auto_prev_dist = 0.0; int auto_last_method = -1; double auto_settle = 0.5;   // MVICP_NN_AUTO policy state (api.cpp)
+  double last_rms = -1.0;          // RMS residual at the end of the last mvicp_optimize since the last search (< 0: none): predicts the next NN distances
   bool nn_cell = true;             // grid method: wave-cooperative cell staging kernel for seeded rounds (0: per-lane hash kernel everywhere)
-  double auto_switch = 1.5;        // AUTO: hand over from the tile kernel to the grid method once the median distance is below this many hash cells
+  double auto_switch = 1.0;        // AUTO: hand over from the tile kernel to the grid method once the median distance is below this many hash cells
   double prune_rho = 0.05;         // grid kernel: with a seed, skip block cells farther than seed distance + prune_rho * cell edge; 0 = off
   int grid_curve = 1;              // cell order of the sorted clouds: 0 Morton (Z-order), 1 Hilbert
   double grid_target = 5.0;        // points per occupied cell the cell-edge heuristic aims at (4-6 measure the same within 2 %)

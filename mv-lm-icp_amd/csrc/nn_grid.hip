@@ -342,25 +342,25 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
 }
 
 
-// ---- phase 1, seeded rounds: WAVE-COOPERATIVE CELL STAGING ---------------------------------------------------------------
-// From the second search on every query knows last round's neighbour.  After the pose update that neighbour sits at distance
-// d_seed from the query, so the true nearest neighbour lies inside the ball B(q, d_seed): only the grid cells that intersect that
-// ball (a handful once the registration moves by less than a cell) can hold it.  nn_grid_kernel answers this per lane from
-// global memory — ~40 divergent 16-B loads per lane (8 hash probes + two loads per candidate record), which is what bounds it
-// (the texture addresser handles about one distinct cache line per cycle).  The 64 queries of a wave are curve-adjacent source
-// points, so their balls overlap the SAME few dozen cells.  Here the wave cooperates:
-//   1. every lane enumerates the cells its ball touches (exact cell lower bounds; empty cells are dropped with the dense
-//      brick occupancy masks) and inserts them into a small hash SET in LDS (64-bit atomicCAS);
-//   2. the distinct cells (typically 30-60 per wave instead of 64 x 8) are looked up ONCE — brick entry -> cell table
-//      {start, count} — and their point runs are copied into LDS;
-//   3. every lane scans its own cells from LDS in the reference's fp64 arithmetic with the (d2, original index) total order.
-// A lane is resolved by construction: every target outside the cells it scanned is provably outside its ball.  The ball is
-// d_seed + rho * h so that the lower bound handed to the temporal cache keeps a margin (same role as in nn_grid_kernel).
-// Lanes without a usable seed, with a ball wider than CELL_SPAN cells, or that do not fit the wave's LDS budget join the far
-// list with their best candidate so far and are finished by nn_far_kernel — exactness never depends on the budget.
-constexpr int CELL_HS = 128;     // hash-set slots per wave
-constexpr int CELL_CAP = 240;    // staged points per wave (3 x 8 B each)
-constexpr int CELL_SPAN = 6;     // widest per-lane cell box, per axis
+// ---- phase 1 on clouds with a brick map: WAVE-COOPERATIVE CELL STAGING -------------------------------------------------------
+// nn_grid_kernel answers a query per lane from global memory: 8 hash probes + two 16-B loads per candidate record, ~40 divergent
+// loads per lane, which is what bounds it (the texture addresser retires about one distinct cache line per cycle).  But the 64
+// queries of a wave are curve-adjacent source points: their searches touch the SAME few dozen cells.  Here the wave cooperates:
+//   A. every lane names the occupied cells of its 2x2x2 home block (dense brick occupancy masks: no probes for empty cells; cells
+//      that cannot beat last round's neighbour are dropped) and inserts them into a small hash SET in LDS (64-bit atomicCAS);
+//      each DISTINCT cell is then looked up once per wave (brick entry -> cell table {start, count}) and its point run copied
+//      into LDS; every lane scans its own cells from LDS in the reference's fp64 arithmetic, (d2, original index) total order;
+//   B. the running best bounds the answer: the true neighbour lies in the ball B(q, sqrt(best)).  Lanes whose ball (plus the
+//      margin rho * h that keeps next round's temporal-cache bound useful) reaches beyond the home block repeat the same three
+//      steps for the cells of the ball outside the block.  The ball only shrinks afterwards, so two passes always suffice.
+// A lane is resolved by construction: every target it did not scan lies outside its ball or in a cell whose lower bound exceeded
+// the running best.  Lanes with no candidate in the home block, with a ball wider than CELL_SPAN cells, or that do not fit the
+// workgroup's LDS budget join the far list with their best candidate so far and are finished by nn_far_kernel — exactness never
+// depends on the budget.
+constexpr int CELL_HS = 128;      // hash-set slots per wave
+constexpr int CELL_POOL = 960;    // staged points per workgroup (3 x 8 B each), shared by its waves through a bump allocator
+constexpr int CELL_SPAN = 6;      // widest per-lane ball box, cells per axis
+constexpr unsigned int CELL_UNSET = 0xfffffffeu, CELL_NOFIT = 0xffffffffu;
 
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -378,14 +378,97 @@ __device__ __forceinline__ double cell_lb2(const GridView& g, int ix, int iy, in
   return (gx * gx + gy * gy + gz * gz) * 0.999999;
 }
 
+__device__ __forceinline__ bool cell_insert(unsigned long long* __restrict__ hk, unsigned long long key) {
+  unsigned int s = hash_slot(key, 64 - 7) & (CELL_HS - 1);
+  for (int probe = 0; probe < 24; ++probe) {
+    const unsigned long long old = atomicCAS(&hk[s], EMPTY, key);
+    if (old == EMPTY || old == key) return true;
+    s = (s + 1) & (CELL_HS - 1);
+  }
+  return false;   // set (nearly) full
+}
+__device__ __forceinline__ int cell_find(const unsigned long long* __restrict__ hk, unsigned long long key) {
+  unsigned int s = hash_slot(key, 64 - 7) & (CELL_HS - 1);
+  for (int probe = 0; probe < 24; ++probe) {
+    const unsigned long long k = hk[s];
+    if (k == key) return (int)s;
+    if (k == EMPTY) return -1;
+    s = (s + 1) & (CELL_HS - 1);
+  }
+  return -1;
+}
+
+struct CellLane {   // per-lane search state
+  double qx, qy, qz, best, second;
+  int bpos;          // SORTED position of the running best (-1: none)
+  unsigned int n_cand;
+  bool ovf;
+};
+
+// occupancy bit of cell (ix, iy, iz); `be` / `last_b` cache the brick entry across consecutive cells
+__device__ __forceinline__ bool cell_occupied(const GridView& g, int ix, int iy, int iz, BrickEntry& be, long long& last_b) {
+  const long long b = ((long long)(iz >> 2) * g.by + (iy >> 2)) * g.bx + (ix >> 2);
+  if (b != last_b) { be = g.bricks[b]; last_b = b; }
+  return (be.mask >> ((ix & 3) | ((iy & 3) << 2) | ((iz & 3) << 4))) & 1ull;
+}
+
+// stage every cell of the wave's set that has not been staged yet: one lookup + one copy per distinct cell
+__device__ __forceinline__ unsigned int cell_stage(const GridView& g, const unsigned long long* __restrict__ hk, unsigned int* __restrict__ hv,
+                                                   unsigned int* __restrict__ hs, double* __restrict__ sx, double* __restrict__ sy, double* __restrict__ sz,
+                                                   unsigned int* __restrict__ pool, int lane) {
+  unsigned int staged = 0;
+  for (int s = lane; s < CELL_HS; s += 64) {
+    const unsigned long long key = hk[s];
+    if (key == EMPTY || hv[s] != CELL_UNSET) continue;
+    const int ix = (int)(key & 0x1fffffull), iy = (int)((key >> 21) & 0x1fffffull), iz = (int)((key >> 42) & 0x1fffffull);
+    const long long b = ((long long)(iz >> 2) * g.by + (iy >> 2)) * g.bx + (ix >> 2);
+    const unsigned int tab = g.bricks[b].tab;
+    const uint2 run = g.celltab[(size_t)tab * 64 + ((ix & 3) | ((iy & 3) << 2) | ((iz & 3) << 4))];
+    const unsigned int off = run.y <= (unsigned int)CELL_POOL ? atomicAdd(pool, run.y) : (unsigned int)CELL_POOL;
+    if (off + run.y > (unsigned int)CELL_POOL) { hv[s] = CELL_NOFIT; continue; }
+    hs[s] = run.x;
+    const double* __restrict__ src = g.spts + 3 * (size_t)run.x;
+    for (unsigned int k = 0; k < run.y; ++k) { sx[off + k] = src[3 * k]; sy[off + k] = src[3 * k + 1]; sz[off + k] = src[3 * k + 2]; }
+    hv[s] = (off << 16) | run.y;
+    ++staged;
+  }
+  return staged;
+}
+
+// scan one staged cell for the lane
+__device__ __forceinline__ void cell_scan(const GridView& g, CellLane& L, const unsigned long long* __restrict__ hk, const unsigned int* __restrict__ hv,
+                                          const unsigned int* __restrict__ hs, const double* __restrict__ sx, const double* __restrict__ sy,
+                                          const double* __restrict__ sz, unsigned long long key) {
+  const int s = cell_find(hk, key);
+  if (s < 0) { L.ovf = true; return; }
+  const unsigned int v = hv[s];
+  if (v == CELL_NOFIT || v == CELL_UNSET) { L.ovf = true; return; }
+  const unsigned int off = v >> 16, cnt = v & 0xffffu;
+  const int start = (int)hs[s];
+  for (unsigned int k = 0; k < cnt; ++k) {
+    const int pos = start + (int)k;
+    if (pos == L.bpos) continue;   // the running best met again (last round's neighbour is an ordinary target of its cell)
+    const double d = dist2(L.qx, L.qy, L.qz, sx[off + k], sy[off + k], sz[off + k]);
+    if (d < L.best) {
+      if (L.bpos >= 0) L.second = fmin(L.second, L.best);
+      L.best = d; L.bpos = pos;
+    } else {
+      L.second = fmin(L.second, d);
+      if (d == L.best && L.bpos >= 0 && g.sidx[pos] < g.sidx[L.bpos]) L.bpos = pos;   // exact tie: lowest ORIGINAL index (rare: two global loads)
+    }
+  }
+  L.n_cand += cnt;
+}
+
 __global__ __launch_bounds__(NT, 5) void nn_cell_kernel(const GridJob* __restrict__ jobs, double bound, unsigned long long* __restrict__ stats,
                                                         int2* __restrict__ far_list, unsigned int* __restrict__ far_count, double prune_rho) {
   __shared__ double sxf[kEdgeXf];
   __shared__ unsigned long long s_hkey[NT / 64][CELL_HS];
-  __shared__ unsigned int s_hval[NT / 64][CELL_HS];      // (LDS offset << 16) | count, or 0xffffffff: did not fit
+  __shared__ unsigned int s_hval[NT / 64][CELL_HS];      // (LDS offset << 16) | count; CELL_UNSET: not staged yet; CELL_NOFIT: pool exhausted
   __shared__ unsigned int s_hstart[NT / 64][CELL_HS];    // sorted position of the cell's first point
-  __shared__ double s_x[NT / 64][CELL_CAP], s_y[NT / 64][CELL_CAP], s_z[NT / 64][CELL_CAP];
-  __shared__ unsigned int s_cnt[NT / 64];
+  __shared__ double s_x[CELL_POOL], s_y[CELL_POOL], s_z[CELL_POOL];
+  __shared__ unsigned int s_pool;
+  __shared__ unsigned int s_stat[NT / 64][2];
   const GridJob& job = jobs[blockIdx.y];
   if (blockIdx.x * NT >= job.n) return;
   if (threadIdx.x < kEdgeXf) sxf[threadIdx.x] = job.xf[threadIdx.x];
@@ -393,34 +476,33 @@ __global__ __launch_bounds__(NT, 5) void nn_cell_kernel(const GridJob* __restric
   unsigned long long* hk = s_hkey[wave];
   unsigned int* hv = s_hval[wave];
   unsigned int* hs = s_hstart[wave];
-  double* sx = s_x[wave]; double* sy = s_y[wave]; double* sz = s_z[wave];
   hk[lane] = EMPTY; hk[lane + 64] = EMPTY;
-  if (lane == 0) s_cnt[wave] = 0u;
+  hv[lane] = CELL_UNSET; hv[lane + 64] = CELL_UNSET;
+  if (threadIdx.x == 0) s_pool = 0u;
+  if (lane < 2) s_stat[wave][lane] = 0u;
   __syncthreads();
   const int i = blockIdx.x * NT + threadIdx.x;
   const bool active = i < job.n;
   const GridView& g = job.dst;
   const double big = 1.7976931348623157e308;
 
-  double qx = 0.0, qy = 0.0, qz = 0.0, p0 = 0.0, p1 = 0.0, p2 = 0.0;
+  CellLane L;
+  L.qx = L.qy = L.qz = 0.0;
+  L.best = bound;        // nothing at or beyond the cutoff bound needs resolving (frame.cpp:156)
+  L.bpos = -1; L.second = big; L.n_cand = 0; L.ovf = false;
+  double TA2 = big;      // pass A scans the home cells within this squared distance (seeded: old-neighbour distance + margin)
+  double p0 = 0.0, p1 = 0.0, p2 = 0.0;
   if (active) {
     p0 = job.q[3 * (size_t)i]; p1 = job.q[3 * (size_t)i + 1]; p2 = job.q[3 * (size_t)i + 2];
-    xf_point(sxf, p0, p1, p2, qx, qy, qz);
+    xf_point(sxf, p0, p1, p2, L.qx, L.qy, L.qz);
   }
-  double best = bound;       // nothing at or beyond the cutoff bound needs resolving (frame.cpp:156)
-  int bpos = -1;             // SORTED position of the running best (-1: none)
-  double second = big;       // smallest d2 among the scanned targets other than the running best
-  double skipped = big;      // smallest lower bound among the cells not scanned because they cannot beat the running best
-  double Rball = 0.0, R2 = 0.0;
-  bool hit = false, need = false, ovf = false;
-  unsigned int n_cand = 0;
-  int cx0 = 0, cx1 = -1, cy0 = 0, cy1 = -1, cz0 = 0, cz1 = -1;
+  bool hit = false;
   const double tol = 1e-7 * g.h;
-  if (active) {
-    const int pi = job.seed ? job.out_idx[i] : -1;   // sorted position of last round's neighbour
+  if (active && job.seed) {
+    const int pi = job.out_idx[i];   // sorted position of last round's neighbour
     if (pi >= 0 && pi < g.n) {
       const double* tp = g.spts + 3 * (size_t)pi;
-      const double d = dist2(qx, qy, qz, tp[0], tp[1], tp[2]);
+      const double d = dist2(L.qx, L.qy, L.qz, tp[0], tp[1], tp[2]);
       const double slack = sxf[24];
       if (slack >= 0.0 && job.out_lb != nullptr) {
         // temporal cache (see nn_grid_kernel): how far THIS query moved since the last search is |dM p + dv|
@@ -437,116 +519,112 @@ __global__ __launch_bounds__(NT, 5) void nn_cell_kernel(const GridJob* __restric
         }
       }
       if (!hit && d < bound) {
-        best = d; bpos = pi;
-        Rball = sqrt(d) * (1.0 + 1e-12) + prune_rho * g.h;
-        const double Rs = Rball * (1.0 + 1e-9) + tol;
-        R2 = Rs * Rs;
-        const double lim = 2.0e6;
-        cx0 = (int)floor(fmin(fmax((qx - Rs - g.ox) * g.inv_h, -lim), lim)); cx1 = (int)floor(fmin(fmax((qx + Rs - g.ox) * g.inv_h, -lim), lim));
-        cy0 = (int)floor(fmin(fmax((qy - Rs - g.oy) * g.inv_h, -lim), lim)); cy1 = (int)floor(fmin(fmax((qy + Rs - g.oy) * g.inv_h, -lim), lim));
-        cz0 = (int)floor(fmin(fmax((qz - Rs - g.oz) * g.inv_h, -lim), lim)); cz1 = (int)floor(fmin(fmax((qz + Rs - g.oz) * g.inv_h, -lim), lim));
-        // cells outside the grid hold nothing (the grid covers the cloud's bounding box)
-        cx0 = max(cx0, 0); cy0 = max(cy0, 0); cz0 = max(cz0, 0);
-        cx1 = min(cx1, g.dx - 1); cy1 = min(cy1, g.dy - 1); cz1 = min(cz1, g.dz - 1);
-        need = (cx1 - cx0 < CELL_SPAN) && (cy1 - cy0 < CELL_SPAN) && (cz1 - cz0 < CELL_SPAN);
+        // the old neighbour is an ordinary candidate and bounds the search: the answer is within sqrt(d); cells within rho * h more
+        // are scanned too, so that the lower bound left for next round's temporal cache keeps that margin
+        L.best = d; L.bpos = pi;
+        const double ra = (sqrt(d) * (1.0 + 1e-12) + prune_rho * g.h) * (1.0 + 1e-9) + tol;
+        TA2 = ra * ra;
       }
     }
   }
-  // lanes that neither hit the cache nor take part below are finished by phase 2 from their provisional result
+  const bool search = active && !hit;
+  bool resolved = false;
+  double R1 = 0.0;
+  unsigned int n_cells = 0;
 
-  if (__ballot(need) != 0ull) {
-    // ---- 1. occupied cells of every ball -> hash set
-    if (need) {
+  if (__ballot(search) != 0ull) {
+    // ---- pass A: the 2x2x2 block of cells nearest to the query
+    int hx = 0, hy = 0, hz = 0;
+    if (search) {
+      const double lim = 2.0e6;
+      hx = (int)floor(fmin(fmax((L.qx - g.ox) * g.inv_h - 0.5, -lim), lim));
+      hy = (int)floor(fmin(fmax((L.qy - g.oy) * g.inv_h - 0.5, -lim), lim));
+      hz = (int)floor(fmin(fmax((L.qz - g.oz) * g.inv_h - 0.5, -lim), lim));
       long long last_b = -1;
       BrickEntry be; be.mask = 0ull; be.tab = 0u; be.pad = 0u;
-      for (int iz = cz0; iz <= cz1; ++iz)
-        for (int iy = cy0; iy <= cy1; ++iy)
-          for (int ix = cx0; ix <= cx1; ++ix) {
-            if (cell_lb2(g, ix, iy, iz, qx, qy, qz, tol) > R2) continue;
-            const long long b = ((long long)(iz >> 2) * g.by + (iy >> 2)) * g.bx + (ix >> 2);
-            if (b != last_b) { be = g.bricks[b]; last_b = b; }
-            const int bit = (ix & 3) | ((iy & 3) << 2) | ((iz & 3) << 4);
-            if (!((be.mask >> bit) & 1ull)) continue;
-            const unsigned long long key = cell_key(ix, iy, iz);
-            unsigned int s = hash_slot(key, 64 - 7) & (CELL_HS - 1);
-            int probe = 0;
-            for (; probe < 24; ++probe) {
-              const unsigned long long old = atomicCAS(&hk[s], EMPTY, key);
-              if (old == EMPTY || old == key) break;
-              s = (s + 1) & (CELL_HS - 1);
-            }
-            if (probe == 24) ovf = true;   // set (nearly) full: this lane is finished by phase 2
-          }
+      for (int c = 0; c < 8; ++c) {
+        const int ix = hx + (c & 1), iy = hy + ((c >> 1) & 1), iz = hz + (c >> 2);
+        if (ix < 0 || iy < 0 || iz < 0 || ix >= g.dx || iy >= g.dy || iz >= g.dz) continue;
+        if (!cell_occupied(g, ix, iy, iz, be, last_b)) continue;
+        if (cell_lb2(g, ix, iy, iz, L.qx, L.qy, L.qz, tol) > TA2) continue;   // beyond the old neighbour's ball (+ margin)
+        if (!cell_insert(hk, cell_key(ix, iy, iz))) L.ovf = true;
+      }
     }
     wave_sync();
-    // ---- 2. each distinct cell is looked up and staged once per wave
-    for (int s = lane; s < CELL_HS; s += 64) {
-      const unsigned long long key = hk[s];
-      if (key == EMPTY) continue;
-      const int ix = (int)(key & 0x1fffffull), iy = (int)((key >> 21) & 0x1fffffull), iz = (int)((key >> 42) & 0x1fffffull);
-      const long long b = ((long long)(iz >> 2) * g.by + (iy >> 2)) * g.bx + (ix >> 2);
-      const unsigned int tab = g.bricks[b].tab;
-      const int bit = (ix & 3) | ((iy & 3) << 2) | ((iz & 3) << 4);
-      const uint2 run = g.celltab[(size_t)tab * 64 + bit];
-      const unsigned int off = atomicAdd(&s_cnt[wave], run.y);
-      if (off + run.y > (unsigned int)CELL_CAP) { hv[s] = 0xffffffffu; continue; }
-      hv[s] = (off << 16) | run.y;
-      hs[s] = run.x;
-      const double* src = g.spts + 3 * (size_t)run.x;
-      for (unsigned int k = 0; k < run.y; ++k) { sx[off + k] = src[3 * k]; sy[off + k] = src[3 * k + 1]; sz[off + k] = src[3 * k + 2]; }
-    }
+    n_cells += cell_stage(g, hk, hv, hs, s_x, s_y, s_z, &s_pool, lane);
     wave_sync();
-    // ---- 3. every lane scans its own cells from LDS (reference arithmetic, (d2, original index) order)
-    if (need && !ovf) {
+    bool passB = false;
+    int cx0 = 0, cx1 = -1, cy0 = 0, cy1 = -1, cz0 = 0, cz1 = -1;
+    double R2 = 0.0;
+    if (search && !L.ovf) {
       long long last_b = -1;
       BrickEntry be; be.mask = 0ull; be.tab = 0u; be.pad = 0u;
-      for (int iz = cz0; iz <= cz1 && !ovf; ++iz)
-        for (int iy = cy0; iy <= cy1 && !ovf; ++iy)
-          for (int ix = cx0; ix <= cx1; ++ix) {
-            const double lb2 = cell_lb2(g, ix, iy, iz, qx, qy, qz, tol);
-            if (lb2 > R2) continue;
-            const long long b = ((long long)(iz >> 2) * g.by + (iy >> 2)) * g.bx + (ix >> 2);
-            if (b != last_b) { be = g.bricks[b]; last_b = b; }
-            const int bit = (ix & 3) | ((iy & 3) << 2) | ((iz & 3) << 4);
-            if (!((be.mask >> bit) & 1ull)) continue;
-            if (lb2 > best) { skipped = fmin(skipped, lb2); continue; }   // ties are still visited (index rule)
-            const unsigned long long key = cell_key(ix, iy, iz);
-            unsigned int s = hash_slot(key, 64 - 7) & (CELL_HS - 1);
-            int probe = 0;
-            for (; probe < 24; ++probe) {
-              if (hk[s] == key) break;
-              s = (s + 1) & (CELL_HS - 1);
+      for (int c = 0; c < 8 && !L.ovf; ++c) {
+        const int ix = hx + (c & 1), iy = hy + ((c >> 1) & 1), iz = hz + (c >> 2);
+        if (ix < 0 || iy < 0 || iz < 0 || ix >= g.dx || iy >= g.dy || iz >= g.dz) continue;
+        if (!cell_occupied(g, ix, iy, iz, be, last_b)) continue;
+        if (cell_lb2(g, ix, iy, iz, L.qx, L.qy, L.qz, tol) > TA2) continue;   // everything in it is >= sqrt(TA2) >= R1 away
+        cell_scan(g, L, hk, hv, hs, s_x, s_y, s_z, cell_key(ix, iy, iz));
+      }
+      if (!L.ovf && L.bpos >= 0) {
+        // the answer lies in the ball of radius sqrt(best); rho * h more keeps a margin for next round's temporal cache
+        R1 = sqrt(L.best) * (1.0 + 1e-12) + prune_rho * g.h;
+        const double Rs = R1 * (1.0 + 1e-9) + tol;
+        R2 = Rs * Rs;
+        const double lim = 2.0e6;
+        cx0 = (int)floor(fmin(fmax((L.qx - Rs - g.ox) * g.inv_h, -lim), lim)); cx1 = (int)floor(fmin(fmax((L.qx + Rs - g.ox) * g.inv_h, -lim), lim));
+        cy0 = (int)floor(fmin(fmax((L.qy - Rs - g.oy) * g.inv_h, -lim), lim)); cy1 = (int)floor(fmin(fmax((L.qy + Rs - g.oy) * g.inv_h, -lim), lim));
+        cz0 = (int)floor(fmin(fmax((L.qz - Rs - g.oz) * g.inv_h, -lim), lim)); cz1 = (int)floor(fmin(fmax((L.qz + Rs - g.oz) * g.inv_h, -lim), lim));
+        if (cx0 >= hx && cx1 <= hx + 1 && cy0 >= hy && cy1 <= hy + 1 && cz0 >= hz && cz1 <= hz + 1) {
+          resolved = true;   // the ball stays inside the block: done
+        } else {
+          // cells outside the grid hold nothing (the grid covers the cloud's bounding box)
+          cx0 = max(cx0, 0); cy0 = max(cy0, 0); cz0 = max(cz0, 0);
+          cx1 = min(cx1, g.dx - 1); cy1 = min(cy1, g.dy - 1); cz1 = min(cz1, g.dz - 1);
+          passB = (cx1 - cx0 < CELL_SPAN) && (cy1 - cy0 < CELL_SPAN) && (cz1 - cz0 < CELL_SPAN);
+        }
+      }
+    }
+    // ---- pass B: the cells of the ball outside the home block
+    if (__ballot(passB) != 0ull) {
+      if (passB) {
+        long long last_b = -1;
+        BrickEntry be; be.mask = 0ull; be.tab = 0u; be.pad = 0u;
+        for (int iz = cz0; iz <= cz1; ++iz)
+          for (int iy = cy0; iy <= cy1; ++iy)
+            for (int ix = cx0; ix <= cx1; ++ix) {
+              if (ix >= hx && ix <= hx + 1 && iy >= hy && iy <= hy + 1 && iz >= hz && iz <= hz + 1) continue;
+              if (!cell_occupied(g, ix, iy, iz, be, last_b)) continue;
+              if (cell_lb2(g, ix, iy, iz, L.qx, L.qy, L.qz, tol) > R2) continue;      // outside the ball
+              if (!cell_insert(hk, cell_key(ix, iy, iz))) L.ovf = true;
             }
-            if (probe == 24) { ovf = true; break; }
-            const unsigned int v = hv[s];
-            if (v == 0xffffffffu) { ovf = true; break; }
-            const unsigned int off = v >> 16, cnt = v & 0xffffu;
-            const int start = (int)hs[s];
-            for (unsigned int k = 0; k < cnt; ++k) {
-              const int pos = start + (int)k;
-              if (pos == bpos) continue;   // the running best met again (the seed is an ordinary target of its cell)
-              const double d = dist2(qx, qy, qz, sx[off + k], sy[off + k], sz[off + k]);
-              if (d < best) {
-                second = fmin(second, best);
-                best = d; bpos = pos;
-              } else {
-                second = fmin(second, d);
-                if (d == best && g.sidx[pos] < g.sidx[bpos]) bpos = pos;   // exact tie: lowest ORIGINAL index (rare: two global loads)
-              }
+      }
+      wave_sync();
+      n_cells += cell_stage(g, hk, hv, hs, s_x, s_y, s_z, &s_pool, lane);
+      wave_sync();
+      if (passB && !L.ovf) {
+        long long last_b = -1;
+        BrickEntry be; be.mask = 0ull; be.tab = 0u; be.pad = 0u;
+        for (int iz = cz0; iz <= cz1 && !L.ovf; ++iz)
+          for (int iy = cy0; iy <= cy1 && !L.ovf; ++iy)
+            for (int ix = cx0; ix <= cx1 && !L.ovf; ++ix) {
+              if (ix >= hx && ix <= hx + 1 && iy >= hy && iy <= hy + 1 && iz >= hz && iz <= hz + 1) continue;
+              if (!cell_occupied(g, ix, iy, iz, be, last_b)) continue;
+              if (cell_lb2(g, ix, iy, iz, L.qx, L.qy, L.qz, tol) > R2) continue;      // outside the ball: >= R1 away
+              cell_scan(g, L, hk, hv, hs, s_x, s_y, s_z, cell_key(ix, iy, iz));
             }
-            n_cand += cnt;
-          }
+        resolved = !L.ovf;
+      }
     }
   }
 
-  const bool resolved = need && !ovf;
-  if (active && !hit) {
-    job.out_idx[i] = bpos;
-    job.out_d2[i] = best;
-    // every target that was not scanned lies outside the ball (>= Rball) or in a cell whose lower bound exceeded the running best
-    if (job.out_lb != nullptr) job.out_lb[i] = resolved ? sqrt(fmin(fmin(second, skipped), Rball * Rball * (1.0 - 1e-9))) * (1.0 - 1e-12) : 0.0;
+  if (search) {
+    job.out_idx[i] = L.bpos;
+    job.out_d2[i] = L.best;
+    // every target that was not scanned is at least R1 away: outside the ball, or in a home cell beyond sqrt(TA2) >= R1
+    if (job.out_lb != nullptr) job.out_lb[i] = resolved ? sqrt(fmin(L.second, R1 * R1 * (1.0 - 1e-9))) * (1.0 - 1e-12) : 0.0;
     if (resolved) {
-      if (job.dirty) update_list(job, i, bpos, best, bound);
+      if (job.dirty) update_list(job, i, L.bpos, L.best, bound);
     } else {
       const unsigned long long mask = __ballot(1);
       const int leader = __ffsll((long long)mask) - 1;
@@ -557,10 +635,17 @@ __global__ __launch_bounds__(NT, 5) void nn_cell_kernel(const GridJob* __restric
       far_list[base + rank] = make_int2((int)blockIdx.y, i);
     }
   }
-  if (stats && active) {
-    unsigned long long c = __reduce_add_u64((unsigned long long)n_cand), fr = __reduce_add_u64((hit || resolved) ? 0ull : 1ull), hh = __reduce_add_u64(hit ? 1ull : 0ull);
-    const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + (threadIdx.x >> 6);
-    if (__lane0()) { atomicAdd(&stats[4 * slot], c); atomicAdd(&stats[4 * slot + 2], fr); atomicAdd(&stats[4 * slot + 3], hh); }
+  if (stats) {
+    // census (profiling only): candidates scanned, distinct cells staged, far lanes, cache hits — per wave, one slot each
+    if (L.n_cand) atomicAdd(&s_stat[wave][0], L.n_cand);
+    if (n_cells) atomicAdd(&s_stat[wave][1], n_cells);
+    const unsigned long long fr = __ballot(search && !resolved), hh = __ballot(hit);
+    wave_sync();
+    if (lane == 0) {
+      const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + wave;
+      atomicAdd(&stats[4 * slot], (unsigned long long)s_stat[wave][0]); atomicAdd(&stats[4 * slot + 1], (unsigned long long)s_stat[wave][1]);
+      atomicAdd(&stats[4 * slot + 2], (unsigned long long)__popcll(fr)); atomicAdd(&stats[4 * slot + 3], (unsigned long long)__popcll(hh));
+    }
   }
 }
 
@@ -998,10 +1083,10 @@ int run(mvicp_ctx* c, const std::vector<GridJob>& jobs, double bound) {
   {
     ProfScope ps(c, "nn", 36.0 * nq);  // query 24 B + result 12 B; the rest comes from the census below (0 if the census is off)
     const dim3 grid((max_n + NT - 1) / NT, (unsigned)jobs.size());
-    // seeded rounds on clouds with a brick map: the wave-cooperative cell-staging kernel; otherwise (first search of an edge,
-    // raw queries, profiling switches) the per-lane hash kernel
+    // edge searches on clouds with a brick map: the wave-cooperative cell-staging kernel; otherwise (raw queries, profiling
+    // switches, grids too large for a dense brick map) the per-lane hash kernel
     bool use_cell = c->nn_cell && !c->nn_tree_only && !c->nn_skip_far && edge_path;
-    for (const GridJob& j : jobs) if (!j.seed || j.dst.bricks == nullptr || j.xf == nullptr) use_cell = false;
+    for (const GridJob& j : jobs) if (j.dst.bricks == nullptr || j.xf == nullptr) use_cell = false;
     if (c->nn_tree_only)
       hipLaunchKernelGGL((nn_grid_kernel<true>), grid, dim3(NT), 0, c->stream, d_jobs, bound, d_stats, 0, (int2*)c->d_far_list, c->d_far_count, 0.0);
     else if (use_cell)

@@ -310,6 +310,11 @@ int mvicp_optimize(mvicp_ctx* c, double* poses, unsigned char* fixed, int param,
   HostScope hs(c, "host.optimize");
   CtxEval u{c, point_to_plane, robust};
   const int st = lm_solve(c->n_frames, c->E, c->esrc.data(), c->edst.data(), poses, fixed, param, max_iterations, ctx_eval, &u, summary);
+  if (st == MVICP_OK && summary) {   // feeds the AUTO kernel choice of the next search (api.cpp): RMS residual the solve ended on
+    double n = 0.0;
+    for (int e = 0; e < c->E; ++e) n += c->h_count[e];
+    c->last_rms = n > 0.0 && summary->final_cost >= 0.0 ? std::sqrt(2.0 * summary->final_cost / n) : -1.0;
+  }
   if (c->profile) prof_collect(c);
   return st;
 }

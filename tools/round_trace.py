@@ -29,11 +29,11 @@ for name, M in (("grid", L.NN_GRID), ("tile", L.NN_TILE), ("auto", L.NN_AUTO)):
         ms, n, b = eng.profile_get("nn")
         sel_ms = eng.profile_get("select")[0]
         poses, sm = eng.optimize(poses, pb["fixed"], 2, 1, 1, 50)
-        row = (round(ms, 2), round(float(np.mean(w)) / 1.5 * 1e3, 3), sm["iterations"], round(sel_ms, 3))
+        row = (round(ms, 2), round(float(np.mean(w)) / 1.5 * 1e3, 3), sm["iterations"], round(sel_ms, 3), round(float(np.sqrt(2 * sm["final_cost"] / max(1, c.sum()))) * 1e3, 3))
         if census:
             cs = eng.nn_census()
             dq = max(cs["queries"], 1.0)   # profile_reset() zeroes the census too: per-round figures
             row += (float(round(cs["candidates"] / dq, 1)), float(round(cs["hits"] / dq, 3)), float(round(cs["far"] / dq, 3)))
         out.append(row)
-    print(name, "nn_ms, mean median-dist mm, lm iters, select_ms [, cand/q, cache-hit, far]:", out)
+    print(name, "nn_ms, mean median-dist mm, lm iters, select_ms, rms residual after LM mm [, cand/q, cache-hit, far]:", out)
     eng.close()
