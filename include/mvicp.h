@@ -167,9 +167,10 @@ int mvicp_closedform_point_to_plane(const double* src, const double* dst, const 
  * once it has settled; "prune_rho", "auto_settle", "grid_curve": see DESIGN.md.  Tuning knobs: correspondences are
  * bit-identical for every setting. */
 int mvicp_set_option(mvicp_ctx* ctx, const char* name, double value);
-/* NN census accumulated while profiling and the "nn_census" option are on: out[0..4] = queries, candidate points
- * examined, tree boxes tested, queries that needed the tree fallback, queries answered by the temporal cache. */
-int mvicp_nn_census(mvicp_ctx* ctx, double* out5);
+/* NN census accumulated while profiling and the "nn_census" option are on: out[0..5] = queries, candidate points
+ * examined, tree boxes / grid cells looked up, queries that needed the tree fallback, queries answered by the temporal cache,
+ * candidate points fetched from memory (a wave-cooperative kernel fetches a point once and examines it from LDS many times). */
+int mvicp_nn_census(mvicp_ctx* ctx, double* out6);
 
 /* ---- profiling (HIP events on the library's own stream) ------------------------------------------ */
 /* on = 0: off; 1: every scope below; 2: only "nn" and "linearize" (fewer event packets between the kernels of a

@@ -210,7 +210,17 @@ void census_resolve(mvicp_ctx* c) {
   const unsigned long long* st = c->h_census;
   const double nq = c->census_nq;
   ProfEntry& pe = c->prof["nn"];
-  if (c->census_kind == 2) {
+  // SURVEY.md §8(d) algorithmic bytes of an NN launch = 36 B per query (already in the scope) + 24 B per candidate point FETCHED FROM
+  // MEMORY + 8 B per cell / box looked up; the library's own finer model (record widths, cache state) goes to pe.bytes as before
+  if (c->census_kind == 3) {
+    // cell-staging kernel: st[4] points staged into LDS (24 B each, once per wave), st[5] distinct cells looked up per wave (16-B brick
+    // entry + 8-B cell-table entry), st[0] candidates scanned from LDS (no memory traffic), far part (st[1] boxes) from nn_far_kernel
+    const double hits = (double)st[3];
+    pe.bytes += 52.0 * hits + 24.0 * (double)st[4] + 24.0 * (double)st[5] + 32.0 * (double)st[1];
+    c->nn_candidates += (double)st[0]; c->nn_nodes += (double)st[1] + (double)st[5]; c->nn_far += (double)st[2]; c->nn_queries += nq; c->nn_hits += hits;
+    c->nn_fetched += (double)st[4];
+  } else if (c->census_kind == 2) {
+    c->nn_fetched += (double)st[0];
     // tile kernel, memory side: every opened tile is loaded ONCE per wave (24 B xyz + 4 B index per point) and every tested
     // box once per wave (24 B); the per-lane distance evaluations (st[2]) are served from LDS.
     pe.bytes += 28.0 * (double)st[0] + 24.0 * (double)st[1];
@@ -221,6 +231,7 @@ void census_resolve(mvicp_ctx* c) {
     const double hits = (double)st[3], searched = nq - hits;
     pe.bytes += 52.0 * hits + (c->census_kind == 1 ? 8.0 : 136.0) * searched + 32.0 * (double)st[0] + 32.0 * (double)st[1];
     c->nn_candidates += (double)st[0]; c->nn_nodes += (double)st[1]; c->nn_far += (double)st[2]; c->nn_queries += nq; c->nn_hits += hits;
+    c->nn_fetched += (double)st[0];   // per-lane kernel: every candidate examined is a record fetched
   }
 }
 
@@ -516,7 +527,7 @@ int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) {
     c->d_blocks_host = (double*)dp + c->pin_blocks_off;
     c->d_res_host = (double*)dp + c->pin_res_off;
   }
-  if (!c->h_census) MV_HIP(hipHostMalloc((void**)&c->h_census, 4 * sizeof(unsigned long long), hipHostMallocDefault));
+  if (!c->h_census) MV_HIP(hipHostMalloc((void**)&c->h_census, 8 * sizeof(unsigned long long), hipHostMallocDefault));
   return MVICP_OK;
 }
 
@@ -810,10 +821,10 @@ int mvicp_set_option(mvicp_ctx* c, const char* name, double value) {
   set_error("unknown option '%s'", name);
   return MVICP_ERR_ARG;
 }
-int mvicp_nn_census(mvicp_ctx* c, double* out4) {
+int mvicp_nn_census(mvicp_ctx* c, double* out6) {
   MV_CHECK(bind(c));
-  if (!out4) { set_error("null output"); return MVICP_ERR_ARG; }
-  out4[0] = c->nn_queries; out4[1] = c->nn_candidates; out4[2] = c->nn_nodes; out4[3] = c->nn_far; out4[4] = c->nn_hits;
+  if (!out6) { set_error("null output"); return MVICP_ERR_ARG; }
+  out6[0] = c->nn_queries; out6[1] = c->nn_candidates; out6[2] = c->nn_nodes; out6[3] = c->nn_far; out6[4] = c->nn_hits; out6[5] = c->nn_fetched;
   return MVICP_OK;
 }
 
@@ -828,7 +839,7 @@ int mvicp_profile_reset(mvicp_ctx* c) {
   MV_HIP(hipStreamSynchronize(c->stream));
   prof_collect(c);
   for (auto& kv : c->prof) { kv.second.ms = 0; kv.second.launches = 0; kv.second.bytes = 0; }
-  c->nn_candidates = c->nn_nodes = c->nn_far = c->nn_queries = c->nn_hits = 0;
+  c->nn_candidates = c->nn_nodes = c->nn_far = c->nn_queries = c->nn_hits = c->nn_fetched = 0;
   return MVICP_OK;
 }
 int mvicp_profile_get(mvicp_ctx* c, const char* kernel, double* total_ms, long long* launches, double* alg_bytes) {

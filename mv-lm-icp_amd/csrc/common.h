@@ -157,8 +157,8 @@ struct mvicp_ctx {
   double* d_blocks_host = nullptr;  // device view of the blocks region: single-rank evaluations write the E x 91 blocks straight to the host
   double* lin_out = nullptr;        // where the next launch_linearize puts the E x 91 blocks (d_out or d_blocks_host)
   bool spin_wait = false;           // poll the stream instead of a blocking wait (measured: no gain, HIP's own wait already spins)
-  unsigned long long* h_census = nullptr;   // pinned: 4 counters of the last NN launch, resolved after the round's own sync
-  bool census_pending = false; double census_nq = 0; int census_kind = 0;   // kind: 0 grid, 1 tree-only grid, 2 tile
+  unsigned long long* h_census = nullptr;   // pinned: 8 counters of the last NN launch, resolved after the round's own sync
+  bool census_pending = false; double census_nq = 0; int census_kind = 0;   // kind: 0 grid (per-lane), 1 tree-only grid, 2 tile, 3 grid (cell staging)
   // brute-force split scratch
   int* d_split_idx = nullptr; double* d_split_d2 = nullptr; size_t split_cap = 0;
 
@@ -187,12 +187,14 @@ struct mvicp_ctx {
   int tile_waves = 0;              // nn_tile_kernel variant: waves per SIMD it is compiled for (0 = the measured best for the depth)
   double auto_prev_dist = 0.0; int auto_last_method = -1; double auto_settle = 0.5;   // MVICP_NN_AUTO policy state (api.cpp)
   double last_rms = -1.0;          // RMS residual at the end of the last mvicp_optimize since the last search (< 0: none): predicts the next NN distances
-  bool nn_cell = true;             // grid method: wave-cooperative cell staging kernel for seeded rounds (0: per-lane hash kernel everywhere)
+  bool nn_cell = false;            // grid method: wave-cooperative cell-staging kernel (nn_cell_kernel) instead of the per-lane hash kernel.  Exact and
+                                   // tested at full size, but measured SLOWER on MI355X (cfg4 rounds 3-7: 5.4 / 3.2 / 2.3 / 1.7 / 1.0 ms vs 2.3 / 1.8 / 2.6 / 0.9 / 0.6 ms,
+                                   // profiles/r02_nn_cell_experiment.txt): off by default
   double auto_switch = 1.0;        // AUTO: hand over from the tile kernel to the grid method once the median distance is below this many hash cells
   double prune_rho = 0.05;         // grid kernel: with a seed, skip block cells farther than seed distance + prune_rho * cell edge; 0 = off
   int grid_curve = 1;              // cell order of the sorted clouds: 0 Morton (Z-order), 1 Hilbert
   double grid_target = 5.0;        // points per occupied cell the cell-edge heuristic aims at (4-6 measure the same within 2 %)
-  double nn_candidates = 0, nn_nodes = 0, nn_far = 0, nn_queries = 0, nn_hits = 0;
+  double nn_candidates = 0, nn_nodes = 0, nn_far = 0, nn_queries = 0, nn_hits = 0, nn_fetched = 0;
 
   // profiling
   bool profile = false; int profile_level = 0;   // 1: every scope, 2: only "nn" and "linearize"

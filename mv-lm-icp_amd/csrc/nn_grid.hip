@@ -216,7 +216,7 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
           if (stats) {
             unsigned long long c1 = __reduce_add_u64(1ull);
             const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + (threadIdx.x >> 6);
-            if (__lane0()) atomicAdd(&stats[4 * slot + 3], c1);
+            if (__lane0()) atomicAdd(&stats[8 * slot + 3], c1);
           }
           return;
         }
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
     unsigned long long c = n_cand, far = resolved ? 0 : 1;
     c = __reduce_add_u64(c); far = __reduce_add_u64(far);
     const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + (threadIdx.x >> 6);
-    if (__lane0()) { atomicAdd(&stats[4 * slot], c); atomicAdd(&stats[4 * slot + 2], far); }
+    if (__lane0()) { atomicAdd(&stats[8 * slot], c); atomicAdd(&stats[8 * slot + 2], far); }
   }
 }
 
@@ -415,7 +415,7 @@ __device__ __forceinline__ bool cell_occupied(const GridView& g, int ix, int iy,
 // stage every cell of the wave's set that has not been staged yet: one lookup + one copy per distinct cell
 __device__ __forceinline__ unsigned int cell_stage(const GridView& g, const unsigned long long* __restrict__ hk, unsigned int* __restrict__ hv,
                                                    unsigned int* __restrict__ hs, double* __restrict__ sx, double* __restrict__ sy, double* __restrict__ sz,
-                                                   unsigned int* __restrict__ pool, int lane) {
+                                                   unsigned int* __restrict__ pool, int lane, unsigned int* n_pts) {
   unsigned int staged = 0;
   for (int s = lane; s < CELL_HS; s += 64) {
     const unsigned long long key = hk[s];
@@ -430,7 +430,7 @@ __device__ __forceinline__ unsigned int cell_stage(const GridView& g, const unsi
     const double* __restrict__ src = g.spts + 3 * (size_t)run.x;
     for (unsigned int k = 0; k < run.y; ++k) { sx[off + k] = src[3 * k]; sy[off + k] = src[3 * k + 1]; sz[off + k] = src[3 * k + 2]; }
     hv[s] = (off << 16) | run.y;
-    ++staged;
+    ++staged; *n_pts += run.y;
   }
   return staged;
 }
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(NT, 5) void nn_cell_kernel(const GridJob* __restric
   __shared__ unsigned int s_hstart[NT / 64][CELL_HS];    // sorted position of the cell's first point
   __shared__ double s_x[CELL_POOL], s_y[CELL_POOL], s_z[CELL_POOL];
   __shared__ unsigned int s_pool;
-  __shared__ unsigned int s_stat[NT / 64][2];
+  __shared__ unsigned int s_stat[NT / 64][3];
   const GridJob& job = jobs[blockIdx.y];
   if (blockIdx.x * NT >= job.n) return;
   if (threadIdx.x < kEdgeXf) sxf[threadIdx.x] = job.xf[threadIdx.x];
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(NT, 5) void nn_cell_kernel(const GridJob* __restric
   hk[lane] = EMPTY; hk[lane + 64] = EMPTY;
   hv[lane] = CELL_UNSET; hv[lane + 64] = CELL_UNSET;
   if (threadIdx.x == 0) s_pool = 0u;
-  if (lane < 2) s_stat[wave][lane] = 0u;
+  if (lane < 3) s_stat[wave][lane] = 0u;
   __syncthreads();
   const int i = blockIdx.x * NT + threadIdx.x;
   const bool active = i < job.n;
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(NT, 5) void nn_cell_kernel(const GridJob* __restric
   const bool search = active && !hit;
   bool resolved = false;
   double R1 = 0.0;
-  unsigned int n_cells = 0;
+  unsigned int n_cells = 0, n_pts = 0;
 
   if (__ballot(search) != 0ull) {
     // ---- pass A: the 2x2x2 block of cells nearest to the query
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(NT, 5) void nn_cell_kernel(const GridJob* __restric
       }
     }
     wave_sync();
-    n_cells += cell_stage(g, hk, hv, hs, s_x, s_y, s_z, &s_pool, lane);
+    n_cells += cell_stage(g, hk, hv, hs, s_x, s_y, s_z, &s_pool, lane, &n_pts);
     wave_sync();
     bool passB = false;
     int cx0 = 0, cx1 = -1, cy0 = 0, cy1 = -1, cz0 = 0, cz1 = -1;
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(NT, 5) void nn_cell_kernel(const GridJob* __restric
             }
       }
       wave_sync();
-      n_cells += cell_stage(g, hk, hv, hs, s_x, s_y, s_z, &s_pool, lane);
+      n_cells += cell_stage(g, hk, hv, hs, s_x, s_y, s_z, &s_pool, lane, &n_pts);
       wave_sync();
       if (passB && !L.ovf) {
         long long last_b = -1;
@@ -638,13 +638,14 @@ __global__ __launch_bounds__(NT, 5) void nn_cell_kernel(const GridJob* __restric
   if (stats) {
     // census (profiling only): candidates scanned, distinct cells staged, far lanes, cache hits — per wave, one slot each
     if (L.n_cand) atomicAdd(&s_stat[wave][0], L.n_cand);
-    if (n_cells) atomicAdd(&s_stat[wave][1], n_cells);
+    if (n_cells) { atomicAdd(&s_stat[wave][1], n_cells); atomicAdd(&s_stat[wave][2], n_pts); }
     const unsigned long long fr = __ballot(search && !resolved), hh = __ballot(hit);
     wave_sync();
     if (lane == 0) {
       const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + wave;
-      atomicAdd(&stats[4 * slot], (unsigned long long)s_stat[wave][0]); atomicAdd(&stats[4 * slot + 1], (unsigned long long)s_stat[wave][1]);
-      atomicAdd(&stats[4 * slot + 2], (unsigned long long)__popcll(fr)); atomicAdd(&stats[4 * slot + 3], (unsigned long long)__popcll(hh));
+      atomicAdd(&stats[8 * slot], (unsigned long long)s_stat[wave][0]); atomicAdd(&stats[8 * slot + 5], (unsigned long long)s_stat[wave][1]);
+      atomicAdd(&stats[8 * slot + 4], (unsigned long long)s_stat[wave][2]);
+      atomicAdd(&stats[8 * slot + 2], (unsigned long long)__popcll(fr)); atomicAdd(&stats[8 * slot + 3], (unsigned long long)__popcll(hh));
     }
   }
 }
@@ -779,22 +780,22 @@ __global__ __launch_bounds__(NT) void nn_far_kernel(const GridJob* __restrict__ 
     unsigned long long c = l == 0 ? n_cand : 0, nd = l == 0 ? n_nodes : 0;
     c = __reduce_add_u64(c); nd = __reduce_add_u64(nd);
     const size_t slot = ((size_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6)) % stats_slots;
-    if (__lane0()) { atomicAdd(&stats[4 * slot], c); atomicAdd(&stats[4 * slot + 1], nd); }
+    if (__lane0()) { atomicAdd(&stats[8 * slot], c); atomicAdd(&stats[8 * slot + 1], nd); }
   }
 }
 
-// sums the per-wave census slots (4 counters each) into out4 (zeroed by the caller); 64 workgroups, 4 atomics each
-__global__ __launch_bounds__(256) void census_sum_kernel(const unsigned long long* __restrict__ stats, size_t slots, unsigned long long* __restrict__ out4) {
-  __shared__ unsigned long long sh[4][256];
-  unsigned long long v[4] = {0, 0, 0, 0};
+// sums the per-wave census slots (8 counters each) into out8 (zeroed by the caller); 64 workgroups, 8 atomics each
+__global__ __launch_bounds__(256) void census_sum_kernel(const unsigned long long* __restrict__ stats, size_t slots, unsigned long long* __restrict__ out8) {
+  __shared__ unsigned long long sh[8][256];
+  unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < slots; i += (size_t)gridDim.x * 256)
-    for (int k = 0; k < 4; ++k) v[k] += stats[4 * i + k];
-  for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] = v[k];
+    for (int k = 0; k < 8; ++k) v[k] += stats[8 * i + k];
+  for (int k = 0; k < 8; ++k) sh[k][threadIdx.x] = v[k];
   __syncthreads();
-  if (threadIdx.x < 4) {
+  if (threadIdx.x < 8) {
     unsigned long long s = 0;
     for (int i = 0; i < 256; ++i) s += sh[threadIdx.x][i];
-    atomicAdd(&out4[threadIdx.x], s);
+    atomicAdd(&out8[threadIdx.x], s);
   }
 }
 
@@ -1056,7 +1057,7 @@ int run(mvicp_ctx* c, const std::vector<GridJob>& jobs, double bound) {
   unsigned long long* d_stats = nullptr;
   const size_t slots = (size_t)((max_n + NT - 1) / NT) * jobs.size() * (NT / 64);
   if (c->profile && c->nn_census) {
-    const size_t need = sizeof(unsigned long long) * 4 * (slots + 1);
+    const size_t need = sizeof(unsigned long long) * 8 * (slots + 1);
     if (need > c->census_bytes) {
       if (c->d_census) MV_HIP(hipFree(c->d_census));
       MV_HIP(hipMalloc((void**)&c->d_census, need));
@@ -1080,12 +1081,13 @@ int run(mvicp_ctx* c, const std::vector<GridJob>& jobs, double bound) {
     MV_HIP(hipMemsetAsync(c->d_far_count, 0, sizeof(unsigned int), c->stream));
   }
   c->far_count_clean = edge_path;
+  bool use_cell = false;
   {
     ProfScope ps(c, "nn", 36.0 * nq);  // query 24 B + result 12 B; the rest comes from the census below (0 if the census is off)
     const dim3 grid((max_n + NT - 1) / NT, (unsigned)jobs.size());
     // edge searches on clouds with a brick map: the wave-cooperative cell-staging kernel; otherwise (raw queries, profiling
     // switches, grids too large for a dense brick map) the per-lane hash kernel
-    bool use_cell = c->nn_cell && !c->nn_tree_only && !c->nn_skip_far && edge_path;
+    use_cell = c->nn_cell && !c->nn_tree_only && !c->nn_skip_far && edge_path;
     for (const GridJob& j : jobs) if (j.dst.bricks == nullptr || j.xf == nullptr) use_cell = false;
     if (c->nn_tree_only)
       hipLaunchKernelGGL((nn_grid_kernel<true>), grid, dim3(NT), 0, c->stream, d_jobs, bound, d_stats, 0, (int2*)c->d_far_list, c->d_far_count, 0.0);
@@ -1102,11 +1104,11 @@ int run(mvicp_ctx* c, const std::vector<GridJob>& jobs, double bound) {
   }
   MV_HIP(hipGetLastError());
   if (d_stats) {
-    if (!c->h_census) MV_HIP(hipHostMalloc((void**)&c->h_census, 4 * sizeof(unsigned long long), hipHostMallocDefault));
+    if (!c->h_census) MV_HIP(hipHostMalloc((void**)&c->h_census, 8 * sizeof(unsigned long long), hipHostMallocDefault));
     // counters -> pinned memory, asynchronously; census_resolve() folds them in after the caller's own wait (no extra sync)
-    hipLaunchKernelGGL(census_sum_kernel, dim3(64), dim3(256), 0, c->stream, d_stats, slots, d_stats + 4 * slots);
-    MV_HIP(hipMemcpyAsync(c->h_census, d_stats + 4 * slots, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-    c->census_pending = true; c->census_nq = nq; c->census_kind = c->nn_tree_only ? 1 : 0;
+    hipLaunchKernelGGL(census_sum_kernel, dim3(64), dim3(256), 0, c->stream, d_stats, slots, d_stats + 8 * slots);
+    MV_HIP(hipMemcpyAsync(c->h_census, d_stats + 8 * slots, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    c->census_pending = true; c->census_nq = nq; c->census_kind = c->nn_tree_only ? 1 : (use_cell ? 3 : 0);
   }
   return MVICP_OK;
 }

@@ -373,22 +373,22 @@ __global__ __launch_bounds__(NT, WPE) void nn_tile_kernel(const TileJob* __restr
     // wave-uniform counters: candidates examined PER LANE x active lanes, boxes tested per wave
     const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + wave;
     const unsigned long long act = (unsigned long long)min(64, job.n - (i & ~63));
-    stats[4 * slot] = n_cand; stats[4 * slot + 1] = n_box; stats[4 * slot + 2] = (unsigned long long)n_cand * act;
+    stats[8 * slot] = n_cand; stats[8 * slot + 1] = n_box; stats[8 * slot + 2] = (unsigned long long)n_cand * act;
   }
 }
 
-// sums the per-wave census slots (4 counters each) into out4 (zeroed by the caller); 64 workgroups, 4 atomics each
-__global__ __launch_bounds__(256) void census_sum_kernel(const unsigned long long* __restrict__ stats, size_t slots, unsigned long long* __restrict__ out4) {
-  __shared__ unsigned long long sh[4][256];
-  unsigned long long v[4] = {0, 0, 0, 0};
+// sums the per-wave census slots (8 counters each) into out8 (zeroed by the caller); 64 workgroups, 8 atomics each
+__global__ __launch_bounds__(256) void census_sum_kernel(const unsigned long long* __restrict__ stats, size_t slots, unsigned long long* __restrict__ out8) {
+  __shared__ unsigned long long sh[8][256];
+  unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < slots; i += (size_t)gridDim.x * 256)
-    for (int k = 0; k < 4; ++k) v[k] += stats[4 * i + k];
-  for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] = v[k];
+    for (int k = 0; k < 8; ++k) v[k] += stats[8 * i + k];
+  for (int k = 0; k < 8; ++k) sh[k][threadIdx.x] = v[k];
   __syncthreads();
-  if (threadIdx.x < 4) {
+  if (threadIdx.x < 8) {
     unsigned long long s = 0;
     for (int i = 0; i < 256; ++i) s += sh[threadIdx.x][i];
-    atomicAdd(&out4[threadIdx.x], s);
+    atomicAdd(&out8[threadIdx.x], s);
   }
 }
 
@@ -475,7 +475,7 @@ int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound) {
   unsigned long long* d_stats = nullptr;
   const size_t slots = (size_t)((max_n + NT - 1) / NT) * jobs.size() * (NT / 64);
   if (c->profile && c->nn_census) {
-    const size_t need = sizeof(unsigned long long) * 4 * (slots + 1);
+    const size_t need = sizeof(unsigned long long) * 8 * (slots + 1);
     if (need > c->census_bytes) {
       if (c->d_census) MV_HIP(hipFree(c->d_census));
       MV_HIP(hipMalloc((void**)&c->d_census, need));
@@ -505,10 +505,10 @@ int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound) {
   }
   MV_HIP(hipGetLastError());
   if (d_stats) {
-    if (!c->h_census) MV_HIP(hipHostMalloc((void**)&c->h_census, 4 * sizeof(unsigned long long), hipHostMallocDefault));
+    if (!c->h_census) MV_HIP(hipHostMalloc((void**)&c->h_census, 8 * sizeof(unsigned long long), hipHostMallocDefault));
     // counters -> pinned memory, asynchronously; census_resolve() folds them in after the caller's own wait (no extra sync)
-    hipLaunchKernelGGL(census_sum_kernel, dim3(64), dim3(256), 0, c->stream, d_stats, slots, d_stats + 4 * slots);
-    MV_HIP(hipMemcpyAsync(c->h_census, d_stats + 4 * slots, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    hipLaunchKernelGGL(census_sum_kernel, dim3(64), dim3(256), 0, c->stream, d_stats, slots, d_stats + 8 * slots);
+    MV_HIP(hipMemcpyAsync(c->h_census, d_stats + 8 * slots, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     c->census_pending = true; c->census_nq = nq; c->census_kind = 2;
   }
   return MVICP_OK;

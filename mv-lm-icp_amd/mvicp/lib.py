@@ -285,9 +285,9 @@ class Engine:
         _check(self.lib, self.lib.mvicp_set_option(self.h, name.encode(), float(value)))
 
     def nn_census(self):
-        out = np.zeros(5)
+        out = np.zeros(6)
         _check(self.lib, self.lib.mvicp_nn_census(self.h, _dp(out)))
-        return {"queries": out[0], "candidates": out[1], "nodes": out[2], "far": out[3], "hits": out[4]}
+        return {"queries": out[0], "candidates": out[1], "nodes": out[2], "far": out[3], "hits": out[4], "fetched": out[5]}
 
     # ---- profiling
     def profile(self, on=True):

@@ -362,7 +362,8 @@ struct Evaluator {
       const double* dnor = pb.nor + 3 * (size_t)pb.foff[d];
       const double a = pb.robust ? (double)pb.eweight[e] : 0.0;
       const int fs = fidx[s], fd = fidx[d];
-      for (int c = pb.eoff[e]; c < pb.eoff[e + 1]; ++c) {
+      // one correspondence: residual, (local) Jacobian rows, robust corrector, scatter into (Hq, gq, costq)
+      auto one = [&](int c, double* Hq, double* gq, double& costq) {
         const double* ps = spts + 3 * (size_t)pb.first[c];
         const double* pd = dpts + 3 * (size_t)pb.second[c];
         const double* pn = dnor + 3 * (size_t)pb.second[c];
@@ -402,12 +403,12 @@ struct Evaluator {
         if (pb.robust) {
           double rho[3];
           soft_l_one(a, sq, rho);
-          cost += 0.5 * rho[0];
+          costq += 0.5 * rho[0];
           scale = std::sqrt(rho[1]);  // Corrector: rho[2] <= 0 -> residual_scaling = sqrt(rho'), alpha = 0
         } else {
-          cost += 0.5 * sq;
+          costq += 0.5 * sq;
         }
-        if (!jac) continue;
+        if (!jac) return;
         for (int k = 0; k < nres; ++k) {
           const double rk = r[k] * scale;
           double* row = Jl[k];
@@ -418,17 +419,36 @@ struct Evaluator {
             if (fi < 0) continue;
             for (int li = 0; li < 6; ++li) {
               const double ji = row[bi * 6 + li];
-              g[fi * 6 + li] += ji * rk;
+              gq[fi * 6 + li] += ji * rk;
               for (int bj = 0; bj < 2; ++bj) {
                 const int fj = bj == 0 ? fs : fd;
                 if (fj < 0) continue;
-                double* Hrow = H + (size_t)(fi * 6 + li) * nn + fj * 6;
+                double* Hrow = Hq + (size_t)(fi * 6 + li) * nn + fj * 6;
                 for (int lj = 0; lj < 6; ++lj) Hrow[lj] += ji * row[bj * 6 + lj];
               }
             }
           }
         }
+      };
+#ifdef _OPENMP
+      // all-cores build (cpu_baseline only; oracle/Makefile `fast`): thread-private accumulators, summed per edge.  The default build
+      // has no -fopenmp and runs the serial loop below — the arithmetic order every parity test was pinned on.
+#pragma omp parallel
+      {
+        std::vector<double> Hp, gp;
+        double costp = 0.0;
+        if (jac) { Hp.assign((size_t)nn * nn, 0.0); gp.assign(nn, 0.0); }
+#pragma omp for schedule(static) nowait
+        for (int c = pb.eoff[e]; c < pb.eoff[e + 1]; ++c) one(c, Hp.data(), gp.data(), costp);
+#pragma omp critical
+        {
+          cost += costp;
+          if (jac) { for (size_t k = 0; k < (size_t)nn * nn; ++k) H[k] += Hp[k]; for (int k = 0; k < nn; ++k) g[k] += gp[k]; }
+        }
       }
+#else
+      for (int c = pb.eoff[e]; c < pb.eoff[e + 1]; ++c) one(c, H, g, cost);
+#endif
     }
     return cost;
   }

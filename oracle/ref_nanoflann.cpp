@@ -59,6 +59,8 @@ void ref_nn_free(void* h) {
 // frame.cpp:195-205 for a batch of queries already expressed in the dst frame.
 void ref_nn_query(void* h, const double* queries, int n, int* idx, double* d2) {
   Index* ix = (Index*)h;
+  // (queries are independent; the pragma is live only in the -fopenmp `fast` build used by bench.py's all-cores CPU figure)
+#pragma omp parallel for schedule(dynamic, 2048)
   for (int k = 0; k < n; ++k) {
     size_t ret_index = 0;
     double out_dist_sqr = 0;
