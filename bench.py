@@ -1,17 +1,19 @@
 #!/usr/bin/env python3
 """bench.py — ICP iterations/sec of the MI355X multiview LM-ICP hot path (BASELINE.json metric).
 
-One "step" = one outer ICP iteration = the loop body of the reference's src/main_multiview.cpp:150-169
-without visualisation: correspondence search over all E edges (NN + cutoff + median) followed by one LM
-solve (<= 50 iterations; one device linearization per LM iteration + the host dense solve).
+One "step" = one outer ICP iteration = the loop body of the reference's src/main_multiview.cpp:150-169 without
+visualisation: correspondence search over all E edges (NN + cutoff + median) followed by one LM solve (<= 50 iterations;
+one device linearization per LM iteration + the host solve).  The timed rounds are rounds warmup+1 .. warmup+steps of ONE
+registration that starts from the noisy initial poses, so how many of them still move the poses depends on --warmup/--steps:
+the JSON line reports the two regimes separately (`regimes`) next to `value` (all timed rounds).
 
-    python bench.py [--gpus N --steps K --warmup W] [--workload cfg2|cfg3|cfg4|cfg5|tiny]
+    python bench.py [--gpus N --steps K --warmup W] [--workload cfg2|cfg3|cfg4|cfg5|tiny|shard8]
 
-N > 1: launched by torch.distributed.run, one rank per GPU; edges are sharded across ranks and the
-per-edge normal-equation blocks are summed with an RCCL all-reduce per LM evaluation (strong scaling:
-the problem is fixed).  Rank 0 prints ONE JSON line.
+N > 1: launched by torch.distributed.run, one rank per GPU; edges are sharded across ranks and the per-edge normal-equation
+blocks are summed with an RCCL all-reduce per LM evaluation (strong scaling: the problem is fixed).  Rank 0 prints ONE JSON line.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -33,57 +35,136 @@ WORKLOADS = {
     "shard8": (5, 200_000, 1, 2, "shard8: 5 views x 200k pts (E=8): the per-rank share of cfg4 on 8 GPUs, for fixed-cost analysis"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
+PROFILE_ROUND = "r02"
 
 
-def cpu_baseline(pb, plane, param, n_edges_full, budget_views=4, rounds=2):
-    """Reference-equivalent CPU path on a bounded sample of the SAME clouds: NN = the real vendored nanoflann
-    (oracle/_ref, 1 thread) when present, LM = the oracle's Jet-based restatement of Ceres (1 thread)."""
+def source_sha16():
+    """Hash of the sources the device path is built from: a committed rocprofv3 summary is only quoted for the code it measured."""
+    h = hashlib.sha256()
+    pkg = os.path.join(ROOT, "mv-lm-icp_amd")
+    files = []
+    for sub in ("csrc", "host"):
+        d = os.path.join(pkg, sub)
+        files += sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith((".hip", ".cpp", ".h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_features():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                return set(line.split(":", 1)[1].split())
+    except OSError:
+        pass
+    return set()
+
+
+def cpu_baseline(pb, plane, param, n_edges_full, round_poses, moved, sample_views=3):
+    """Reference-equivalent CPU path timed on a bounded sample of the SAME workload and the SAME rounds: the first `sample_views`
+    views (their edges), started from the poses the GPU run had at the beginning of (a) its first timed round that moved the poses
+    and (b) its last timed round; per-round time = NN for the sample's edges (real vendored nanoflann, oracle/_ref) + one LM solve
+    (the oracle's Jet/autodiff restatement of Ceres; Ceres itself is not installed), scaled by the edge count and weighted by how
+    many timed rounds were of each kind.  Variants: -O2 single thread (the reference's build: CMakeLists.txt:14-22, Ceres
+    num_threads 1), -O3 AVX2 single thread, -O3 AVX2 + OpenMP on every core."""
+    import ctypes as C
     import orclib
-    orc = orclib.load()
-    ref = orclib.load_ref()
-    Ks = min(budget_views, len(pb["pts"]))
+    Ks = min(sample_views, len(pb["pts"]))
     keep = [e for e, (s, d) in enumerate(zip(pb["src"], pb["dst"])) if s < Ks and d < Ks]
     src = pb["src"][keep]; dst = pb["dst"][keep]
     pts, nor = pb["pts"][:Ks], pb["nor"][:Ks]
-    poses = pb["init"][:Ks].copy()
     fixed = pb["fixed"][:Ks]
-    t0 = time.perf_counter()
-    trees = {}
-    import ctypes as C
-    if ref is not None:
-        for d in sorted(set(dst.tolist())):
-            p = np.ascontiguousarray(pts[d])
-            trees[d] = C.c_void_p(ref.lib.ref_nn_build(p.ctypes.data_as(C.c_void_p), C.c_int(len(p))))
-    t_build = time.perf_counter() - t0
-    t_round = []
-    for r in range(rounds):
-        t1 = time.perf_counter()
+    moving_rounds = [r for r, m in enumerate(moved) if m]
+    fixed_rounds = [r for r, m in enumerate(moved) if not m]
+    samples = {}
+    if moving_rounds:
+        samples["moving"] = moving_rounds[0]
+    if fixed_rounds:
+        samples["fixed_point"] = fixed_rounds[-1]
+
+    def load_variant(fast):
+        osuf = "_fast" if fast else ""
+        orc_so = os.path.join(ROOT, "oracle", "_build", f"liborc{osuf}.so")
+        ref_so = os.path.join(ROOT, "oracle", "_ref", f"libref_nanoflann{osuf}.so")
+        if not os.path.exists(orc_so):
+            return None
+        orc = orclib.Oracle(C.CDLL(orc_so))
+        ref = orclib.RefNN(C.CDLL(ref_so)) if os.path.exists(ref_so) else None
+        return orc, ref
+
+    def one_round(orc, ref, poses0):
+        t0 = time.perf_counter()
         corr, w = [], []
         for s, d in zip(src, dst):
             if ref is not None:
-                q = orc.query_transform(poses[s], poses[d], pts[s])
+                q = orc.query_transform(poses0[s], poses0[d], pts[s])
                 idx = np.empty(len(q), dtype=np.int32); d2 = np.empty(len(q), dtype=np.float64)
                 ref.lib.ref_nn_query(trees[d], q.ctypes.data_as(C.c_void_p), C.c_int(len(q)), idx.ctypes.data_as(C.c_void_p), d2.ctypes.data_as(C.c_void_p))
                 f, sec, dist, wt = orc.filter_median(idx, d2, 0.05)
             else:
-                f, sec, dist, wt, _, _ = orc.correspond_edge(pts[s], poses[s], pts[d], poses[d], 0.05)
+                f, sec, dist, wt, _, _ = orc.correspond_edge(pts[s], poses0[s], pts[d], poses0[d], 0.05)
             corr.append((f, sec)); w.append(wt)
+        t1 = time.perf_counter()
         prob = orc.make_problem(pts, nor, fixed, src, dst, corr, w, param, plane, 1)
-        poses, sm = orc.optimize(prob, poses, 50)
-        t_round.append(time.perf_counter() - t1)
-    for h in trees.values():
-        ref.lib.ref_nn_free(h)
-    per_round_sample = float(np.mean(t_round))
+        _, sm = orc.optimize(prob, poses0, 50)
+        t2 = time.perf_counter()
+        return t1 - t0, t2 - t1, sm["iterations"]
+
+    feats = cpu_features()
+    fast_ok = {"avx2", "fma", "bmi2"} <= feats
+    ncores = os.cpu_count() or 1
+    try:
+        gomp = C.CDLL("libgomp.so.1")
+    except OSError:
+        gomp = None
+    variants = [("O2_1thread", False, 1)]
+    if fast_ok and gomp is not None:
+        variants += [("O3_avx2_1thread", True, 1), ("O3_avx2_allcores", True, ncores)]
     scale = n_edges_full / max(1, len(keep))
-    per_round_full = per_round_sample * scale
+    out_var = {}
+    tree_build_s = None
+    for name, fast, threads in variants:
+        lv = load_variant(fast)
+        if lv is None:
+            continue
+        orc, ref = lv
+        if gomp is not None:
+            gomp.omp_set_num_threads(C.c_int(threads))
+        trees = {}
+        tb = time.perf_counter()
+        if ref is not None:
+            ref.lib.ref_nn_build.restype = C.c_void_p
+            for d in sorted(set(dst.tolist())):
+                p = np.ascontiguousarray(pts[d])
+                trees[d] = C.c_void_p(ref.lib.ref_nn_build(p.ctypes.data_as(C.c_void_p), C.c_int(len(p))))
+        if tree_build_s is None:
+            tree_build_s = time.perf_counter() - tb
+        per_kind = {}
+        for kind, r in samples.items():
+            nn_s, lm_s, iters = one_round(orc, ref, np.ascontiguousarray(round_poses[r][:Ks]))
+            per_kind[kind] = {"round": r, "nn_s_sample": nn_s, "lm_s_sample": lm_s, "lm_iterations": iters, "s_per_round_full": (nn_s + lm_s) * scale}
+        if ref is not None:
+            for h in trees.values():
+                ref.lib.ref_nn_free(h)
+        n_m, n_f = len(moving_rounds), len(fixed_rounds)
+        tot = 0.0
+        for kind, n in (("moving", n_m), ("fixed_point", n_f)):
+            if n:
+                tot += n * per_kind[kind]["s_per_round_full"]
+        s_per_round = tot / max(1, n_m + n_f)
+        out_var[name] = {"value": 1.0 / s_per_round, "unit": "iterations/s", "cores": threads, "s_per_round": s_per_round, "by_regime": per_kind}
+    base = out_var["O2_1thread"]
     return {
-        "value": 1.0 / per_round_full, "unit": "iterations/s", "cores": 1,
-        "kind": "port",
-        "sample": (f"first {Ks} views of the same clouds ({len(keep)} of {n_edges_full} edges, N={len(pts[0])}), {rounds} ICP rounds from the same initial "
-                   f"poses, mean {per_round_sample:.2f} s/round, scaled x{scale:.2f} by edge count; NN = "
-                   + ("real vendored nanoflann (oracle/_ref)" if ref is not None else "oracle brute force")
-                   + ", LM = oracle Jet/autodiff restatement of Ceres (Ceres itself not installed); single thread like the reference"),
-        "tree_build_s": t_build,
+        "value": base["value"], "unit": "iterations/s", "cores": 1, "kind": "port",
+        "sample": (f"first {Ks} views of the same clouds ({len(keep)} of {n_edges_full} edges, N={len(pts[0])}); started from the GPU run's poses at the "
+                   f"start of timed round {samples.get('moving', '-')} (first timed round that moved the poses) and of timed round {samples.get('fixed_point', '-')} "
+                   f"(last timed round, poses stationary); each = NN of the sample's edges (real vendored nanoflann, oracle/_ref) + one LM solve (oracle "
+                   f"Jet/autodiff restatement of Ceres; Ceres is not installed); scaled x{scale:.2f} by edge count and weighted {len(moving_rounds)} moving : "
+                   f"{len(fixed_rounds)} stationary rounds like the timed GPU window.  value = -O2, 1 thread (the reference's build and threading)"),
+        "variants": out_var, "tree_build_s_sample": tree_build_s, "host_cores": ncores,
+        "fast_build_note": "-O3 -march=x86-64-v3 (AVX2/FMA, portable stand-in for -march=native: the .so is built off-box), -ffp-contract=off; all-cores = OpenMP over correspondences / queries",
     }
 
 
@@ -95,6 +176,8 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("MVICP_WORKLOAD", "cfg4"))
     ap.add_argument("--nn", default="auto", choices=["auto", "brute", "grid", "tile"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-replay", action="store_true", help="skip the untimed census replay pass (profiling runs: keeps the kernel trace to the timed protocol)")
+    ap.add_argument("--allow-host-exchange", action="store_true", help="N > 1 only: if the RCCL communicator cannot be created, fall back to a host-staged gloo all-reduce instead of failing")
     ap.add_argument("--grid-target", type=float, default=None)
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (mvicp_set_option), repeatable; tuning / A-B runs")
     args = ap.parse_args()
@@ -128,6 +211,7 @@ def main():
         eng.set_option(name, float(val))
     eng.set_frames(pb["pts"], pb["nor"])
     eng.set_graph(pb["src"], pb["dst"])
+    exchange = "none"
     if world > 1:
         rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         rccl = rccl if os.path.exists(rccl) else None
@@ -135,15 +219,23 @@ def main():
         if rank == 0:
             uid.copy_(torch.frombuffer(bytearray(mvicp.Engine.comm_unique_id(rccl)), dtype=torch.uint8))
         dist.broadcast(uid, 0)
+        err = ""
         try:
             eng.comm_init(bytes(uid.cpu().numpy().tobytes()), rccl)
             ok = torch.ones(1, device="cuda")
-        except Exception as ex:  # keep the run alive: host-staged exchange over gloo (slower, same results)
-            print(f"[bench] rank {rank}: RCCL communicator unavailable ({ex}); falling back to the host-staged all-reduce", file=sys.stderr)
+        except Exception as ex:
+            err = str(ex)
             ok = torch.zeros(1, device="cuda")
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         exchange = "rccl all-reduce of per-edge blocks"
         if ok.item() == 0:
+            if not args.allow_host_exchange:
+                # the measured path must be the RCCL one: fail loudly instead of silently timing a host-staged exchange
+                print(f"[bench] rank {rank}: RCCL communicator unavailable ({err or 'failed on another rank'}); pass --allow-host-exchange to time the "
+                      f"host-staged gloo fallback instead", file=sys.stderr)
+                eng.close()
+                dist.destroy_process_group()
+                sys.exit(3)
             gloo = dist.new_group(backend="gloo")
 
             def _host_allreduce(a):
@@ -151,22 +243,24 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=gloo)
 
             eng.comm_set_callback(_host_allreduce)
-            exchange = "host-staged gloo all-reduce (RCCL init failed)"
-    if world == 1:
-        exchange = "none"
+            exchange = "host-staged gloo all-reduce (RCCL init failed; --allow-host-exchange)"
     method = {"auto": L.NN_AUTO, "brute": L.NN_BRUTE, "grid": L.NN_GRID, "tile": L.NN_TILE}[args.nn]
 
     poses = pb["init"].copy()
     log = []
+    round_poses = []
 
     def step():
         nonlocal poses
+        before = poses
+        round_poses.append(before)
         t0 = time.perf_counter()
         counts, weights = eng.correspond(poses, pb["fixed"], 0.05, method)
         t1 = time.perf_counter()
         poses, sm = eng.optimize(poses, pb["fixed"], param, plane, True, 50)
         t2 = time.perf_counter()
-        log.append({"nn_ms": (t1 - t0) * 1e3, "lm_ms": (t2 - t1) * 1e3, "lm_iters": sm["iterations"], "evals": sm["evaluations"], "corr": int(counts.sum())})
+        log.append({"nn_ms": (t1 - t0) * 1e3, "lm_ms": (t2 - t1) * 1e3, "lm_iters": sm["iterations"], "evals": sm["evaluations"], "corr": int(counts.sum()),
+                    "steps_taken": sm["successful_steps"], "moved": not np.array_equal(before, poses)})
 
     def fence():
         if world > 1:
@@ -178,7 +272,7 @@ def main():
         step()
     eng.profile(2)   # live HIP-event scopes around the two roofline kernels only ("nn", "linearize"); everything else: replay pass below
     eng.profile_reset()
-    log.clear()
+    log.clear(); round_poses.clear()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -191,87 +285,136 @@ def main():
         elapsed = float(tt.item())
 
     timed = {k: eng.profile_get(k) for k in ("nn", "linearize")}
+    spec_hits = eng.profile_get("spec.hit")[1]
     host = {k: eng.profile_get(k)[0] / args.steps for k in ("host.correspond", "host.corr.setup", "host.corr.nn_launch", "host.corr.post_launch", "host.corr.wait",
                                                             "host.corr.finish", "host.optimize", "host.evaluate")}
     eng.profile(False)
     timed_log = list(log)
+    timed_poses = list(round_poses)
     final_poses = poses.copy()
 
     # Replay pass (UNTIMED): the same rounds again from the same initial poses, now with every profiling scope and the NN
     # census on (per-launch candidate / box / cache-hit counts = the algorithmic bytes of every NN launch).  The engine is
     # deterministic, so the replay walks through exactly the same poses and launches as the timed loop (checked below);
     # keeping the census kernels, their memsets and 20 extra event packets per round out of the timed region.
-    eng.set_graph(pb["src"], pb["dst"])   # forget the NN history (temporal cache, seeds, AUTO state)
-    poses = pb["init"].copy()
-    for _ in range(args.warmup):
-        step()
-    eng.profile(1)
-    eng.set_option("nn_census", 1)
-    eng.profile_reset()
-    for _ in range(args.steps):
-        step()
-    fence()
-    replay = {k: eng.profile_get(k) for k in ("nn", "compact", "gather", "select", "linearize", "reduce")}
-    census = eng.nn_census()
-    eng.set_option("nn_census", 0)
-    eng.profile(False)
-    replay_identical = bool(np.array_equal(poses, final_poses))
+    replay = None
+    census = None
+    replay_identical = None
+    if not args.no_replay:
+        eng.set_graph(pb["src"], pb["dst"])   # forget the NN history (temporal cache, seeds, AUTO state)
+        poses = pb["init"].copy()
+        for _ in range(args.warmup):
+            step()
+        eng.profile(1)
+        eng.set_option("nn_census", 1)
+        eng.profile_reset()
+        for _ in range(args.steps):
+            step()
+        fence()
+        replay = {k: eng.profile_get(k) for k in ("nn", "compact", "gather", "select", "linearize", "reduce")}
+        census = eng.nn_census()
+        eng.set_option("nn_census", 0)
+        eng.profile(False)
+        replay_identical = bool(np.array_equal(poses, final_poses))
     log[:] = timed_log
-    # time and launch count: live in the timed region; algorithmic bytes: the replay's census
-    prof = dict(replay)
-    prof["nn"] = (timed["nn"][0], timed["nn"][1], replay["nn"][2] if replay["nn"][1] == timed["nn"][1] else float("nan"))
-    prof["linearize"] = timed["linearize"]
+
+    # ---- roofline.  Time and launch count: live HIP events in the timed region.  Algorithmic bytes:
+    #   linearize  56 B (point-to-plane: p, n, n.q) / 48 B (point-to-point: p, q) per correspondence per evaluation  [library scope bytes]
+    #   nn         per launch 24 N_src (queries) + 12 N_src (index + distance) + 24 x candidate points FETCHED FROM MEMORY + 8 x cells / boxes
+    #              looked up, from the replay's exact census (hash-slot reads of the per-lane kernel are not counted: conservative).
+    #              `compulsory` = the structure-independent bound 60 B per query the survey quotes next to it.
+    prof = {"linearize": timed["linearize"]}
+    nn_ms, nn_n, _ = timed["nn"]
+    nn_alg = nn_comp = nn_model = float("nan")
+    if census is not None and replay["nn"][1] == nn_n and nn_n > 0:
+        nn_alg = (36.0 * census["queries"] + 24.0 * census["fetched"] + 8.0 * census["nodes"]) / nn_n
+        nn_comp = 60.0 * census["queries"] / nn_n
+        nn_model = replay["nn"][2] / nn_n
+    prof["nn"] = (nn_ms, nn_n, nn_alg * nn_n if nn_n else 0.0)
+
+    sha = source_sha16()
 
     def pmc_traffic(name):
-        """HBM bytes per launch from the committed rocprofv3 PMC passes of THIS command (tools/profile.sh -> profiles/):
-        separate --pmc FETCH_SIZE / WRITE_SIZE runs, per bench scope, warm-up launches skipped.  FETCH_SIZE is doubled for
-        the 16-B/lane coalesced linearize stream as MI355X_MICROARCH.md §HBM prescribes for gfx950; the NN stage mixes access
-        widths (uncalibrated there), so its raw counters are used as they are."""
-        path = os.path.join(ROOT, "profiles", f"r01_{args.workload}_kernels.json")
-        if world != 1 or args.nn != "auto" or not os.path.exists(path):
+        """HBM bytes per launch of THIS command from a committed rocprofv3 PMC summary (tools/profile.sh -> profiles/), used only if
+        that summary was taken with the same workload / warm-up / steps / NN method AND the same device sources (hash) — otherwise null.
+        FETCH_SIZE is doubled for the 16-B/lane coalesced linearize stream as MI355X_MICROARCH.md §HBM prescribes for gfx950; the NN
+        stage mixes access widths (uncalibrated there), so its raw counters are used as they are."""
+        path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{args.workload}_w{args.warmup}s{args.steps}_kernels.json")
+        if world != 1 or args.nn != "auto" or args.opt or not os.path.exists(path):
             return None
         try:
-            sc = json.load(open(path))["scopes"][name]
+            j = json.load(open(path))
+            if j.get("source_sha16") != sha or j.get("warmup_skipped") != args.warmup or j.get("timed_rounds") != args.steps:
+                return None
+            sc = j["scopes"][name]
             return (sc["FETCH_SIZE_KiB"] * (2.0 if name == "linearize" else 1.0) + sc["WRITE_SIZE_KiB"]) * 1024.0
         except Exception:
             return None
 
     def roof(name):
         ms, n, b = prof[name]
-        if n == 0 or ms <= 0:
+        if n == 0 or ms <= 0 or not np.isfinite(b):
             return None
         ach = (b / n) / (ms / n * 1e-3) / 1e9
-        return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(name), "launches": n, "avg_us": ms / n * 1e3, "alg_bytes_per_launch": b / n}
+        r = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+             "traffic": pmc_traffic(name), "launches": n, "avg_us": ms / n * 1e3, "alg_bytes_per_launch": b / n}
+        if name == "nn":
+            r["compulsory_bytes_per_launch"] = nn_comp
+            r["compulsory_frac"] = nn_comp / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS
+            r["overhead_bytes"] = max(0.0, nn_model - b / n)   # temporal-cache / list state and record padding in the library's own finer byte model
+            r["bytes_formula"] = "36 B/query + 24 B/candidate point fetched + 8 B/cell or box looked up (SURVEY.md §8d), census of the untimed replay pass"
+        return r
 
     dominant = max(("nn", "linearize"), key=lambda k: prof[k][0])
-    err_t = max(synth.pose_diff(poses[k], pb["gt"][k])[0] for k in range(K))
-    err_r = max(synth.pose_diff(poses[k], pb["gt"][k])[1] for k in range(K))
+    err_t = max(synth.pose_diff(final_poses[k], pb["gt"][k])[0] for k in range(K))
+    err_r = max(synth.pose_diff(final_poses[k], pb["gt"][k])[1] for k in range(K))
+
+    def regime(sel):
+        rows = [l for l in log if sel(l)]
+        if not rows:
+            return {"rounds": 0}
+        ms = float(np.mean([l["nn_ms"] + l["lm_ms"] for l in rows]))
+        return {"rounds": len(rows), "ms_per_step": ms, "iterations_per_s": 1e3 / ms, "correspond_ms": float(np.mean([l["nn_ms"] for l in rows])),
+                "optimize_ms": float(np.mean([l["lm_ms"] for l in rows])), "lm_iterations": float(np.mean([l["lm_iters"] for l in rows])),
+                "device_evaluations": float(np.mean([l["evals"] for l in rows]))}
 
     if rank == 0:
+        rejected = sum(l["lm_iters"] - l["steps_taken"] for l in log)
         out = {
             "metric": "ICP iterations/sec (NN+Jacobian+LM)", "value": args.steps / elapsed, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "views": K, "pts_per_view": N, "edges": int(eng.E), "cutoff": 0.05, "knn": 2, "robust": True,
                        "parallelism": f"edge-sharded x{world}, {exchange}" if world > 1 else "single GPU", "nn": args.nn},
+            "protocol": {"timed_rounds": [args.warmup + 1, args.warmup + args.steps], "start": "noisy initial poses of the synthetic registration (round 1)",
+                         "note": "value = all timed rounds; `regimes` splits them by whether the LM solve changed any pose (moving) or ended without stepping "
+                                 "(fixed point: the registration has converged and a round re-verifies it)"},
+            "regimes": {"moving_rounds": regime(lambda l: l["moved"]), "fixed_point_rounds": regime(lambda l: not l["moved"])},
+            "round_ms": [round(l["nn_ms"] + l["lm_ms"], 4) for l in log],
             "roofline": roof(dominant), "roofline_nn": roof("nn"), "roofline_linearize": roof("linearize"),
             "phase_ms_per_step": {"correspond": float(np.mean([l["nn_ms"] for l in log])), "optimize": float(np.mean([l["lm_ms"] for l in log])),
                                   "lm_iterations": float(np.mean([l["lm_iters"] for l in log])), "device_evaluations": float(np.mean([l["evals"] for l in log])),
                                   "correspondences": float(np.mean([l["corr"] for l in log]))},
-            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},   # nn, linearize: timed region; the rest: replay pass
-            "replay_pass": {"identical_poses": replay_identical, "nn_ms_per_step": replay["nn"][0] / args.steps,
-                            "note": "untimed re-run of the same rounds with all scopes + NN census on (algorithmic bytes per launch)"},
+            "lm_step_economy": {"lm_iterations": int(sum(l["lm_iters"] for l in log)), "rejected_or_terminal_steps": int(rejected),
+                                "evaluations": int(sum(l["evals"] for l in log)), "first_evaluations_served_by_the_queued_launch": int(spec_hits)},
+            "kernel_ms_per_step": {"nn": timed["nn"][0] / args.steps, "linearize": timed["linearize"][0] / args.steps},
             "host_ms_per_step": host,
-            "nn_census_per_query": {"candidates": census["candidates"] / max(1.0, census["queries"]), "tree_boxes": census["nodes"] / max(1.0, census["queries"]),
-                                    "tree_fallback_fraction": census["far"] / max(1.0, census["queries"]),
-                                    "temporal_cache_hit_fraction": census["hits"] / max(1.0, census["queries"])},
             "pose_error_vs_gt": {"max_translation_m": err_t, "max_rotation_rad": err_r},
+            "source_sha16": sha,
         }
+        if replay is not None:
+            out["kernel_ms_per_step"].update({k: replay[k][0] / args.steps for k in ("compact", "gather", "select", "reduce")})   # secondary scopes: replay pass
+            out["replay_pass"] = {"identical_poses": replay_identical, "nn_ms_per_step": replay["nn"][0] / args.steps,
+                                  "note": "untimed re-run of the same rounds with all scopes + NN census on (algorithmic bytes per launch)"}
+            q = max(1.0, census["queries"])
+            out["nn_census_per_query"] = {"candidates_examined": census["candidates"] / q, "candidate_points_fetched": census["fetched"] / q,
+                                          "cells_or_boxes": census["nodes"] / q, "tree_fallback_fraction": census["far"] / q,
+                                          "temporal_cache_hit_fraction": census["hits"] / q}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(pb, plane, param, int(eng.E))
-                out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+                out["cpu_baseline"] = cpu_baseline(pb, plane, param, int(eng.E), timed_poses, [l["moved"] for l in log])
+                out["speedup_vs_cpu_baseline"] = {"value": out["value"] / out["cpu_baseline"]["value"],
+                                                  "note": "GPU whole-job rate / extrapolated single-thread CPU port rate over the same timed rounds; a reported baseline, not a kernel-quality figure"}
             except Exception as ex:  # the baseline is a reported extra, never the measurement
                 out["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(out))

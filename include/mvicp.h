@@ -164,7 +164,10 @@ int mvicp_closedform_point_to_plane(const double* src, const double* dst, const 
  * "spin_wait" (0/1, default 0): poll the stream for up to 2 ms before blocking on the per-evaluation / per-round waits.
  * "tile_seed" (0/1, default 1): the tile kernel starts from last round's neighbours; "tile_waves" (0 = auto, 4..8):
  * occupancy variant of the tile kernel; "sel_bracket" (0/1, default 1): one-pass median select around last round's median
- * once it has settled; "prune_rho", "auto_settle", "grid_curve": see DESIGN.md.  Tuning knobs: correspondences are
+ * once it has settled; "spec_eval" (0/1, default 1): mvicp_correspond queues the first linearization of the following
+ * mvicp_optimize (same poses, previous solve's flags) behind its own kernels so the round waits once, not twice; "nn_cell"
+ * (0/1, default 0): wave-cooperative cell-staging variant of the grid kernel; "prune_rho", "auto_settle", "auto_switch",
+ * "grid_curve": see DESIGN.md.  Tuning knobs: correspondences are
  * bit-identical for every setting. */
 int mvicp_set_option(mvicp_ctx* ctx, const char* name, double value);
 /* NN census accumulated while profiling and the "nn_census" option are on: out[0..5] = queries, candidate points

@@ -8,6 +8,7 @@
 
 #include "common.h"
 #include "comm.h"
+#include "../host/se3.h"
 
 namespace mvicp {
 
@@ -126,7 +127,7 @@ void free_graph(mvicp_ctx* c) {
   dev_free(c->d_chunk_first); dev_free(c->d_partials); dev_free(c->d_out);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   c->h_pin = nullptr; c->h_pin_doubles = 0; c->d_res_host = nullptr; c->d_blocks_host = nullptr; c->lin_out = nullptr;
-  c->census_pending = false;
+  c->census_pending = false; c->spec_ready = false; c->spec_arm = false; c->d_spec_host = nullptr; c->d_adev_host = nullptr;
   c->E = 0; c->total_cap = 0; c->n_cblocks = 0; c->n_chunks = 0; c->have_corr = false;
 }
 
@@ -171,7 +172,7 @@ int ensure_pin(mvicp_ctx* c, size_t doubles) {
 }  // namespace
 
 // Per-edge relative transform for the LM kernels: A = R_d^T R_s, t = R_d^T (t_s - t_d).
-int upload_rel(mvicp_ctx* c, const double* poses) {
+int upload_rel(mvicp_ctx* c, const double* poses, bool rel_only = false) {
   double* h = c->h_pin + c->ctl_r2_off;  // region 2 of the control block: rel | a (a = SoftLOne scales, set by correspond)
   for (int e = 0; e < c->E; ++e) {
     const double* Ps = poses + 16 * (size_t)c->esrc[e];
@@ -182,7 +183,8 @@ int upload_rel(mvicp_ctx* c, const double* poses) {
     const double dt[3] = {Ps[12] - Pd[12], Ps[13] - Pd[13], Ps[14] - Pd[14]};
     for (int i = 0; i < 3; ++i) r[9 + i] = Pd[0 + 4 * i] * dt[0] + Pd[1 + 4 * i] * dt[1] + Pd[2 + 4 * i] * dt[2];
   }
-  MV_HIP(hipMemcpyAsync(c->d_rel, h, sizeof(double) * c->ctl_r2, hipMemcpyHostToDevice, c->stream));
+  // rel_only: leave the SoftLOne scales on the device alone (the select kernels have just written them there)
+  MV_HIP(hipMemcpyAsync(c->d_rel, h, sizeof(double) * (rel_only ? (size_t)c->E * kEdgeRel : c->ctl_r2), hipMemcpyHostToDevice, c->stream));
   return MVICP_OK;
 }
 
@@ -246,8 +248,18 @@ int evaluate_blocks(mvicp_ctx* c, const double* poses, int plane, int robust, do
       }
   }
   HostScope hs(c, "host.evaluate");
-  MV_CHECK(upload_rel(c, poses));
   const size_t n = (size_t)c->E * MVICP_EDGE_BLOCK;
+  if (c->spec_ready) {
+    // the evaluation mvicp_correspond queued ahead: valid only for exactly these poses and flags
+    c->spec_ready = false;
+    if (plane == c->spec_plane && robust == c->spec_robust && c->spec_poses.size() == 16 * (size_t)c->n_frames &&
+        std::memcmp(poses, c->spec_poses.data(), sizeof(double) * c->spec_poses.size()) == 0) {
+      std::memcpy(out, c->h_pin + c->pin_spec_off, sizeof(double) * n);
+      if (c->profile) c->prof["spec.hit"].launches += 1;   // (observable for tests / bench: evaluations served by the queued launch)
+      return MVICP_OK;
+    }
+  }
+  MV_CHECK(upload_rel(c, poses));
   double* h = c->h_pin + c->pin_blocks_off;
   if (c->comm || c->ar_fn) {
     c->lin_out = c->d_out;
@@ -369,6 +381,7 @@ int mvicp_recompute_normals(mvicp_ctx* c, int frame, int k, double* nrm_out, int
     if (e != hipSuccess) { set_error("recompute_normals: %s", hipGetErrorString(e)); st = MVICP_ERR_HIP; }
   }
   dev_free(d_knn);
+  c->spec_ready = false;
   if (st == MVICP_OK && c->E > 0) {
     // The packed operand stream bakes the dst normals in (n and c = n . q, gathered at correspond time) while the reference
     // reads dstCloud.nor when it builds the problem (icp-ceres.cpp:270-292): every list that points INTO this frame is stale.
@@ -519,14 +532,20 @@ int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) {
   c->pin_blocks_off = c->ctl_r2_off + c->ctl_r2;
   c->pin_res_off = c->pin_blocks_off + (size_t)E * MVICP_EDGE_BLOCK;
   c->pin_misc_off = c->pin_res_off + 2 * (size_t)E;
+  c->pin_spec_off = c->pin_misc_off + 4 * (size_t)E + 64;          // blocks of the speculative first evaluation
+  c->pin_adev_off = c->pin_spec_off + (size_t)E * MVICP_EDGE_BLOCK; // SoftLOne scales as the device computed them
   if (c->h_pin) { MV_HIP(hipHostFree(c->h_pin)); c->h_pin = nullptr; c->h_pin_doubles = 0; }
-  MV_CHECK(ensure_pin(c, c->pin_misc_off + 4 * (size_t)E + 64));
+  MV_CHECK(ensure_pin(c, c->pin_adev_off + (size_t)E + 8));
   {
     void* dp = nullptr;
     MV_HIP(hipHostGetDevicePointer(&dp, c->h_pin, 0));
     c->d_blocks_host = (double*)dp + c->pin_blocks_off;
     c->d_res_host = (double*)dp + c->pin_res_off;
+    c->d_spec_host = (double*)dp + c->pin_spec_off;
+    c->d_adev_host = (double*)dp + c->pin_adev_off;
   }
+  c->spec_ready = false; c->spec_arm = false;
+  c->prev_xf.assign((size_t)E * 24, 0.0);
   if (!c->h_census) MV_HIP(hipHostMalloc((void**)&c->h_census, 8 * sizeof(unsigned long long), hipHostMallocDefault));
   return MVICP_OK;
 }
@@ -564,8 +583,13 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
     const double rmax = c->frames[c->esrc[e]].max_norm;
     const bool cache_on = c->nn_cache_valid && c->nn_cache_enable && c->active[e] && (int)c->nn_cache_edge.size() == E && c->nn_cache_edge[e] &&
                           c->nn_cache_thresh == thresh;
-    // allowance for the rounding of the fp64 query map itself (both evaluations): ~1e-16 (|M||p| + |v|), taken 1e4 times larger
-    x[24] = cache_on ? 1e-12 * (scale * (rmax + 1.0) + 1.0) : -1.0;
+    // allowance for the rounding of the fp64 query map itself (both evaluations): ~1e-16 (|M||p| + |v|), taken 1e4 times larger.
+    // A transform that is BIT-IDENTICAL to last search's (a converged registration: the LM ends without stepping) reproduces every
+    // query bit for bit: no allowance, and dM = dv = 0 below, so the kernel sees eps == 0 and re-verifies without rewriting anything.
+    double* pxf = &c->prev_xf[(size_t)e * 24];
+    const bool same_xf = cache_on && std::memcmp(pxf, x, sizeof(double) * 24) == 0;
+    x[24] = cache_on ? (same_xf ? 0.0 : 1e-12 * (scale * (rmax + 1.0) + 1.0)) : -1.0;
+    std::memcpy(pxf, x, sizeof(double) * 24);
     for (int k = 37; k < kEdgeXf; ++k) x[k] = 0.0;
     std::memcpy(pq, Mq, sizeof(Mq));
   }
@@ -649,7 +673,30 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   mark("host.corr.nn_launch");
   MV_CHECK(launch_compact(c, bound));
   MV_CHECK(launch_gather_stream(c));
+  // Speculative first evaluation of the solve that follows (see common.h): same sharding on every rank, so either all ranks
+  // queue it (incl. its all-reduce) or none does.  Not with the host-staged callback transport (that one blocks).
+  c->spec_ready = false;
+  c->spec_arm = c->spec_enable && c->spec_flags_valid && !c->ar_fn;
+  if (c->spec_arm && c->spec_plane)
+    for (int e = 0; e < E; ++e) if (c->active[e] && c->frames[c->edst[e]].grid.snor == nullptr) c->spec_arm = false;
   if (use_bracket) MV_CHECK(launch_select_bracket(c)); else MV_CHECK(launch_select_median(c));
+  if (c->spec_arm) {
+    // the solve evaluates at x_to_pose(pose_to_x(P)) (host/lm.cpp): the same round trip here, so the poses match bit for bit
+    c->spec_poses.resize(16 * (size_t)c->n_frames);
+    double xp[7];
+    for (int k = 0; k < c->n_frames; ++k) { se3::pose_to_x(c->spec_param, poses + 16 * (size_t)k, xp); se3::x_to_pose(c->spec_param, xp, &c->spec_poses[16 * (size_t)k]); }
+    MV_CHECK(upload_rel(c, c->spec_poses.data(), true));
+    const size_t nb = (size_t)E * MVICP_EDGE_BLOCK;
+    if (c->comm) {
+      c->lin_out = c->d_out;
+      MV_CHECK(launch_linearize(c, c->spec_plane, c->spec_robust));
+      MV_CHECK(comm_allreduce_sum(c, c->d_out, nb));
+      MV_HIP(hipMemcpyAsync(c->h_pin + c->pin_spec_off, c->d_out, sizeof(double) * nb, hipMemcpyDeviceToHost, c->stream));
+    } else {
+      c->lin_out = c->d_spec_host;
+      MV_CHECK(launch_linearize(c, c->spec_plane, c->spec_robust));
+    }
+  }
   mark("host.corr.post_launch");
   // (count, median d2) per edge arrive in mapped host memory, written by select_final_kernel;
   // weight = (float)(1.5 * sqrt(median d2))  (frame.cpp:168-176)
@@ -657,10 +704,12 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   census_resolve(c);
   mark("host.corr.wait");
   const double* hr = c->h_pin + c->pin_res_off;
+  double spec_bad = 0.0;
   if (use_bracket) {
     bool redo = false;
     for (int e = 0; e < E; ++e) if (c->owned[e] && c->active[e] && hr[2 * e + 1] < 0.0) redo = true;
     if (redo) {   // some median left its bracket: full select for everything (rare once the registration has settled)
+      spec_bad = 1.0;   // the queued evaluation used the scales of the failed select
       MV_CHECK(launch_select_median(c));
       MV_CHECK(stream_wait(c));
     }
@@ -670,10 +719,22 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
     c->sel_med2[e] = c->sel_med1[e];
     c->sel_med1[e] = hr[2 * e] > 0 ? hr[2 * e + 1] : -1.0;
   }
-  std::vector<double> pack(2 * (size_t)E, 0.0);
+  std::vector<double> pack(2 * (size_t)E + 1, 0.0);
   for (int e = 0; e < E; ++e)
     if (c->owned[e] && c->active[e]) { pack[2 * e] = hr[2 * e]; pack[2 * e + 1] = hr[2 * e] > 0 ? hr[2 * e + 1] : 0.0; }
+  if (c->spec_arm) {
+    // trust the queued evaluation only if the scales the device derived from the medians are the host's (IEEE sqrt) bit for bit
+    const double* ad = c->h_pin + c->pin_adev_off;
+    for (int e = 0; e < E; ++e)
+      if (c->owned[e] && c->active[e]) {
+        const double a_host = pack[2 * e] > 0 ? (double)(float)(std::sqrt(pack[2 * e + 1]) * 1.5) : 0.0;
+        if (ad[e] != a_host) spec_bad = 1.0;
+      }
+    pack[2 * (size_t)E] = spec_bad;   // rides on the counts / medians exchange: every rank takes the same decision
+  }
   if (c->comm || c->ar_fn) MV_CHECK(comm_allreduce_host(c, pack.data(), pack.size()));
+  c->spec_ready = c->spec_arm && pack[2 * (size_t)E] == 0.0;
+  c->spec_arm = false;
   double* ha = c->h_pin + c->ctl_r2_off + (size_t)E * kEdgeRel;   // `a` slice of region 2: uploaded with rel by the next evaluation
   for (int e = 0; e < E; ++e) {
     c->h_count[e] = (int)pack[2 * e];
@@ -742,6 +803,7 @@ int mvicp_set_correspondences(mvicp_ctx* c, int edge, int n, const int* first, c
     MV_HIP(hipMemset(c->d_cd2 + off, 0, sizeof(double) * n));
   }
   c->nn_cache_valid = false;
+  c->spec_ready = false;
   c->list_valid[edge] = 0;
   c->sel_med1[edge] = c->sel_med2[edge] = -1.0;
   const double a = (double)weight;
@@ -813,6 +875,7 @@ int mvicp_set_option(mvicp_ctx* c, const char* name, double value) {
   if (std::strcmp(name, "tile_seed") == 0) { c->tile_seed = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "tile_waves") == 0) { c->tile_waves = (int)value; return MVICP_OK; }
   if (std::strcmp(name, "spin_wait") == 0) { c->spin_wait = value != 0.0; return MVICP_OK; }
+  if (std::strcmp(name, "spec_eval") == 0) { c->spec_enable = value != 0.0; c->spec_ready = false; return MVICP_OK; }
   if (std::strcmp(name, "grid_target") == 0) {
     if (!(value >= 0.5 && value <= 64.0)) { set_error("grid_target out of range"); return MVICP_ERR_ARG; }
     c->grid_target = value;

@@ -124,6 +124,7 @@ struct mvicp_ctx {
   bool nn_cache_valid = false; bool nn_cache_enable = true; float nn_cache_thresh = -1.f;
   std::vector<char> nn_cache_edge;  // edges searched (active) in the last grid search
   std::vector<double> prev_q;       // E x 12: query map M = Rd^-1 Rs (9, col-major) and v = Rd^-1 (ts - td) of the last search
+  std::vector<double> prev_xf;      // E x 24: the raw query transform (Rs ts Rd^-1 td) of the last search: bit-identical -> queries bit-identical
   // per-correspondence (total_cap)
   int* d_first = nullptr; int* d_second = nullptr; double* d_cd2 = nullptr;
   int* d_qpos = nullptr;            // per query: its position in the edge's compacted list, or -1 (rejected by the cutoff)
@@ -156,6 +157,14 @@ struct mvicp_ctx {
   double* d_res_host = nullptr;     // device view of the results region: (count, median d2) per edge, written by select_final_kernel
   double* d_blocks_host = nullptr;  // device view of the blocks region: single-rank evaluations write the E x 91 blocks straight to the host
   double* lin_out = nullptr;        // where the next launch_linearize puts the E x 91 blocks (d_out or d_blocks_host)
+  // Speculative first evaluation: mvicp_correspond queues the linearization the NEXT mvicp_optimize will ask for first (same poses,
+  // the parameterization / cost flags of the previous solve) right behind the select kernels, so the round waits once for
+  // (counts, medians, first blocks) instead of twice.  Used only if the solve really asks for exactly that evaluation.
+  bool spec_enable = true; bool spec_flags_valid = false; int spec_param = 0, spec_plane = 0, spec_robust = 0;
+  bool spec_arm = false;            // this correspond call queues one (select kernels write the SoftLOne scales on the device)
+  bool spec_ready = false;          // blocks of spec_poses are in the pinned spec region
+  std::vector<double> spec_poses;   // n_frames x 16: poses the speculative evaluation was made at (after the parameterization round trip)
+  size_t pin_spec_off = 0, pin_adev_off = 0; double* d_spec_host = nullptr; double* d_adev_host = nullptr;
   bool spin_wait = false;           // poll the stream instead of a blocking wait (measured: no gain, HIP's own wait already spins)
   unsigned long long* h_census = nullptr;   // pinned: 8 counters of the last NN launch, resolved after the round's own sync
   bool census_pending = false; double census_nq = 0; int census_kind = 0;   // kind: 0 grid (per-lane), 1 tree-only grid, 2 tile, 3 grid (cell staging)

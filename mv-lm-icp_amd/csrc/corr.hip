@@ -325,12 +325,23 @@ __global__ __launch_bounds__(NT) void select_pick_kernel(int E, const int* __res
   }
 }
 
+// SoftLOne scale of an edge on the device: a = (double)(float)(1.5 * sqrt(median d2)) — OutgoingEdge::weight (frame.cpp:168-176) widened
+// the way Ceres reads it (icp-ceres.cpp:284,374,449).  Lets the first LM evaluation of the round be queued before the host has
+// seen the median; the host recomputes the weight with its own IEEE sqrt and only trusts that evaluation if the two agree bit for bit.
+__device__ __forceinline__ void write_a_scale(int cnt, double med, int e, double* __restrict__ a_dev, double* __restrict__ a_host) {
+  if (a_dev == nullptr) return;
+  const double a = cnt > 0 ? (double)(float)__dmul_rn(sqrt(med), 1.5) : 0.0;
+  a_dev[e] = a;
+  if (a_host) a_host[e] = a;
+}
+
 // one workgroup per edge: pick digit C, then the keys matching the 33-bit prefix (out of the second compact buffer) ->
 // 3 x 10-bit passes in LDS.  Also hands (count, median d2) to the host through the mapped result buffer.
 __global__ __launch_bounds__(NT) void select_final_kernel(int E, const int* __restrict__ count, const long long* __restrict__ cap_off,
                                                           const double* __restrict__ keys2, const unsigned int* __restrict__ cnt2,
                                                           const unsigned int* __restrict__ hist, const SelState* __restrict__ state,
-                                                          double* __restrict__ median, double* __restrict__ host_res) {
+                                                          double* __restrict__ median, double* __restrict__ host_res,
+                                                          double* __restrict__ a_dev, double* __restrict__ a_host) {
   __shared__ unsigned int lh[1024];
   __shared__ int wave_tot[NT / 64];
   __shared__ int sh_pick[2];
@@ -366,6 +377,7 @@ __global__ __launch_bounds__(NT) void select_final_kernel(int E, const int* __re
   if (threadIdx.x == 0) {
     median[e] = med;
     if (host_res) { host_res[2 * e] = (double)(cnt > 0 ? cnt : 0); host_res[2 * e + 1] = med; }
+    write_a_scale(cnt, med, e, a_dev, a_host);
   }
 }
 
@@ -417,7 +429,7 @@ __global__ __launch_bounds__(NT) void bracket_pass_kernel(const int* __restrict_
 __global__ __launch_bounds__(NT) void bracket_final_kernel(int E, const int* __restrict__ count, const long long* __restrict__ cap_off,
                                                            const double* __restrict__ keys1, const unsigned int* __restrict__ cnt_lt,
                                                            const unsigned int* __restrict__ cnt_mid, double* __restrict__ median,
-                                                           double* __restrict__ host_res) {
+                                                           double* __restrict__ host_res, double* __restrict__ a_dev, double* __restrict__ a_host) {
   __shared__ unsigned int lh[kSelBins];
   __shared__ int wave_tot[NT / 64];
   __shared__ int sh_pick[2];
@@ -475,6 +487,7 @@ __global__ __launch_bounds__(NT) void bracket_final_kernel(int E, const int* __r
     if (ok) median[e] = med;
     host_res[2 * e] = (double)(cnt > 0 ? cnt : 0);
     host_res[2 * e + 1] = ok ? med : -1.0;   // -1: rank outside the bracket -> the host falls back to the full select
+    write_a_scale(ok ? cnt : 0, med, e, a_dev, a_host);
   }
 }
 
@@ -528,7 +541,7 @@ int launch_select_bracket(mvicp_ctx* c) {
                        (const double*)c->d_sel_lohi, cnt_lt, c->d_sel_keys1, cnt_mid);
   }
   hipLaunchKernelGGL(bracket_final_kernel, dim3(c->E), dim3(NT), 0, c->stream, c->E, c->d_count, c->d_cap_off, c->d_sel_keys1, (const unsigned int*)cnt_lt,
-                     (const unsigned int*)cnt_mid, c->d_median, c->d_res_host);
+                     (const unsigned int*)cnt_mid, c->d_median, c->d_res_host, c->spec_arm ? c->d_a : (double*)nullptr, c->spec_arm ? c->d_adev_host : (double*)nullptr);
   MV_HIP(hipGetLastError());
   return MVICP_OK;
 }
@@ -556,7 +569,8 @@ int launch_select_median(mvicp_ctx* c) {
                        hist, (const SelState*)st, c->d_sel_keys2, cnt2);
   }
   hipLaunchKernelGGL(select_final_kernel, dim3(c->E), dim3(NT), 0, c->stream, c->E, c->d_count, c->d_cap_off, c->d_sel_keys2, (const unsigned int*)cnt2,
-                     (const unsigned int*)hist, (const SelState*)st, c->d_median, c->d_res_host);
+                     (const unsigned int*)hist, (const SelState*)st, c->d_median, c->d_res_host, c->spec_arm ? c->d_a : (double*)nullptr,
+                     c->spec_arm ? c->d_adev_host : (double*)nullptr);
   MV_HIP(hipGetLastError());
   return MVICP_OK;
 }

@@ -128,14 +128,16 @@ __device__ __forceinline__ bool __lane0() {
 // gather are skipped for that edge.  Anything else marks the edge dirty.
 // No hot-address atomics: a query that invalidates the list stores 1 into its workgroup's slot (plain store, benign
 // same-value race); dirty_reduce_kernel ORs the slots per edge afterwards.
-__device__ __forceinline__ void update_list(const GridJob& job, int i, int idx_new, double d2_new, double bound) {
+// same_neighbour: the caller KNOWS idx_new is last round's neighbour (temporal-cache hit): a valid list then holds exactly that index
+// at the query's position (the list was built from out_idx and every round since kept every neighbour), so the load is skipped.
+__device__ __forceinline__ void update_list(const GridJob& job, int i, int idx_new, double d2_new, double bound, bool same_neighbour = false) {
   if (*job.dirty != 0) return;   // forced dirty by the host (no valid list yet): nothing to check, qpos may be uninitialised
   const int pos = job.qpos[i];
   const bool acc = idx_new >= 0 && d2_new < bound;
   bool clean;
   if (pos < 0) clean = !acc;
   else {
-    clean = acc && job.second[pos] == idx_new;
+    clean = acc && (same_neighbour || job.second[pos] == idx_new);
     if (clean) job.cd2[pos] = d2_new;
   }
   if (!clean) job.dirty_slots[i / NT] = 1;
@@ -210,9 +212,13 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
         const double eps = sqrt(e0 * e0 + e1 * e1 + e2 * e2) * (1.0 + 1e-9) + slack;
         const double nlb = job.out_lb[out] - eps;
         if (sqrt(d) * (1.0 + 1e-12) < nlb) {
-          job.out_d2[out] = d;
-          job.out_lb[out] = nlb;
-          if (job.dirty) update_list(job, i, pi, d, bound);
+          // eps == 0 only when the host found the edge's query transform bit-identical to last round's (slack 0, dM = dv = 0): the
+          // query, its distance, its bound and its list entry are then exactly what is stored already — nothing to write
+          if (eps != 0.0) {
+            job.out_d2[out] = d;
+            job.out_lb[out] = nlb;
+            if (job.dirty) update_list(job, i, pi, d, bound, true);
+          }
           if (stats) {
             unsigned long long c1 = __reduce_add_u64(1ull);
             const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + (threadIdx.x >> 6);
@@ -512,9 +518,11 @@ __global__ __launch_bounds__(NT, 5) void nn_cell_kernel(const GridJob* __restric
         const double eps = sqrt(e0 * e0 + e1 * e1 + e2 * e2) * (1.0 + 1e-9) + slack;
         const double nlb = job.out_lb[i] - eps;
         if (sqrt(d) * (1.0 + 1e-12) < nlb) {
-          job.out_d2[i] = d;
-          job.out_lb[i] = nlb;
-          if (job.dirty) update_list(job, i, pi, d, bound);
+          if (eps != 0.0) {   // (eps == 0: bit-identical query transform, everything stored is already exact — see nn_grid_kernel)
+            job.out_d2[i] = d;
+            job.out_lb[i] = nlb;
+            if (job.dirty) update_list(job, i, pi, d, bound, true);
+          }
           hit = true;
         }
       }

@@ -308,7 +308,9 @@ int mvicp_optimize(mvicp_ctx* c, double* poses, unsigned char* fixed, int param,
   if (e != hipSuccess) { set_error("hipSetDevice: %s", hipGetErrorString(e)); return MVICP_ERR_HIP; }
   if (c->E == 0) { set_error("no graph"); return MVICP_ERR_STATE; }
   HostScope hs(c, "host.optimize");
-  CtxEval u{c, point_to_plane, robust};
+  // what the NEXT search may evaluate ahead of time (api.cpp, speculative first evaluation)
+  c->spec_flags_valid = true; c->spec_param = param; c->spec_plane = point_to_plane ? 1 : 0; c->spec_robust = robust ? 1 : 0;
+  CtxEval u{c, point_to_plane ? 1 : 0, robust ? 1 : 0};
   const int st = lm_solve(c->n_frames, c->E, c->esrc.data(), c->edst.data(), poses, fixed, param, max_iterations, ctx_eval, &u, summary);
   if (st == MVICP_OK && summary) {   // feeds the AUTO kernel choice of the next search (api.cpp): RMS residual the solve ended on
     double n = 0.0;

@@ -539,7 +539,7 @@ def test_temporal_cache_is_bit_identical_to_full_search(orc):
     {"tile_seed": 0}, {"tile_waves": 4}, {"tile_waves": 8}, {"prune_rho": 0.0}, {"prune_rho": 0.6},
     {"auto_settle": 0.05}, {"auto_settle": 5.0}, {"nn_cache": 0, "list_reuse": 0}, {"spin_wait": 1}, {"sel_bracket": 0},
     {"grid_curve": 0}, {"grid_target": 2.5}, {"nn_cell": 1}, {"nn_cell": 1, "auto_switch": 0.2}, {"nn_cell": 1, "auto_switch": 50.0}, {"nn_cell": 1, "prune_rho": 0.0},
-    {"prune_rho": 3.0},
+    {"prune_rho": 3.0}, {"spec_eval": 0},
 ])
 def test_tuning_options_never_change_results(opts):
     """Every speed knob (kernel variants, seeding, cell pruning, AUTO hand-over policy, caches) must leave the whole ICP
@@ -695,3 +695,29 @@ def test_full_size_properties_cfg4():
         parts.append(e.linearize(pb["gt"], 1, 1)); counts.append(c)
         e.close()
     assert np.array_equal(parts[0] + parts[1], b1) and np.array_equal(counts[0] + counts[1], c1)
+
+
+def test_speculative_first_evaluation_is_used_and_exact():
+    """mvicp_correspond queues the first linearization of the following solve (same poses after the parameterization round trip,
+    previous solve's flags).  From the second round on every solve must be served by it (one wait per round instead of two), a change
+    of flags must fall back to a fresh evaluation, and the trajectory must be bit-identical to spec_eval = 0."""
+    pb = synth.make_problem(4, 4000)
+    res = {}
+    for spec in (1, 0):
+        e = mvicp.Engine(0)
+        e.set_option("spec_eval", spec)
+        e.set_frames(pb["pts"], pb["nor"]); e.set_graph(pb["src"], pb["dst"])
+        e.profile(True)
+        poses = pb["init"].copy()
+        hits = []
+        for r in range(6):
+            e.profile_reset()
+            e.correspond(poses, pb["fixed"], 0.05)
+            param, plane = (L.PARAM_ANGLE_AXIS, 0) if r == 3 else (L.PARAM_SOPHUS_SE3, 1)   # round 3 changes the flags: the queued launch must be ignored
+            poses, sm = e.optimize(poses, pb["fixed"], param, plane, True, 50)
+            hits.append(e.profile_get("spec.hit")[1])
+        res[spec] = (poses, hits)
+        e.close()
+    assert np.array_equal(res[1][0], res[0][0])
+    assert res[0][1] == [0] * 6
+    assert res[1][1] == [0, 1, 1, 0, 0, 1], res[1][1]   # round 0: no flags yet; round 3: flags differ; round 4: flags differ from round 3's

@@ -3,11 +3,14 @@
 #   pass 1: --kernel-trace --stats                (per-kernel time)
 #   pass 2: --pmc FETCH_SIZE   (+ --kernel-trace) (TCC fetch bytes, own run: 3 of 4 TCC slots)
 #   pass 3: --pmc WRITE_SIZE   (+ --kernel-trace)
-# Outputs land in gpurun_out/prof/<tag>/ ; tools/summarize_prof.py turns them into profiles/<tag>_*.txt
+# usage: bash tools/profile.sh <workload> <warmup> <steps>      ->  gpurun_out/prof/r02_<workload>_w<W>s<K>/
+# tools/summarize_prof.py turns the CSVs into <tag>_summary.txt / <tag>_kernels.json (copy those into profiles/): per-kernel tables
+# plus the two bench scopes restricted to the TIMED rounds, and the hash of the device sources (bench.py quotes `traffic` from the
+# JSON only when workload, warm-up, steps and that hash all match its own run).
 set -u
-TAG=${1:-r01_cfg4}
-shift || true
-CMD=${@:-python bench.py --workload cfg4 --steps 10 --warmup 1 --no-cpu-baseline}
+WL=${1:-cfg4}; W=${2:-1}; K=${3:-19}
+TAG=r02_${WL}_w${W}s${K}
+CMD="python bench.py --workload $WL --warmup $W --steps $K --no-cpu-baseline --no-replay"
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof/$TAG
@@ -15,5 +18,4 @@ mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $CMD > $OUT/bench_trace.json 2> $OUT/trace.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o f -- $CMD > $OUT/bench_fetch.json 2> $OUT/fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- $CMD > $OUT/bench_write.json 2> $OUT/write.err
-python tools/summarize_prof.py $OUT $TAG
-find $OUT -name '*.csv' | head -20
+python tools/summarize_prof.py $OUT $TAG $W $K

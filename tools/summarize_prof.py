@@ -115,10 +115,13 @@ if os.path.exists(p):
         j = json.loads(open(p).read().strip().splitlines()[-1])
         lines.append("")
         lines.append("# bench line of the traced run (HIP-event figures measured live in bench.py)")
-        lines.append(json.dumps({k: j[k] for k in ("value", "ms_per_step", "roofline", "roofline_nn", "roofline_linearize", "kernel_ms_per_step") if k in j}))
+        lines.append(json.dumps({k: j[k] for k in ("value", "ms_per_step", "steps", "warmup", "regimes", "roofline", "roofline_nn", "roofline_linearize", "kernel_ms_per_step") if k in j}))
     except Exception as ex:
         lines.append(f"# bench line unreadable: {ex}")
-json.dump({"tag": tag, "warmup_skipped": warmup, "timed_rounds": steps, "kernels": kern, "scopes": scopes}, open(os.path.join(out_dir, f"{tag}_kernels.json"), "w"), indent=1, sort_keys=True)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (source_sha16: the summary is only quoted by bench.py for the device sources it was measured on)
+json.dump({"tag": tag, "warmup_skipped": warmup, "timed_rounds": steps, "kernels": kern, "scopes": scopes, "source_sha16": bench.source_sha16()},
+          open(os.path.join(out_dir, f"{tag}_kernels.json"), "w"), indent=1, sort_keys=True)
 txt = "\n".join(lines) + "\n"
 open(os.path.join(out_dir, f"{tag}_summary.txt"), "w").write(txt)
 print(txt)
