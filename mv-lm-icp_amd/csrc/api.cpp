@@ -252,7 +252,7 @@ int evaluate_blocks(mvicp_ctx* c, const double* poses, int plane, int robust, do
   if (c->spec_ready) {
     // the evaluation mvicp_correspond queued ahead: valid only for exactly these poses and flags
     c->spec_ready = false;
-    if (plane == c->spec_plane && robust == c->spec_robust && c->spec_poses.size() == 16 * (size_t)c->n_frames &&
+    if (plane == c->spec_q_plane && robust == c->spec_q_robust && c->spec_poses.size() == 16 * (size_t)c->n_frames &&
         std::memcmp(poses, c->spec_poses.data(), sizeof(double) * c->spec_poses.size()) == 0) {
       std::memcpy(out, c->h_pin + c->pin_spec_off, sizeof(double) * n);
       if (c->profile) c->prof["spec.hit"].launches += 1;   // (observable for tests / bench: evaluations served by the queued launch)
@@ -686,15 +686,16 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
     double xp[7];
     for (int k = 0; k < c->n_frames; ++k) { se3::pose_to_x(c->spec_param, poses + 16 * (size_t)k, xp); se3::x_to_pose(c->spec_param, xp, &c->spec_poses[16 * (size_t)k]); }
     MV_CHECK(upload_rel(c, c->spec_poses.data(), true));
+    c->spec_q_plane = c->spec_plane; c->spec_q_robust = c->spec_robust;
     const size_t nb = (size_t)E * MVICP_EDGE_BLOCK;
     if (c->comm) {
       c->lin_out = c->d_out;
-      MV_CHECK(launch_linearize(c, c->spec_plane, c->spec_robust));
+      MV_CHECK(launch_linearize(c, c->spec_q_plane, c->spec_q_robust));
       MV_CHECK(comm_allreduce_sum(c, c->d_out, nb));
       MV_HIP(hipMemcpyAsync(c->h_pin + c->pin_spec_off, c->d_out, sizeof(double) * nb, hipMemcpyDeviceToHost, c->stream));
     } else {
       c->lin_out = c->d_spec_host;
-      MV_CHECK(launch_linearize(c, c->spec_plane, c->spec_robust));
+      MV_CHECK(launch_linearize(c, c->spec_q_plane, c->spec_q_robust));
     }
   }
   mark("host.corr.post_launch");

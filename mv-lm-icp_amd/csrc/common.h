@@ -161,6 +161,7 @@ struct mvicp_ctx {
   // the parameterization / cost flags of the previous solve) right behind the select kernels, so the round waits once for
   // (counts, medians, first blocks) instead of twice.  Used only if the solve really asks for exactly that evaluation.
   bool spec_enable = true; bool spec_flags_valid = false; int spec_param = 0, spec_plane = 0, spec_robust = 0;
+  int spec_q_plane = 0, spec_q_robust = 0;   // flags the QUEUED evaluation was launched with (spec_plane / spec_robust may have moved on since)
   bool spec_arm = false;            // this correspond call queues one (select kernels write the SoftLOne scales on the device)
   bool spec_ready = false;          // blocks of spec_poses are in the pinned spec region
   std::vector<double> spec_poses;   // n_frames x 16: poses the speculative evaluation was made at (after the parameterization round trip)

@@ -204,7 +204,11 @@ int lm_solve(int K, int E, const int* src, const int* dst, double* poses, unsign
   sm->evaluations = 1;
   double cost = as.assemble(x.data(), blocks.data(), H.data(), g.data(), env.data());
   sm->initial_cost = sm->final_cost = cost;
-  auto finish = [&]() { poses_of(x, poses); sm->final_cost = cost; return MVICP_OK; };
+  // Poses go back through the parameterization like the reference's write-back (icp-ceres.cpp:312-321,386-394,472-474) — but only when
+  // the solve moved something: x -> pose -> x is not bit-idempotent for every pose (a last-bit 2-cycle), and a solve that ends
+  // without taking a step must leave the caller's poses exactly as they were, so that a converged registration is a true fixed
+  // point of the round (bit-identical query transforms round after round).
+  auto finish = [&]() { if (sm->successful_steps > 0) poses_of(x, poses); sm->final_cost = cost; return MVICP_OK; };
   if (n == 0) { sm->termination = 1; return finish(); }
   double x_norm = xnorm(x);
   auto gmax_of = [&](const std::vector<double>& gv) { double m = 0; for (int i = 0; i < n; ++i) m = std::max(m, std::fabs(gv[i])); return m; };

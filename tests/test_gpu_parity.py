@@ -393,6 +393,13 @@ def test_rccl_communicator_single_rank(orc):
     assert np.array_equal(ca, cb) and np.array_equal(wa, wb) and np.array_equal(ba, bb)
     Pa, _ = a.optimize(pb["init"], pb["fixed"]); Pb, _ = b.optimize(pb["init"], pb["fixed"])
     assert np.array_equal(Pa, Pb)
+    # later rounds: the speculative first evaluation goes through the communicator too (device buffer -> all-reduce -> pinned copy)
+    b.profile(True)
+    for _ in range(3):
+        a.correspond(Pa, pb["fixed"], 0.05); b.correspond(Pb, pb["fixed"], 0.05)
+        Pa, _ = a.optimize(Pa, pb["fixed"]); Pb, _ = b.optimize(Pb, pb["fixed"])
+        assert np.array_equal(Pa, Pb)
+    assert b.profile_get("spec.hit")[1] == 3
     a.close(); b.close()
 
 
