@@ -544,7 +544,7 @@ int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) {
     c->d_spec_host = (double*)dp + c->pin_spec_off;
     c->d_adev_host = (double*)dp + c->pin_adev_off;
   }
-  c->spec_ready = false; c->spec_arm = false;
+  c->spec_ready = false; c->spec_arm = false; c->bracket_counters_clean = false;
   c->prev_xf.assign((size_t)E * 24, 0.0);
   if (!c->h_census) MV_HIP(hipHostMalloc((void**)&c->h_census, 8 * sizeof(unsigned long long), hipHostMallocDefault));
   return MVICP_OK;
@@ -558,6 +558,7 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   HostScope hs_all(c, "host.correspond");
   // per-edge query transforms (frame.cpp:117-118,131,136) + active mask (frame.cpp:93)
   std::vector<int> nsrc(E, 0);
+  std::vector<char> same_edge(E, 0);   // the edge's query transform is bit-identical to last search's (and the temporal cache is on for it)
   double* hx = c->h_pin;
   for (int e = 0; e < E; ++e) {
     c->active[e] = c->owned[e] && !(fixed && fixed[c->esrc[e]]);
@@ -589,6 +590,7 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
     double* pxf = &c->prev_xf[(size_t)e * 24];
     const bool same_xf = cache_on && std::memcmp(pxf, x, sizeof(double) * 24) == 0;
     x[24] = cache_on ? (same_xf ? 0.0 : 1e-12 * (scale * (rmax + 1.0) + 1.0)) : -1.0;
+    same_edge[e] = same_xf;
     std::memcpy(pxf, x, sizeof(double) * 24);
     for (int k = 37; k < kEdgeXf; ++k) x[k] = 0.0;
     std::memcpy(pq, Mq, sizeof(Mq));
@@ -671,8 +673,15 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   for (int e = 0; e < E; ++e) c->list_valid[e] = c->active[e];
 
   mark("host.corr.nn_launch");
-  MV_CHECK(launch_compact(c, bound));
-  MV_CHECK(launch_gather_stream(c));
+  // A search whose every edge has last round's exact transform and a valid list reproduces every query bit for bit: no list can
+  // change, so the (data-dependent, early-exiting) compaction and gather kernels are not even launched.
+  bool nothing_can_change = method == MVICP_NN_GRID && c->list_reuse && !c->nn_tree_only && !c->nn_skip_far;
+  for (int e = 0; e < E && nothing_can_change; ++e)
+    if (c->active[e] && !(same_edge[e] && hd[e] == 0)) nothing_can_change = false;
+  if (!nothing_can_change) {
+    MV_CHECK(launch_compact(c, bound));
+    MV_CHECK(launch_gather_stream(c));
+  }
   // Speculative first evaluation of the solve that follows (see common.h): same sharding on every rank, so either all ranks
   // queue it (incl. its all-reduce) or none does.  Not with the host-staged callback transport (that one blocks).
   c->spec_ready = false;

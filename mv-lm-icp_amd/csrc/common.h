@@ -142,6 +142,7 @@ struct mvicp_ctx {
   double* d_sel_lohi = nullptr;      // view into the control block: per edge the bracket [lo, hi] (d2) of the one-pass select
   std::vector<double> sel_med1, sel_med2;   // per owned edge: median d2 of the last / the one-before-last round (< 0: unknown)
   bool sel_bracket = true;           // option: use the one-pass bracket select once the medians have settled
+  bool bracket_counters_clean = false;   // the bracket pass's two per-edge counters are zero on the device (left so by bracket_final_kernel)
   double* d_sel_keys1 = nullptr; double* d_sel_keys2 = nullptr;                  // compact key buffers of passes B and C (total_cap each)
   // linearize chunks
   int lin_chunk_override = 0;

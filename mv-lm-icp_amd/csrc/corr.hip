@@ -389,46 +389,65 @@ __global__ __launch_bounds__(NT) void bracket_pass_kernel(const int* __restrict_
                                                           const long long* __restrict__ cap_off, const double* __restrict__ keys,
                                                           const double* __restrict__ lohi, unsigned int* __restrict__ cnt_lt,
                                                           double* __restrict__ out_keys, unsigned int* __restrict__ out_cnt) {
-  constexpr int SPT = kSelBlock / NT;
-  __shared__ int wave_tot[NT / 64];
-  __shared__ unsigned int sh_base;
+  // One streaming read of the keys, 16 B per lane per load; no workgroup scans: the count below the bracket is a ballot/popcount per
+  // wave, and the rare keys inside the bracket (about 1 %) are appended with one wave-aggregated atomic per load step that has any.
+  constexpr int SPT = kSelBlock / NT;   // keys per thread, two per step
+  __shared__ unsigned int s_lt[NT / 64];
   const int b = blockIdx.x;
   const int e = find_edge(sblock_off, E, b);
   const int lb = b - sblock_off[e];
   const int cnt = count[e];
   if ((long long)lb * kSelBlock >= cnt) return;
   const unsigned long long lo = (unsigned long long)__double_as_longlong(lohi[2 * e]), hi = (unsigned long long)__double_as_longlong(lohi[2 * e + 1]);
-  const long long base = cap_off[e];
-  unsigned long long kept[SPT];
-  int nlt = 0, nmid = 0;
+  const long long base = cap_off[e];   // multiple of 64 keys: 16-B aligned pairs
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned int nlt = 0;
 #pragma unroll
-  for (int i = 0; i < SPT; ++i) {
-    const int pos = lb * kSelBlock + i * NT + threadIdx.x;
-    kept[i] = ~0ull;   // not a key (d2 >= 0 has bit 63 clear)
-    if (pos < cnt) {
-      const unsigned long long key = (unsigned long long)__double_as_longlong(__builtin_nontemporal_load(&keys[base + pos]));
-      if (key < lo) ++nlt;
-      else if (key <= hi) { kept[i] = key; ++nmid; }
+  for (int i = 0; i < SPT / 2; ++i) {
+    const int pos = lb * kSelBlock + 2 * (i * NT + threadIdx.x);
+    unsigned long long k0 = ~0ull, k1 = ~0ull;   // ~0: not a key (d2 >= 0 has bit 63 clear)
+    if (pos + 1 < cnt) {
+      typedef double d2v __attribute__((ext_vector_type(2)));
+      const d2v v = __builtin_nontemporal_load(reinterpret_cast<const d2v*>(keys + base + pos));
+      k0 = (unsigned long long)__double_as_longlong(v.x); k1 = (unsigned long long)__double_as_longlong(v.y);
+    } else if (pos < cnt) {
+      k0 = (unsigned long long)__double_as_longlong(keys[base + pos]);
+    }
+    nlt += (k0 < lo ? 1u : 0u) + (k1 < lo ? 1u : 0u);
+    const bool m0 = k0 >= lo && k0 <= hi, m1 = k1 >= lo && k1 <= hi;   // (~0 > hi always)
+    const unsigned long long any = __ballot(m0 || m1);
+    if (any) {
+      const unsigned int mine = (m0 ? 1u : 0u) + (m1 ? 1u : 0u);
+      // exclusive prefix of `mine` over the wave from the two ballots
+      const unsigned long long b0 = __ballot(m0), b1 = __ballot(m1);
+      const unsigned long long below = (1ull << lane) - 1ull;
+      const unsigned int pre = (unsigned int)(__popcll(b0 & below) + __popcll(b1 & below));
+      const unsigned int tot = (unsigned int)(__popcll(b0) + __popcll(b1));
+      unsigned int wbase = 0;
+      const int leader = __ffsll((long long)any) - 1;
+      if (lane == leader) wbase = atomicAdd(&out_cnt[e], tot);
+      wbase = __shfl(wbase, leader, 64);
+      unsigned int o = wbase + pre;
+      if (m0) out_keys[base + o++] = __longlong_as_double((long long)k0);
+      if (m1) out_keys[base + o] = __longlong_as_double((long long)k1);
+      (void)mine;
     }
   }
-  int total_lt, total_mid;
-  block_exclusive_scan(nlt, wave_tot, &total_lt);
-  __syncthreads();
-  int off = block_exclusive_scan(nmid, wave_tot, &total_mid);
-  if (threadIdx.x == 0) {
-    if (total_lt) atomicAdd(&cnt_lt[e], (unsigned int)total_lt);
-    sh_base = total_mid ? atomicAdd(&out_cnt[e], (unsigned int)total_mid) : 0u;
-  }
-  __syncthreads();
-  off += (int)sh_base;
+  // keys below the bracket: wave popcount -> one atomic per workgroup
+  unsigned int w = nlt;
 #pragma unroll
-  for (int i = 0; i < SPT; ++i)
-    if (kept[i] != ~0ull) out_keys[base + off++] = __longlong_as_double((long long)kept[i]);
+  for (int d = 32; d >= 1; d >>= 1) w += __shfl_xor(w, d, 64);
+  if (lane == 0) s_lt[wave] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int t = s_lt[0] + s_lt[1] + s_lt[2] + s_lt[3];
+    if (t) atomicAdd(&cnt_lt[e], t);
+  }
 }
 
 __global__ __launch_bounds__(NT) void bracket_final_kernel(int E, const int* __restrict__ count, const long long* __restrict__ cap_off,
-                                                           const double* __restrict__ keys1, const unsigned int* __restrict__ cnt_lt,
-                                                           const unsigned int* __restrict__ cnt_mid, double* __restrict__ median,
+                                                           const double* __restrict__ keys1, unsigned int* __restrict__ cnt_lt,
+                                                           unsigned int* __restrict__ cnt_mid, double* __restrict__ median,
                                                            double* __restrict__ host_res, double* __restrict__ a_dev, double* __restrict__ a_host) {
   __shared__ unsigned int lh[kSelBins];
   __shared__ int wave_tot[NT / 64];
@@ -489,6 +508,9 @@ __global__ __launch_bounds__(NT) void bracket_final_kernel(int E, const int* __r
     host_res[2 * e + 1] = ok ? med : -1.0;   // -1: rank outside the bracket -> the host falls back to the full select
     write_a_scale(ok ? cnt : 0, med, e, a_dev, a_host);
   }
+  // leave the two counters zeroed for the next round's bracket pass (no memset in the steady-state launch sequence)
+  __syncthreads();
+  if (threadIdx.x == 0) { cnt_lt[e] = 0u; cnt_mid[e] = 0u; }
 }
 
 }  // namespace
@@ -536,12 +558,13 @@ int launch_select_bracket(mvicp_ctx* c) {
   unsigned int* cnt_lt = c->d_sel_hist;   // reuses the histogram scratch: cnt_lt [E] | cnt_mid [E]
   unsigned int* cnt_mid = cnt_lt + E;
   if (c->n_sblocks) {
-    MV_HIP(hipMemsetAsync(cnt_lt, 0, sizeof(unsigned int) * 2 * E, c->stream));
+    if (!c->bracket_counters_clean) MV_HIP(hipMemsetAsync(cnt_lt, 0, sizeof(unsigned int) * 2 * E, c->stream));
+    c->bracket_counters_clean = true;   // bracket_final_kernel re-zeroes what it used
     hipLaunchKernelGGL(bracket_pass_kernel, dim3(c->n_sblocks), dim3(NT), 0, c->stream, c->d_sblock_off, c->E, c->d_count, c->d_cap_off, c->d_cd2,
                        (const double*)c->d_sel_lohi, cnt_lt, c->d_sel_keys1, cnt_mid);
   }
-  hipLaunchKernelGGL(bracket_final_kernel, dim3(c->E), dim3(NT), 0, c->stream, c->E, c->d_count, c->d_cap_off, c->d_sel_keys1, (const unsigned int*)cnt_lt,
-                     (const unsigned int*)cnt_mid, c->d_median, c->d_res_host, c->spec_arm ? c->d_a : (double*)nullptr, c->spec_arm ? c->d_adev_host : (double*)nullptr);
+  hipLaunchKernelGGL(bracket_final_kernel, dim3(c->E), dim3(NT), 0, c->stream, c->E, c->d_count, c->d_cap_off, c->d_sel_keys1, cnt_lt,
+                     cnt_mid, c->d_median, c->d_res_host, c->spec_arm ? c->d_a : (double*)nullptr, c->spec_arm ? c->d_adev_host : (double*)nullptr);
   MV_HIP(hipGetLastError());
   return MVICP_OK;
 }
@@ -556,6 +579,7 @@ int launch_select_median(mvicp_ctx* c) {
   unsigned int* cnt1 = hist + 3 * E * kSelBins;
   unsigned int* cnt2 = cnt1 + E;
   SelState* st = (SelState*)c->d_sel_state;
+  c->bracket_counters_clean = false;   // the radix passes use the same scratch
   if (c->n_sblocks) {
     MV_HIP(hipMemsetAsync(hist, 0, sizeof(unsigned int) * (3 * E * kSelBins + 2 * E), c->stream));
     const dim3 grid(c->n_sblocks), blk(NT);

@@ -122,9 +122,15 @@ __device__ __forceinline__ float bcast(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
+typedef float f2v __attribute__((ext_vector_type(2)));
+
 struct Lane {          // per-lane query state
   double qx, qy, qz, best;
-  float qxf, qyf, qzf;   // fp32 copies for the screens
+  // fp32 copies for the screens, kept as splatted PAIRS (the packed-math operands of leaf_scan).  As four adjacent floats
+  // {qxf, qyf, qzf, thr} the vectorizer loaded them as overlapping <2 x float> pairs, which pinned that quad in scratch memory:
+  // three scratch loads and one scratch store per lane per opened tile — 1.4 GB of memory writes per launch on cfg4 (round-1 PMC).
+  f2v qx2, qy2, qz2;
+  double pad_;           // (keeps thr away from the pairs: no cross-field vector loads)
   float thr;             // fp32 screen threshold, always >= (sqrt(best) + slack)^2 (see leaf_scan)
   int bi;
   bool active;
@@ -138,9 +144,10 @@ struct Group {         // wave-uniform patch description
 // nearest point of the box has box coordinates (exact floats) or the query's own, so |sqrt(lb32) - sqrt(true)| <= slack and
 // every box holding a point with d2 <= best satisfies lb32 <= L.thr.
 __device__ __forceinline__ float box_lb32(const Lane& L, float b0, float b1, float b2, float b3, float b4, float b5) {
-  const float g0 = fmaxf(fmaxf(b0 - L.qxf, L.qxf - b3), 0.f);
-  const float g1 = fmaxf(fmaxf(b1 - L.qyf, L.qyf - b4), 0.f);
-  const float g2 = fmaxf(fmaxf(b2 - L.qzf, L.qzf - b5), 0.f);
+  const float qxf = L.qx2.x, qyf = L.qy2.x, qzf = L.qz2.x;
+  const float g0 = fmaxf(fmaxf(b0 - qxf, qxf - b3), 0.f);
+  const float g1 = fmaxf(fmaxf(b1 - qyf, qyf - b4), 0.f);
+  const float g2 = fmaxf(fmaxf(b2 - qzf, qzf - b5), 0.f);
   return __builtin_fmaf(g2, g2, __builtin_fmaf(g1, g1, g0 * g0));
 }
 
@@ -159,8 +166,6 @@ __device__ __forceinline__ float thr_of(double best, float slack) {
 // The screen is the hot loop of the kernel (VALU-bound): four candidates per step, SoA in LDS so that one 16-B read
 // brings four x (y, z) values, packed fp32 math (v_pk_add/mul/fma: two candidates per instruction), one branch per
 // four candidates; the fp64 confirmation runs only for the lanes / candidates that pass.
-typedef float f2v __attribute__((ext_vector_type(2)));
-
 struct TileLds {   // per wave
   double x[LEAF], y[LEAF], z[LEAF];
   float fx[LEAF], fy[LEAF], fz[LEAF];
@@ -187,7 +192,7 @@ __device__ __forceinline__ void leaf_scan(const TileView& g, int leaf, Lane& L, 
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  const f2v qx2 = {L.qxf, L.qxf}, qy2 = {L.qyf, L.qyf}, qz2 = {L.qzf, L.qzf};
+  const f2v qx2 = L.qx2, qy2 = L.qy2, qz2 = L.qz2;
   // L.thr >= (sqrt(best) + slack)^2 at all times.  When a candidate with screen value d32 becomes the best, sqrt(best) <=
   // sqrt(d32) + slack, so (sqrt(d32) + 2 slack)^2 is a valid new threshold: one fp32 sqrt instead of an fp64 one per update.
   float thr = L.thr;
@@ -350,7 +355,7 @@ __global__ __launch_bounds__(NT, WPE) void nn_tile_kernel(const TileJob* __restr
     // per axis: |fl32(q) - q| + |fl32(p) - p| + rounding of the fp32 subtraction <= 3 * 2^-24 * m; x sqrt(3) axes, x2 safety
     G.slack = bcast((float)(m * (3.0 * 1.7320508 * 2.0 / 16777216.0)) + 1e-30f, 0);
   }
-  L.qxf = (float)L.qx; L.qyf = (float)L.qy; L.qzf = (float)L.qz;
+  { const float a = (float)L.qx, b = (float)L.qy, c2 = (float)L.qz; L.qx2 = f2v{a, a}; L.qy2 = f2v{b, b}; L.qz2 = f2v{c2, c2}; L.pad_ = 0.0; }
   L.thr = thr_of(L.best, G.slack);
   unsigned int n_cand = 0, n_box = 0;
   const int top = g.levels - 1;
