@@ -495,9 +495,11 @@ int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound) {
     int top = jobs[0].dst.levels - 1;   // same depth everywhere -> the traversal specialised for it
     for (const TileJob& j : jobs) if (j.dst.levels - 1 != top) top = -1;
 #define MVICP_TILE_LAUNCH(W, T) hipLaunchKernelGGL((nn_tile_kernel<W, T>), grid, dim3(NT), 0, c->stream, d_jobs, d2_bound, d_stats)
-    const int waves = c->tile_waves;   // 0 = pick: measured best is 8 waves per SIMD for the depth-3 build, 6 otherwise
-    if (top == 2 && (waves == 0 || waves == 8)) MVICP_TILE_LAUNCH(8, 2);
-    else if (top == 2 && waves == 7) MVICP_TILE_LAUNCH(7, 2);
+    const int waves = c->tile_waves;   // 0 = pick: 7 waves per SIMD for the depth-3 build, 6 otherwise
+    // depth-3 build: 7 waves per SIMD measures the same as 8 (cfg4 rounds 1-4: 6.6 / 2.72 / 2.12 / 1.68 vs 6.5 / 2.73 / 2.13 / 1.67 ms) with 2
+    // spilled registers instead of 10; 6 waves (no spill at all) is 3-5 % slower
+    if (top == 2 && (waves == 0 || waves == 7)) MVICP_TILE_LAUNCH(7, 2);
+    else if (top == 2 && waves == 8) MVICP_TILE_LAUNCH(8, 2);
     else if (top == 2 && waves == 6) MVICP_TILE_LAUNCH(6, 2);
     else if (top == 1 && (waves == 0 || waves == 6)) MVICP_TILE_LAUNCH(6, 1);
     else switch (waves) {   // generic depth: waves per SIMD the kernel is compiled for (register budget 512 / n); tuning knob, same results

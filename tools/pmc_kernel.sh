@@ -1,13 +1,15 @@
 #!/bin/bash
-# rocprofv3 --pmc pass over an arbitrary command (GPU box): per-kernel averages of a few SQ counters.
+# rocprofv3 --pmc pass over an arbitrary command (GPU box): per-kernel averages of ONE counter group per pass.
 #   bash tools/pmc_kernel.sh <tag> "<counters>" <cmd...>
+# Keep TCC counters in separate passes (FETCH_SIZE and WRITE_SIZE together do not fit the TCC slots: that pass never returned on
+# this pool and burnt a 30-minute gpurun call in round 2) and always under a timeout.
 set -u
 TAG=$1; CTR=$2; shift 2
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc/$TAG
 mkdir -p $OUT
-rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d $OUT -o p -- "$@" > $OUT/cmd.out 2> $OUT/cmd.err
+timeout ${PMC_TIMEOUT:-240} rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d $OUT -o p -- "$@" > $OUT/cmd.out 2> $OUT/cmd.err
 python - "$OUT" <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]
