@@ -686,8 +686,8 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   // queue it (incl. its all-reduce) or none does.  Not with the host-staged callback transport (that one blocks).
   c->spec_ready = false;
   c->spec_arm = c->spec_enable && c->spec_flags_valid && !c->ar_fn;
-  if (c->spec_arm && c->spec_plane)
-    for (int e = 0; e < E; ++e) if (c->active[e] && c->frames[c->edst[e]].grid.snor == nullptr) c->spec_arm = false;
+  if (c->spec_arm && c->spec_plane)   // (over ALL edges, not this rank's: every rank must take the same decision — the launch carries a collective)
+    for (int e = 0; e < E; ++e) if (!(fixed && fixed[c->esrc[e]]) && c->frames[c->edst[e]].n > 0 && c->frames[c->edst[e]].grid.snor == nullptr) c->spec_arm = false;
   if (use_bracket) MV_CHECK(launch_select_bracket(c)); else MV_CHECK(launch_select_median(c));
   if (c->spec_arm) {
     // the solve evaluates at x_to_pose(pose_to_x(P)) (host/lm.cpp): the same round trip here, so the poses match bit for bit
