@@ -559,9 +559,11 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   // per-edge query transforms (frame.cpp:117-118,131,136) + active mask (frame.cpp:93)
   std::vector<int> nsrc(E, 0);
   std::vector<char> same_edge(E, 0);   // the edge's query transform is bit-identical to last search's (and the temporal cache is on for it)
+  bool same_active_set = (int)c->nn_cache_edge.size() == E;   // the set of searched edges is last search's (a changed `fixed` mask changes it)
   double* hx = c->h_pin;
   for (int e = 0; e < E; ++e) {
     c->active[e] = c->owned[e] && !(fixed && fixed[c->esrc[e]]);
+    if (same_active_set && (c->active[e] != 0) != (c->nn_cache_edge[e] != 0)) same_active_set = false;
     nsrc[e] = c->active[e] ? c->frames[c->esrc[e]].n : 0;
     const double* Ps = poses + 16 * (size_t)c->esrc[e];
     const double* Pd = poses + 16 * (size_t)c->edst[e];
@@ -675,7 +677,7 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   mark("host.corr.nn_launch");
   // A search whose every edge has last round's exact transform and a valid list reproduces every query bit for bit: no list can
   // change, so the (data-dependent, early-exiting) compaction and gather kernels are not even launched.
-  bool nothing_can_change = method == MVICP_NN_GRID && c->list_reuse && !c->nn_tree_only && !c->nn_skip_far;
+  bool nothing_can_change = method == MVICP_NN_GRID && c->list_reuse && !c->nn_tree_only && !c->nn_skip_far && same_active_set;
   for (int e = 0; e < E && nothing_can_change; ++e)
     if (c->active[e] && !(same_edge[e] && hd[e] == 0)) nothing_can_change = false;
   if (!nothing_can_change) {

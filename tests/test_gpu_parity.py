@@ -728,3 +728,26 @@ def test_speculative_first_evaluation_is_used_and_exact():
     assert np.array_equal(res[1][0], res[0][0])
     assert res[0][1] == [0] * 6
     assert res[1][1] == [0, 1, 1, 0, 0, 1], res[1][1]   # round 0: no flags yet; round 3: flags differ; round 4: flags differ from round 3's
+
+
+def test_changed_fixed_mask_at_identical_poses_is_not_mistaken_for_a_fixed_point():
+    """The converged-registration shortcuts (bit-identical transforms: nothing rewritten, compaction not launched) must not survive
+    a change of the fixed mask at the very same poses: edges out of a newly fixed frame lose their lists (frame.cpp:93), edges out of a
+    released frame get theirs."""
+    pb = synth.make_problem(4, 3000)
+    src, dst = synth.pose_graph_knn(pb["init"], 2, skip_fixed0=False)
+    eng = mvicp.Engine(0)
+    eng.set_frames(pb["pts"], pb["nor"]); eng.set_graph(src, dst)
+    masks = [np.array(m, dtype=np.uint8) for m in ([1, 0, 0, 0], [1, 0, 0, 0], [1, 0, 1, 0], [1, 0, 1, 0], [0, 0, 0, 0], [1, 0, 0, 0])]
+    for m in masks:
+        for _ in range(2):   # twice: the second call runs with bit-identical transforms AND an unchanged mask
+            c, w = eng.correspond(pb["gt"], m, 0.05, L.NN_GRID)
+            blk = eng.linearize(pb["gt"], 1, 1)
+            fresh = mvicp.Engine(0)
+            fresh.set_frames(pb["pts"], pb["nor"]); fresh.set_graph(src, dst)
+            cf, wf = fresh.correspond(pb["gt"], m, 0.05, L.NN_GRID)
+            bf = fresh.linearize(pb["gt"], 1, 1)
+            fresh.close()
+            assert np.array_equal(c, cf) and w.tobytes() == wf.tobytes() and np.array_equal(blk, bf), m
+            assert all(c[e] == 0 for e in range(len(src)) if m[src[e]])
+    eng.close()
