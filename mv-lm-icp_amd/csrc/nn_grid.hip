@@ -61,7 +61,8 @@ struct GridJob {
   int* out_idx; double* out_d2;
   const int* inv;      // target original index -> sorted position (null: emit original indices, raw-query API)
   // "did anything change?" bookkeeping of the edge's compacted list (all null for the raw-query API)
-  const int* qpos; const int* second; double* cd2; const int* dirty; int* dirty_slots;  // dirty: host-forced flag; slots: one per NT queries
+  const int* qpos; int* second; double* cd2; const int* dirty; int* dirty_slots;  // dirty: host-forced flag; slots: one per NT queries
+  double* stream; long long total_cap; const double* dst_nor;   // the edge's slice of the packed operand stream (linearize.hip) + sorted dst normals
   double* out_lb;      // per query: lower bound on the distance to every target other than out_idx (null: no cache)
   int seed;            // out_idx still holds last round's neighbours (from any kernel): a starting candidate for far queries
 };
@@ -123,9 +124,9 @@ __device__ __forceinline__ bool __lane0() {
   return (int)(threadIdx.x & 63) == __ffsll((long long)mask) - 1;
 }
 
-// The edge's compacted correspondence list survives a round unchanged when every query keeps both its acceptance
-// (cutoff test) and its neighbour; then only the squared distances need refreshing (in place), and compaction + operand
-// gather are skipped for that edge.  Anything else marks the edge dirty.
+// The edge's compacted correspondence list survives a round when every query keeps its acceptance (cutoff test): squared
+// distances are refreshed in place, a changed neighbour is patched in place (list entry + its operands), and compaction +
+// operand gather are skipped for that edge.  Only a change of acceptance (the list's membership) marks the edge dirty.
 // No hot-address atomics: a query that invalidates the list stores 1 into its workgroup's slot (plain store, benign
 // same-value race); dirty_reduce_kernel ORs the slots per edge afterwards.
 // same_neighbour: the caller KNOWS idx_new is last round's neighbour (temporal-cache hit): a valid list then holds exactly that index
@@ -137,8 +138,25 @@ __device__ __forceinline__ void update_list(const GridJob& job, int i, int idx_n
   bool clean;
   if (pos < 0) clean = !acc;
   else {
-    clean = acc && (same_neighbour || job.second[pos] == idx_new);
-    if (clean) job.cd2[pos] = d2_new;
+    clean = acc;
+    if (clean) {
+      if (!same_neighbour && job.second[pos] != idx_new) {
+        // The query keeps its place in the list (still accepted) but has a NEW neighbour: patch the entry and its operands in place —
+        // n, c = n . q, q of the operand stream, exactly as gather_kernel writes them (corr.hip; same expression, no contraction) —
+        // instead of declaring the whole edge dirty (which re-compacts and re-gathers all of its ~N_src entries).
+        job.second[pos] = idx_new;
+        const double2* pb = reinterpret_cast<const double2*>(job.dst.srec + idx_new);
+        const double2 b0 = pb[0], b1 = pb[1];
+        double* st = job.stream + pos;
+        st[7 * job.total_cap] = b0.x; st[8 * job.total_cap] = b0.y; st[9 * job.total_cap] = b1.x;
+        if (job.dst_nor != nullptr) {
+          const double n0 = job.dst_nor[3 * (size_t)idx_new], n1 = job.dst_nor[3 * (size_t)idx_new + 1], n2 = job.dst_nor[3 * (size_t)idx_new + 2];
+          st[3 * job.total_cap] = n0; st[4 * job.total_cap] = n1; st[5 * job.total_cap] = n2;
+          st[6 * job.total_cap] = n0 * b0.x + n1 * b0.y + n2 * b1.x;
+        }
+      }
+      job.cd2[pos] = d2_new;
+    }
   }
   if (!clean) job.dirty_slots[i / NT] = 1;
 }
@@ -1136,6 +1154,7 @@ int launch_nn_grid_edges(mvicp_ctx* c, double d2_bound) {
     j.out_idx = c->d_nn_idx + c->cap_off[e]; j.out_d2 = c->d_nn_d2 + c->cap_off[e];
     j.inv = d.grid.inv; j.out_lb = c->d_nn_lb + c->cap_off[e];
     j.qpos = c->d_qpos + c->cap_off[e]; j.second = c->d_second + c->cap_off[e]; j.cd2 = c->d_cd2 + c->cap_off[e]; j.dirty = c->d_dirty + e;
+    j.stream = c->d_stream + c->cap_off[e]; j.total_cap = c->total_cap; j.dst_nor = d.grid.snor;
     j.dirty_slots = c->d_dirty_slots + c->dslot_off[e];
     j.seed = ((int)c->nn_cache_edge.size() == c->E && c->nn_cache_edge[e]) ? 1 : 0;
     jobs.push_back(j);
@@ -1151,6 +1170,7 @@ int launch_nn_grid_queries(mvicp_ctx* c, const FrameDev& f, const double* d_q, i
   jobs[0].out_idx = d_idx; jobs[0].out_d2 = d_d2;
   jobs[0].inv = nullptr; jobs[0].out_lb = nullptr;
   jobs[0].qpos = nullptr; jobs[0].second = nullptr; jobs[0].cd2 = nullptr; jobs[0].dirty = nullptr; jobs[0].dirty_slots = nullptr;
+  jobs[0].stream = nullptr; jobs[0].total_cap = 0; jobs[0].dst_nor = nullptr;
   return run(c, jobs, 1.7976931348623157e308);
 }
 
