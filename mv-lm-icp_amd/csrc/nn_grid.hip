@@ -180,99 +180,74 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
                                                      int2* __restrict__ far_list, unsigned int* __restrict__ far_count, double prune_rho) {
   __shared__ double sxf[kEdgeXf];
   __shared__ uint2 s_rng[8][NT];   // per lane: (start, count) of the 8 block cells (written and read by the same thread only)
-  __shared__ int s_miss[NT];       // queries of this workgroup that need a search (sparse rounds: packed into the first lanes)
-  __shared__ int s_nmiss;
   const GridJob& job = jobs[blockIdx.y];
   const int i = blockIdx.x * NT + threadIdx.x;
   if (blockIdx.x * NT >= job.n) return;
   const bool has_xf = job.xf != nullptr;
   if (has_xf && threadIdx.x < kEdgeXf) sxf[threadIdx.x] = job.xf[threadIdx.x];
-  if (threadIdx.x == 0) s_nmiss = 0;
   __syncthreads();
+  if (i >= job.n) return;
   const GridView& g = job.dst;
-  const double slack = has_xf ? sxf[24] : -1.0;
 
-  // query `idx` in the target's frame, and — with last round's neighbour p1 (sorted position in out_idx, left there by whichever
-  // kernel ran) — its squared distance d1 to p1 (< 0: no usable neighbour)
-  auto prepare = [&](int idx, double& x, double& y, double& z, int& p1, double& d1) {
-    const double p0 = job.q[3 * (size_t)idx], pp1 = job.q[3 * (size_t)idx + 1], p2 = job.q[3 * (size_t)idx + 2];
-    if (has_xf) xf_point(sxf, p0, pp1, p2, x, y, z);
-    else { x = p0; y = pp1; z = p2; }
-    p1 = -1; d1 = -1.0;
-    if (!TREE_ONLY && job.seed) {
-      const int pi = job.out_idx[idx];
-      if (pi >= 0 && pi < g.n) {
-        const double2* tp = reinterpret_cast<const double2*>(g.srec + pi);
-        const double2 ta = tp[0], tb = tp[1];
-        p1 = pi; d1 = dist2(x, y, z, ta.x, ta.y, tb.x);
-      }
-    }
-  };
-
-  // ---- phase A, every lane for its own query: temporal cache.  Last search left, per query, its neighbour p1 and a lower
-  // bound L on the distance to every OTHER target.  Since then the query moved by at most eps (pose update), so every other
-  // target is still >= L - eps away; if the re-evaluated distance to p1 is strictly below that, p1 is still the unique nearest
-  // neighbour and its exact squared distance (reference arithmetic) is the answer — no search.  Relative 1e-12 slack covers
-  // sqrt rounding.
-  double qx = 0.0, qy = 0.0, qz = 0.0, d1 = -1.0;
-  int p1i = -1;
-  bool need = i < job.n;
-  if (need) {
-    prepare(i, qx, qy, qz, p1i, d1);
-    if (p1i >= 0 && slack >= 0.0 && job.out_lb != nullptr) {
-      // how far THIS query moved since the last search: |dM p + dv| (exactly, up to the rounding allowance)
-      const double p0 = job.q[3 * (size_t)i], p1 = job.q[3 * (size_t)i + 1], p2 = job.q[3 * (size_t)i + 2];
-      const double e0 = sxf[25] * p0 + sxf[28] * p1 + sxf[31] * p2 + sxf[34];
-      const double e1 = sxf[26] * p0 + sxf[29] * p1 + sxf[32] * p2 + sxf[35];
-      const double e2 = sxf[27] * p0 + sxf[30] * p1 + sxf[33] * p2 + sxf[36];
-      const double eps = sqrt(e0 * e0 + e1 * e1 + e2 * e2) * (1.0 + 1e-9) + slack;
-      const double nlb = job.out_lb[i] - eps;
-      if (sqrt(d1) * (1.0 + 1e-12) < nlb) {
-        // eps == 0 only when the host found the edge's query transform bit-identical to last round's (slack 0, dM = dv = 0): the
-        // query, its distance, its bound and its list entry are then exactly what is stored already — nothing to write
-        if (eps != 0.0) {
-          job.out_d2[i] = d1;
-          job.out_lb[i] = nlb;
-          if (job.dirty) update_list(job, i, p1i, d1, bound, true);
-        }
-        need = false;
-        if (stats) {
-          unsigned long long c1 = __reduce_add_u64(1ull);
-          const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + (threadIdx.x >> 6);
-          if (__lane0()) atomicAdd(&stats[8 * slot + 3], c1);
-        }
-      }
-    }
+  double qx, qy, qz;
+  {
+    const double p0 = job.q[3 * (size_t)i], p1 = job.q[3 * (size_t)i + 1], p2 = job.q[3 * (size_t)i + 2];
+    if (has_xf) xf_point(sxf, p0, p1, p2, qx, qy, qz);
+    else { qx = p0; qy = p1; qz = p2; }
   }
-  // ---- the queries that still need a search.  When they are few (a nearly converged round: a few lanes per wave), every wave that
-  // holds one would run the whole latency-bound search for it; packing the workgroup's misses into its first lanes leaves one busy
-  // wave per workgroup instead of four half-idle ones (the search of a query does not depend on which lane runs it).  Dense rounds
-  // keep every query on its own lane (curve-coherent accesses).
-  if (need) s_miss[atomicAdd(&s_nmiss, 1)] = i;
-  __syncthreads();
-  const int nmiss = s_nmiss;
-  int qi = i;
-  if (!TREE_ONLY && nmiss <= NT / 4) {
-    need = (int)threadIdx.x < nmiss;
-    if (need) {
-      const int mine = s_miss[threadIdx.x];
-      if (mine != i) { qi = mine; prepare(qi, qx, qy, qz, p1i, d1); }
-    }
-  }
-  if (!need) return;
-  const int out = qi;   // results live in the SORTED order of the source cloud (coalesced; the pipeline stays in that order)
+  const int out = i;   // results live in the SORTED order of the source cloud (coalesced; the pipeline stays in that order)
 
   double best = bound;      // nothing at or beyond the cutoff bound needs resolving (frame.cpp:156)
   int bi = 0x7fffffff;
   bool resolved = false;
   unsigned int n_cand = 0;
   double second = 1.7976931348623157e308;
-  // Last round's neighbour also bounds the search: the true neighbour lies within |q - p1| of q, so hash cells of the block
-  // farther than r_p = |q - p1| + rho need not be probed.  Everything in a skipped cell is farther than r_p, which enters the
-  // lower bound handed to the next round's cache: the margin rho (a fraction of the cell edge) is what lets that bound survive
-  // the next pose update.
+
+  // ---- temporal cache.  Last search left, per query, its neighbour p1 and a lower bound L on the distance to every
+  // OTHER target.  Since then the query moved by at most eps (pose update), so every other target is still >= L - eps
+  // away; if the re-evaluated distance to p1 is strictly below that, p1 is still the unique nearest neighbour and its
+  // exact squared distance (reference arithmetic) is the answer — no search.  Relative 1e-12 slack covers sqrt rounding.
+  const double slack = has_xf ? sxf[24] : -1.0;
+  // Last round's neighbour p1 (sorted position in out_idx, left there by whichever kernel ran) serves twice:
+  //  * temporal cache (needs last round's lower bounds, i.e. a grid round): re-evaluate the distance and stop;
+  //  * otherwise its distance bounds the search: the true neighbour lies within |q - p1| of q, so hash cells of the block
+  //    farther than r_p = |q - p1| + rho need not be probed.  Everything in a skipped cell is farther than r_p, which
+  //    enters the lower bound handed to the next round's cache: the margin rho (a fraction of the cell edge) is what lets
+  //    that bound survive the next pose update.
   double rp2 = -1.0;   // < 0: scan the whole block
-  if (p1i >= 0 && prune_rho > 0.0) { const double rp = sqrt(d1) + prune_rho * g.h; rp2 = rp * rp * 1.002; }
+  if (!TREE_ONLY && job.seed) {
+    const int pi = job.out_idx[out];   // sorted position of last round's neighbour
+    if (pi >= 0 && pi < g.n) {
+      const double2* tp = reinterpret_cast<const double2*>(g.srec + pi);
+      const double2 ta = tp[0], tb = tp[1];
+      const double d = dist2(qx, qy, qz, ta.x, ta.y, tb.x);
+      if (slack >= 0.0 && job.out_lb != nullptr) {
+        // how far THIS query moved since the last search: |dM p + dv| (exactly, up to the rounding allowance)
+        const double p0 = job.q[3 * (size_t)i], p1 = job.q[3 * (size_t)i + 1], p2 = job.q[3 * (size_t)i + 2];
+        const double e0 = sxf[25] * p0 + sxf[28] * p1 + sxf[31] * p2 + sxf[34];
+        const double e1 = sxf[26] * p0 + sxf[29] * p1 + sxf[32] * p2 + sxf[35];
+        const double e2 = sxf[27] * p0 + sxf[30] * p1 + sxf[33] * p2 + sxf[36];
+        const double eps = sqrt(e0 * e0 + e1 * e1 + e2 * e2) * (1.0 + 1e-9) + slack;
+        const double nlb = job.out_lb[out] - eps;
+        if (sqrt(d) * (1.0 + 1e-12) < nlb) {
+          // eps == 0 only when the host found the edge's query transform bit-identical to last round's (slack 0, dM = dv = 0): the
+          // query, its distance, its bound and its list entry are then exactly what is stored already — nothing to write
+          if (eps != 0.0) {
+            job.out_d2[out] = d;
+            job.out_lb[out] = nlb;
+            if (job.dirty) update_list(job, i, pi, d, bound, true);
+          }
+          if (stats) {
+            unsigned long long c1 = __reduce_add_u64(1ull);
+            const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + (threadIdx.x >> 6);
+            if (__lane0()) atomicAdd(&stats[8 * slot + 3], c1);
+          }
+          return;
+        }
+      }
+      if (prune_rho > 0.0) { const double rp = sqrt(d) + prune_rho * g.h; rp2 = rp * rp * 1.002; }
+    }
+  }
 
   double m2 = 0.0;
   double skipped = 1.7976931348623157e308;   // smallest distance bound among the block cells not probed
@@ -368,7 +343,7 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
   job.out_d2[out] = best;
   // every other target is either a scanned candidate (>= second) or outside the block (>= m)
   if (job.out_lb != nullptr) job.out_lb[out] = resolved ? sqrt(fmin(fmin(second, m2), skipped)) * (1.0 - 1e-12) : 0.0;
-  if (job.dirty && (resolved || skip_far)) update_list(job, qi, bi == 0x7fffffff ? -1 : job.inv[bi], best, bound);
+  if (job.dirty && (resolved || skip_far)) update_list(job, i, bi == 0x7fffffff ? -1 : job.inv[bi], best, bound);
   if (!resolved && !skip_far) {
     // wave-aggregated append: one atomic per wave
     const unsigned long long mask = __ballot(1);
@@ -378,7 +353,7 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
     unsigned int base = 0;
     if (lane == leader) base = atomicAdd(far_count, (unsigned int)__popcll(mask));
     base = __shfl(base, leader, 64);
-    far_list[base + rank] = make_int2((int)blockIdx.y, qi);
+    far_list[base + rank] = make_int2((int)blockIdx.y, i);
   }
   if (stats) {
     // candidate census for the algorithmic-byte model: one slot per wave, no atomics
