@@ -236,15 +236,27 @@ class Engine:
         return bytes(buf)
 
     # ---- S1
+    def _round_buffers(self, K):
+        """Per-engine staging buffers + their ctypes pointers for the two per-round calls (building numpy arrays and ctypes pointers
+        anew costs ~10 us per call — a few per cent of a converged cfg4 round).  Results are handed back as copies."""
+        b = getattr(self, "_rb", None)
+        if b is None or b["K"] != K or b["E"] != self.E:
+            P = np.zeros((K, 16)); fx = np.zeros(K, dtype=np.uint8)
+            counts = np.zeros(self.E, dtype=np.int32); weights = np.zeros(self.E, dtype=np.float32)
+            sm = Summary()
+            b = {"K": K, "E": self.E, "P": P, "P44": P.reshape(K, 4, 4), "fx": fx, "counts": counts, "weights": weights, "sm": sm,
+                 "pP": _dp(P), "pfx": fx.ctypes.data_as(C.POINTER(C.c_ubyte)), "pc": _ip(counts), "pw": weights.ctypes.data_as(C.POINTER(C.c_float)),
+                 "psm": C.byref(sm)}
+            self._rb = b
+        return b
+
     def correspond(self, poses, fixed, thresh, nn_method=NN_AUTO):
-        P = poses_to_c(poses)
-        fx = np.ascontiguousarray(fixed, dtype=np.uint8)
-        counts = np.zeros(self.E, dtype=np.int32)
-        weights = np.zeros(self.E, dtype=np.float32)
-        _check(self.lib, self.lib.mvicp_correspond(self.h, _dp(P), fx.ctypes.data_as(C.POINTER(C.c_ubyte)), np.float32(thresh), nn_method,
-                                                   _ip(counts), weights.ctypes.data_as(C.POINTER(C.c_float))))
-        self.counts = counts
-        return counts, weights
+        b = self._round_buffers(len(poses))
+        np.copyto(b["P44"], np.transpose(np.asarray(poses, dtype=np.float64), (0, 2, 1)))   # 4x4 row-major -> column-major (Eigen)
+        b["fx"][:] = fixed
+        _check(self.lib, self.lib.mvicp_correspond(self.h, b["pP"], b["pfx"], np.float32(thresh), nn_method, b["pc"], b["pw"]))
+        self.counts = b["counts"].copy()
+        return self.counts, b["weights"].copy()
 
     def get_correspondences(self, edge):
         cap = self.npts[self.src[edge]]
@@ -274,12 +286,11 @@ class Engine:
         return out
 
     def optimize(self, poses, fixed, param=PARAM_SOPHUS_SE3, point_to_plane=True, robust=True, max_iterations=50):
-        P = poses_to_c(poses)
-        fx = np.ascontiguousarray(fixed, dtype=np.uint8).copy()
-        sm = Summary()
-        _check(self.lib, self.lib.mvicp_optimize(self.h, _dp(P), fx.ctypes.data_as(C.POINTER(C.c_ubyte)), param, int(point_to_plane), int(robust),
-                                                 max_iterations, C.byref(sm)))
-        return poses_from_c(P), sm.as_dict()
+        b = self._round_buffers(len(poses))
+        np.copyto(b["P44"], np.transpose(np.asarray(poses, dtype=np.float64), (0, 2, 1)))
+        b["fx"][:] = fixed          # (the solver forces fixed[0] = 1 in this private copy, like icp-ceres.cpp:244,341,417)
+        _check(self.lib, self.lib.mvicp_optimize(self.h, b["pP"], b["pfx"], param, int(point_to_plane), int(robust), max_iterations, b["psm"]))
+        return np.ascontiguousarray(np.transpose(b["P44"], (0, 2, 1))), b["sm"].as_dict()
 
     def set_option(self, name, value):
         _check(self.lib, self.lib.mvicp_set_option(self.h, name.encode(), float(value)))
