@@ -172,7 +172,7 @@ int ensure_pin(mvicp_ctx* c, size_t doubles) {
 }  // namespace
 
 // Per-edge relative transform for the LM kernels: A = R_d^T R_s, t = R_d^T (t_s - t_d).
-int upload_rel(mvicp_ctx* c, const double* poses, bool rel_only = false) {
+void fill_rel(mvicp_ctx* c, const double* poses) {
   double* h = c->h_pin + c->ctl_r2_off;  // region 2 of the control block: rel | a (a = SoftLOne scales, set by correspond)
   for (int e = 0; e < c->E; ++e) {
     const double* Ps = poses + 16 * (size_t)c->esrc[e];
@@ -183,8 +183,10 @@ int upload_rel(mvicp_ctx* c, const double* poses, bool rel_only = false) {
     const double dt[3] = {Ps[12] - Pd[12], Ps[13] - Pd[13], Ps[14] - Pd[14]};
     for (int i = 0; i < 3; ++i) r[9 + i] = Pd[0 + 4 * i] * dt[0] + Pd[1 + 4 * i] * dt[1] + Pd[2 + 4 * i] * dt[2];
   }
-  // rel_only: leave the SoftLOne scales on the device alone (the select kernels have just written them there)
-  MV_HIP(hipMemcpyAsync(c->d_rel, h, sizeof(double) * (rel_only ? (size_t)c->E * kEdgeRel : c->ctl_r2), hipMemcpyHostToDevice, c->stream));
+}
+int upload_rel(mvicp_ctx* c, const double* poses) {
+  fill_rel(c, poses);
+  MV_HIP(hipMemcpyAsync(c->d_rel, c->h_pin + c->ctl_r2_off, sizeof(double) * c->ctl_r2, hipMemcpyHostToDevice, c->stream));
   return MVICP_OK;
 }
 
@@ -661,7 +663,32 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
       lohi[2 * e] = m1 * 0.994; lohi[2 * e + 1] = m1 * 1.006;
     }
   }
-  MV_HIP(hipMemcpyAsync(c->d_ctl, hx, sizeof(double) * c->ctl_r1, hipMemcpyHostToDevice, c->stream));
+  // A search whose every edge has last round's exact transform and a valid list reproduces every query bit for bit: no list can
+  // change, so the (data-dependent, early-exiting) list-maintenance kernels — dirty-flag reduction, compaction, gather — are not
+  // even launched.
+  bool nothing_can_change = method == MVICP_NN_GRID && c->list_reuse && !c->nn_tree_only && !c->nn_skip_far && same_active_set;
+  for (int e = 0; e < E && nothing_can_change; ++e)
+    if (c->active[e] && !(same_edge[e] && hd[e] == 0)) nothing_can_change = false;
+  c->skip_dirty_reduce = nothing_can_change;
+  // Speculative first evaluation of the solve that follows (see common.h): same decision on every rank (the launch carries a
+  // collective), so it only looks at replicated state.  Not with the host-staged callback transport (that one blocks).
+  c->spec_ready = false;
+  c->spec_arm = c->spec_enable && c->spec_flags_valid && !c->ar_fn;
+  if (c->spec_arm && c->spec_plane)
+    for (int e = 0; e < E; ++e) if (!(fixed && fixed[c->esrc[e]]) && c->frames[c->edst[e]].n > 0 && c->frames[c->edst[e]].grid.snor == nullptr) c->spec_arm = false;
+  size_t upload_doubles = c->ctl_r1;
+  if (c->spec_arm) {
+    // the solve evaluates at x_to_pose(pose_to_x(P)) (host/lm.cpp): the same round trip here, so the poses match bit for bit.  The
+    // relative transforms of that evaluation ride on the control-block upload (region 2 follows region 1; the SoftLOne scales
+    // behind them are written on the device by the select kernels later in the stream)
+    c->spec_poses.resize(16 * (size_t)c->n_frames);
+    double xp[7];
+    for (int k = 0; k < c->n_frames; ++k) { se3::pose_to_x(c->spec_param, poses + 16 * (size_t)k, xp); se3::x_to_pose(c->spec_param, xp, &c->spec_poses[16 * (size_t)k]); }
+    fill_rel(c, c->spec_poses.data());
+    c->spec_q_plane = c->spec_plane; c->spec_q_robust = c->spec_robust;
+    upload_doubles = c->ctl_r2_off + (size_t)E * kEdgeRel;
+  }
+  MV_HIP(hipMemcpyAsync(c->d_ctl, hx, sizeof(double) * upload_doubles, hipMemcpyHostToDevice, c->stream));
   if (method == MVICP_NN_BRUTE) MV_CHECK(launch_nn_brute_edges(c));
   else if (method == MVICP_NN_GRID) MV_CHECK(launch_nn_grid_edges(c, bound));
   else if (method == MVICP_NN_TILE) MV_CHECK(launch_nn_tile_edges(c, bound));
@@ -675,29 +702,12 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   for (int e = 0; e < E; ++e) c->list_valid[e] = c->active[e];
 
   mark("host.corr.nn_launch");
-  // A search whose every edge has last round's exact transform and a valid list reproduces every query bit for bit: no list can
-  // change, so the (data-dependent, early-exiting) compaction and gather kernels are not even launched.
-  bool nothing_can_change = method == MVICP_NN_GRID && c->list_reuse && !c->nn_tree_only && !c->nn_skip_far && same_active_set;
-  for (int e = 0; e < E && nothing_can_change; ++e)
-    if (c->active[e] && !(same_edge[e] && hd[e] == 0)) nothing_can_change = false;
   if (!nothing_can_change) {
     MV_CHECK(launch_compact(c, bound));
     MV_CHECK(launch_gather_stream(c));
   }
-  // Speculative first evaluation of the solve that follows (see common.h): same sharding on every rank, so either all ranks
-  // queue it (incl. its all-reduce) or none does.  Not with the host-staged callback transport (that one blocks).
-  c->spec_ready = false;
-  c->spec_arm = c->spec_enable && c->spec_flags_valid && !c->ar_fn;
-  if (c->spec_arm && c->spec_plane)   // (over ALL edges, not this rank's: every rank must take the same decision — the launch carries a collective)
-    for (int e = 0; e < E; ++e) if (!(fixed && fixed[c->esrc[e]]) && c->frames[c->edst[e]].n > 0 && c->frames[c->edst[e]].grid.snor == nullptr) c->spec_arm = false;
   if (use_bracket) MV_CHECK(launch_select_bracket(c)); else MV_CHECK(launch_select_median(c));
-  if (c->spec_arm) {
-    // the solve evaluates at x_to_pose(pose_to_x(P)) (host/lm.cpp): the same round trip here, so the poses match bit for bit
-    c->spec_poses.resize(16 * (size_t)c->n_frames);
-    double xp[7];
-    for (int k = 0; k < c->n_frames; ++k) { se3::pose_to_x(c->spec_param, poses + 16 * (size_t)k, xp); se3::x_to_pose(c->spec_param, xp, &c->spec_poses[16 * (size_t)k]); }
-    MV_CHECK(upload_rel(c, c->spec_poses.data(), true));
-    c->spec_q_plane = c->spec_plane; c->spec_q_robust = c->spec_robust;
+  if (c->spec_arm) {   // the queued first evaluation (its relative transforms went up with the control block)
     const size_t nb = (size_t)E * MVICP_EDGE_BLOCK;
     if (c->comm) {
       c->lin_out = c->d_out;

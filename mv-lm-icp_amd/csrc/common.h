@@ -192,7 +192,8 @@ struct mvicp_ctx {
   bool nn_census = false;          // count candidates / tree nodes per launch while profiling (small extra cost)
   void* d_census = nullptr; size_t census_bytes = 0;
   void* d_far_list = nullptr; size_t far_cap = 0; unsigned int* d_far_count = nullptr;  // nn_grid far-query list
-  bool far_count_clean = false;    // the last grid launch left the counter zeroed (dirty_reduce_kernel)
+  int far_parity = 0;              // d_far_count holds TWO counters used alternately; a launch zeroes the one the next launch will use
+  bool skip_dirty_reduce = false;  // set by mvicp_correspond for a search in which no list can change (see api.cpp)
   bool nn_skip_far = false;        // PROFILING ONLY: leave unresolved queries unresolved (wrong results)
   bool tile_seed = true;           // tile kernel starts from last round's neighbours when there are any
   int tile_waves = 0;              // nn_tile_kernel variant: waves per SIMD it is compiled for (0 = the measured best for the depth)

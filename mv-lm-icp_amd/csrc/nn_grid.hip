@@ -161,9 +161,8 @@ __device__ __forceinline__ void update_list(const GridJob& job, int i, int idx_n
   if (!clean) job.dirty_slots[i / NT] = 1;
 }
 
-// Also leaves the slots and the far-list counter zeroed for the next round (no memsets in the per-round launch sequence).
-__global__ void dirty_reduce_kernel(int E, const int* __restrict__ slot_off, int* __restrict__ slots, int* __restrict__ dirty,
-                                    unsigned int* __restrict__ far_count) {
+// Also leaves the slots zeroed for the next round (no memsets in the per-round launch sequence).
+__global__ void dirty_reduce_kernel(int E, const int* __restrict__ slot_off, int* __restrict__ slots, int* __restrict__ dirty) {
   const int e = blockIdx.x;
   int any = 0;
   for (int k = slot_off[e] + threadIdx.x; k < slot_off[e + 1]; k += blockDim.x) {
@@ -171,7 +170,6 @@ __global__ void dirty_reduce_kernel(int E, const int* __restrict__ slot_off, int
     if (v) { any = 1; slots[k] = 0; }
   }
   if (__syncthreads_or(any) && threadIdx.x == 0) dirty[e] = 1;
-  if (e == 0 && threadIdx.x == 0) *far_count = 0u;   // phase 2 has finished (stream order)
 }
 
 // ---- phase 1: spatial-hash block lookup for every query; queries it cannot prove optimal go to the far list ----
@@ -694,10 +692,14 @@ __device__ __forceinline__ double oct_box_lb(double qx, double qy, double qz, co
 }
 
 __global__ __launch_bounds__(NT) void nn_far_kernel(const GridJob* __restrict__ jobs, const int2* __restrict__ far_list, double bound,
-                                                    const unsigned int* __restrict__ far_count, unsigned long long* __restrict__ stats, size_t stats_slots) {
+                                                    const unsigned int* __restrict__ far_count, unsigned int* __restrict__ next_far_count,
+                                                    unsigned long long* __restrict__ stats, size_t stats_slots) {
   __shared__ int s_id[NT / 8][OCT_STACK];
   __shared__ double s_lb[NT / 8][OCT_STACK];
   const unsigned int nfar = *far_count;
+  // two far-list counters alternate between launches: this launch consumes one, and leaves the OTHER one — which nothing touches
+  // during this launch — zeroed for the next phase 1 (no memset and no clean-up kernel in the per-round sequence)
+  if (blockIdx.x == 0 && threadIdx.x == 0) *next_far_count = 0u;
   const int oct = threadIdx.x >> 3, l = threadIdx.x & 7;
   const int lane = threadIdx.x & 63, obase = lane & ~7;
   unsigned long long n_cand = 0, n_nodes = 0;
@@ -1101,12 +1103,13 @@ int run(mvicp_ctx* c, const std::vector<GridJob>& jobs, double bound) {
   }
   const bool edge_path = jobs[0].dirty_slots != nullptr;   // dirty_reduce_kernel re-zeroes the counter after phase 2
   if (!c->d_far_count) {
-    MV_HIP(hipMalloc((void**)&c->d_far_count, sizeof(unsigned int)));
-    MV_HIP(hipMemsetAsync(c->d_far_count, 0, sizeof(unsigned int), c->stream));
-  } else if (!edge_path || !c->far_count_clean) {
-    MV_HIP(hipMemsetAsync(c->d_far_count, 0, sizeof(unsigned int), c->stream));
+    MV_HIP(hipMalloc((void**)&c->d_far_count, 2 * sizeof(unsigned int)));
+    MV_HIP(hipMemsetAsync(c->d_far_count, 0, 2 * sizeof(unsigned int), c->stream));
+    c->far_parity = 0;
   }
-  c->far_count_clean = edge_path;
+  unsigned int* far_cnt = c->d_far_count + c->far_parity;         // this launch's counter (zero: left so by the previous launch)
+  unsigned int* far_next = c->d_far_count + (c->far_parity ^ 1);
+  c->far_parity ^= 1;
   bool use_cell = false;
   {
     ProfScope ps(c, "nn", 36.0 * nq);  // query 24 B + result 12 B; the rest comes from the census below (0 if the census is off)
@@ -1116,17 +1119,19 @@ int run(mvicp_ctx* c, const std::vector<GridJob>& jobs, double bound) {
     use_cell = c->nn_cell && !c->nn_tree_only && !c->nn_skip_far && edge_path;
     for (const GridJob& j : jobs) if (j.dst.bricks == nullptr || j.xf == nullptr) use_cell = false;
     if (c->nn_tree_only)
-      hipLaunchKernelGGL((nn_grid_kernel<true>), grid, dim3(NT), 0, c->stream, d_jobs, bound, d_stats, 0, (int2*)c->d_far_list, c->d_far_count, 0.0);
+      hipLaunchKernelGGL((nn_grid_kernel<true>), grid, dim3(NT), 0, c->stream, d_jobs, bound, d_stats, 0, (int2*)c->d_far_list, far_cnt, 0.0);
     else if (use_cell)
-      hipLaunchKernelGGL(nn_cell_kernel, grid, dim3(NT), 0, c->stream, d_jobs, bound, d_stats, (int2*)c->d_far_list, c->d_far_count, c->prune_rho);
+      hipLaunchKernelGGL(nn_cell_kernel, grid, dim3(NT), 0, c->stream, d_jobs, bound, d_stats, (int2*)c->d_far_list, far_cnt, c->prune_rho);
     else
-      hipLaunchKernelGGL((nn_grid_kernel<false>), grid, dim3(NT), 0, c->stream, d_jobs, bound, d_stats, c->nn_skip_far ? 1 : 0, (int2*)c->d_far_list, c->d_far_count,
+      hipLaunchKernelGGL((nn_grid_kernel<false>), grid, dim3(NT), 0, c->stream, d_jobs, bound, d_stats, c->nn_skip_far ? 1 : 0, (int2*)c->d_far_list, far_cnt,
                          c->prune_rho);
     // phase 2: persistent grid-stride launch (the far count is only known on the device)
     const unsigned int far_blocks = (unsigned int)std::min<size_t>(256 * 8, (total_q * 8 + NT - 1) / NT);
-    hipLaunchKernelGGL(nn_far_kernel, dim3(far_blocks), dim3(NT), 0, c->stream, d_jobs, (const int2*)c->d_far_list, bound, c->d_far_count, d_stats, slots);
-    if (edge_path)
-      hipLaunchKernelGGL(dirty_reduce_kernel, dim3(c->E), dim3(256), 0, c->stream, c->E, c->d_dslot_off, c->d_dirty_slots, c->d_dirty, c->d_far_count);
+    hipLaunchKernelGGL(nn_far_kernel, dim3(far_blocks), dim3(NT), 0, c->stream, d_jobs, (const int2*)c->d_far_list, bound, (const unsigned int*)far_cnt, far_next, d_stats, slots);
+    // per-edge OR of the "list changed" slots — not needed when the host already knows that nothing can change (api.cpp: every
+    // transform bit-identical, every list valid): no query marks a slot then
+    if (edge_path && !c->skip_dirty_reduce)
+      hipLaunchKernelGGL(dirty_reduce_kernel, dim3(c->E), dim3(256), 0, c->stream, c->E, c->d_dslot_off, c->d_dirty_slots, c->d_dirty);
   }
   MV_HIP(hipGetLastError());
   if (d_stats) {
