@@ -165,7 +165,8 @@ int mvicp_closedform_point_to_plane(const double* src, const double* dst, const 
  * "tile_seed" (0/1, default 1): the tile kernel starts from last round's neighbours; "tile_waves" (0 = auto, 4..8):
  * occupancy variant of the tile kernel; "sel_bracket" (0/1, default 1): one-pass median select around last round's median
  * once it has settled; "spec_eval" (0/1, default 1): mvicp_correspond queues the first linearization of the following
- * mvicp_optimize (same poses, previous solve's flags) behind its own kernels so the round waits once, not twice; "nn_cell"
+ * mvicp_optimize (same poses, previous solve's flags) behind its own kernels so the round waits once, not twice; "lin_share_p"
+ * (0/1, default 1): the linearization reads the source points of an all-accepted edge from the shared sorted cloud; "nn_cell"
  * (0/1, default 0): wave-cooperative cell-staging variant of the grid kernel; "prune_rho", "auto_settle", "auto_switch",
  * "grid_curve": see DESIGN.md.  Tuning knobs: correspondences are
  * bit-identical for every setting. */

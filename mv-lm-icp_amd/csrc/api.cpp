@@ -830,6 +830,10 @@ int mvicp_set_correspondences(mvicp_ctx* c, int edge, int n, const int* first, c
   c->sel_med1[edge] = c->sel_med2[edge] = -1.0;
   const double a = (double)weight;
   MV_HIP(hipMemcpy(c->d_count + edge, &n, sizeof(int), hipMemcpyHostToDevice));
+  {   // an explicit list is arbitrary (repeats, any order): never the identity list the linearize kernel may shortcut
+    const int not_identity = -1;
+    MV_HIP(hipMemcpy(c->d_nsrc + edge, &not_identity, sizeof(int), hipMemcpyHostToDevice));
+  }
   MV_HIP(hipMemcpy(c->d_a + edge, &a, sizeof(double), hipMemcpyHostToDevice));
   c->h_pin[c->ctl_r2_off + (size_t)c->E * kEdgeRel + edge] = a;   // host mirror: region 2 is re-uploaded by every evaluation
   c->h_count[edge] = n;
@@ -886,6 +890,7 @@ int mvicp_set_option(mvicp_ctx* c, const char* name, double value) {
   if (std::strcmp(name, "nn_cache") == 0) { c->nn_cache_enable = value != 0.0; c->nn_cache_valid = false; return MVICP_OK; }
   if (std::strcmp(name, "lin_chunk") == 0) { c->lin_chunk_override = (int)value; return MVICP_OK; }  // takes effect at the next mvicp_set_graph
   if (std::strcmp(name, "list_reuse") == 0) { c->list_reuse = value != 0.0; return MVICP_OK; }
+  if (std::strcmp(name, "lin_share_p") == 0) { c->lin_share_p = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "nn_census") == 0) { c->nn_census = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "nn_skip_far") == 0) { c->nn_skip_far = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "sel_bracket") == 0) { c->sel_bracket = value != 0.0; return MVICP_OK; }

@@ -108,7 +108,8 @@ template <bool PLANE, bool ROBUST>
 __global__ __launch_bounds__(NT) void linearize_kernel(const int* __restrict__ chunk_edge, const int* __restrict__ chunk_start, int chunk,
                                                        const int* __restrict__ count, const long long* __restrict__ cap_off, long long total_cap,
                                                        const double* __restrict__ rel, const double* __restrict__ a_scale,
-                                                       const double* __restrict__ stream, double* __restrict__ partials) {
+                                                       const double* __restrict__ stream, double* __restrict__ partials,
+                                                       const double* const* __restrict__ src_pts, const int* __restrict__ nsrc) {
   const int c = blockIdx.x;
   const int e = chunk_edge[c];
   const int start = chunk_start[c];
@@ -142,10 +143,22 @@ __global__ __launch_bounds__(NT) void linearize_kernel(const int* __restrict__ c
   double2 cur[9], nxt[9];
 #pragma unroll
   for (int j = 0; j < 9; ++j) { cur[j] = make_double2(0.0, 0.0); nxt[j] = make_double2(0.0, 0.0); }
+  // Every query accepted (count == N_src: the usual case once the clouds overlap within the cutoff) makes the list the identity,
+  // first[pos] = pos, so p is the source cloud itself in its sorted order: read it from there (AoS, three 16-B loads per pair of
+  // correspondences, ordinary cacheable loads) instead of from the stream's private copy.  The two edges of a source frame are
+  // consecutive in the chunk order and share that 24 B per point through L2 / MALL — same values, so results are bit-identical.
+  const double* __restrict__ sp = (src_pts != nullptr && cnt == nsrc[e]) ? src_pts[e] : nullptr;
   auto load = [&](double2 (&v)[9], int at) {
     if (at + 1 < end) {
+      if (sp != nullptr) {
+        const double2 a = *reinterpret_cast<const double2*>(sp + 3 * (size_t)at);
+        const double2 b = *reinterpret_cast<const double2*>(sp + 3 * (size_t)at + 2);
+        const double2 c2 = *reinterpret_cast<const double2*>(sp + 3 * (size_t)at + 4);
+        v[0] = make_double2(a.x, b.y); v[1] = make_double2(a.y, c2.x); v[2] = make_double2(b.x, c2.y);
+      }
 #pragma unroll
       for (int j = 0; j < NS; ++j) {
+        if (j < 3 && sp != nullptr) continue;
         // non-temporal: the stream is read exactly once per evaluation and is larger than the caches; keeping it from
         // allocating there is worth +15 % bandwidth (cfg4 136 -> 117 us, cfg5 6.3 -> 7.0 TB/s)
         typedef double d2v __attribute__((ext_vector_type(2)));
@@ -154,7 +167,7 @@ __global__ __launch_bounds__(NT) void linearize_kernel(const int* __restrict__ c
       }
     } else if (at < end) {
 #pragma unroll
-      for (int j = 0; j < NS; ++j) { v[j].x = s0[(size_t)arr(j) * total_cap + at]; v[j].y = 0.0; }
+      for (int j = 0; j < NS; ++j) { v[j].x = (j < 3 && sp != nullptr) ? sp[3 * (size_t)at + j] : s0[(size_t)arr(j) * total_cap + at]; v[j].y = 0.0; }
     }
   };
   load(cur, pos);
@@ -331,10 +344,17 @@ int launch_linearize(mvicp_ctx* c, int plane, int robust) {
   if (c->n_chunks > 0) {
     double bytes = 0;
     for (int e = 0; e < c->E; ++e) if (c->owned[e]) bytes += (plane ? 56.0 : 48.0) * c->h_count[e];
+    // per-edge sorted source clouds (identity-list fast path of the kernel); table cached by content
+    const double* const* d_src = nullptr;
+    if (c->lin_share_p) {
+      std::vector<const double*> tab((size_t)c->E, nullptr);
+      for (int e = 0; e < c->E; ++e) if (c->owned[e]) tab[e] = c->frames[c->esrc[e]].grid.spts;
+      MV_CHECK(cached_upload(c, "lin_src", tab.data(), sizeof(void*) * tab.size(), (void**)&d_src));
+    }
     ProfScope ps(c, "linearize", bytes);
 #define LAUNCH(P, R)                                                                                                                           \
   hipLaunchKernelGGL((linearize_kernel<P, R>), dim3(c->n_chunks), dim3(NT), 0, c->stream, c->d_chunk_edge, c->d_chunk_start, chunk, c->d_count, \
-                     c->d_cap_off, c->total_cap, c->d_rel, c->d_a, c->d_stream, c->d_partials)
+                     c->d_cap_off, c->total_cap, c->d_rel, c->d_a, c->d_stream, c->d_partials, d_src, (const int*)c->d_nsrc)
     if (plane && robust) LAUNCH(true, true);
     else if (plane) LAUNCH(true, false);
     else if (robust) LAUNCH(false, true);
