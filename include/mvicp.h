@@ -168,7 +168,8 @@ int mvicp_closedform_point_to_plane(const double* src, const double* dst, const 
  * mvicp_optimize (same poses, previous solve's flags) behind its own kernels so the round waits once, not twice; "lin_share_p"
  * (0/1, default 1): the linearization reads the source points of an all-accepted edge from the shared sorted cloud; "nn_cell"
  * (0/1, default 0): wave-cooperative cell-staging variant of the grid kernel; "prune_rho", "auto_settle", "auto_switch",
- * "grid_curve": see DESIGN.md.  Tuning knobs: correspondences are
+ * see DESIGN.md; "grid_curve" (default 2): device order of the clouds at the next mvicp_set_frame, 2 = balanced k-d order,
+ * 1 / 0 = Hilbert / Morton index of the hash cell (nn_cell needs 0 or 1).  Tuning knobs: correspondences are
  * bit-identical for every setting. */
 int mvicp_set_option(mvicp_ctx* ctx, const char* name, double value);
 /* NN census accumulated while profiling and the "nn_census" option are on: out[0..5] = queries, candidate points

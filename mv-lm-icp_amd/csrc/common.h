@@ -44,9 +44,10 @@ struct GridDev {
   double origin[3] = {0, 0, 0};
   double cell = 0.0, inv_cell = 0.0;
   int n_cells = 0;             // occupied cells
-  double* spts = nullptr;      // n x 3 sorted by the curve index (Hilbert by default) of the cell
+  double* spts = nullptr;      // n x 3 in the cloud's sorted order (balanced k-d order by default, ctx::grid_curve)
   int* sidx = nullptr;         // n: original index of sorted point
   void* srec = nullptr;        // n x 32 B {x, y, z, idx}: the same, packed for the per-lane candidate scans
+  void* crec = nullptr;        // the records in hash-CELL order ({start, count} runs of `table`); aliases srec unless grid_curve = 2
   double* snor = nullptr;      // n x 3 normals in sorted order (null without normals)
   int* inv = nullptr;          // n: original index -> sorted position
   std::vector<int> h_order, h_inv;  // host copies: sorted -> original, original -> sorted
@@ -205,7 +206,7 @@ struct mvicp_ctx {
                                    // profiles/r02_nn_cell_experiment.txt): off by default
   double auto_switch = 1.0;        // AUTO: hand over from the tile kernel to the grid method once the median distance is below this many hash cells
   double prune_rho = 0.05;         // grid kernel: with a seed, skip block cells farther than seed distance + prune_rho * cell edge; 0 = off
-  int grid_curve = 1;              // cell order of the sorted clouds: 0 Morton (Z-order), 1 Hilbert
+  int grid_curve = 2;              // order of the sorted clouds: 0 Morton (Z-order) of the cells, 1 Hilbert of the cells, 2 balanced k-d order
   double grid_target = 5.0;        // points per occupied cell the cell-edge heuristic aims at (4-6 measure the same within 2 %)
   double nn_candidates = 0, nn_nodes = 0, nn_far = 0, nn_queries = 0, nn_hits = 0, nn_fetched = 0;
 

@@ -9,11 +9,13 @@
 //
 // Per cloud, built ONCE at upload (clouds are static in their local frame, like the reference's lazily
 // built tree, frame.cpp:188-193):
-//   * points sorted by the Hilbert-curve index of their grid cell (cell edge h ~ a few point spacings);
-//     `spts` (sorted xyz) + `sidx` (original index).  The sorted order is also the QUERY order of a source
-//     cloud: neighbouring lanes ask about neighbouring places, so hash slots / point runs / tree nodes are
-//     shared inside a wave and stay in L2.
-//   * an open-addressing hash table  cell -> (start, count)  (16-B entries, <= 50 % load): the spatial hash.
+//   * points in a balanced k-d ORDER (kd_order below; grid_curve 0 / 1: Morton / Hilbert index of the grid cell instead):
+//     `spts` (sorted xyz) + `sidx` (original index) + `srec` (both, 32-B records).  The sorted order is also the QUERY
+//     order of a source cloud: neighbouring lanes ask about neighbouring places, so hash slots / point runs / tree nodes
+//     are shared inside a wave and stay in L2.
+//   * an open-addressing hash table  cell -> (start, count)  (16-B entries, <= 50 % load): the spatial hash (cell edge
+//     h ~ a few point spacings).  Its runs index `crec`, the records in Hilbert-of-cells order (the same array as `srec`
+//     when that IS the sorted order).
 //   * an implicit complete 8-ary box tree over the sorted array (leaf j = points [j n / 8^D, (j+1) n / 8^D), float
 //     AABBs rounded OUTWARD, 32 B per node, heap-indexed: no pointers).
 // Query = (0) temporal cache: if last round's neighbour is provably still nearest, re-evaluate its distance and stop;
@@ -29,6 +31,7 @@
 #include <cstring>
 #include <limits>
 #include <numeric>
+#include <thread>
 #include <unordered_set>
 
 #include "common.h"
@@ -45,7 +48,8 @@ struct HashEntry { unsigned long long key; unsigned int start, count; };
 struct BrickEntry { unsigned long long mask; unsigned int tab; unsigned int pad; };   // 4x4x4 cells: bit (x&3) | (y&3)<<2 | (z&3)<<4
 
 struct GridView {  // device view of one cloud's structure
-  const double* spts; const int* sidx; const PointRec* srec; int n;
+  const double* spts; const int* sidx; const PointRec* srec; int n;   // canonical (sorted-position) order
+  const PointRec* crec;                                                  // the records in CELL order: what the hash runs index (== srec for the curve orders)
   const HashEntry* table; unsigned int mask; int shift;
   double ox, oy, oz, h, inv_h;
   int dx, dy, dz;
@@ -89,23 +93,6 @@ __device__ __forceinline__ void xf_point(const double* __restrict__ x, double p0
 __device__ __forceinline__ double dist2(double qx, double qy, double qz, double x, double y, double z) {
   const double d0 = __dsub_rn(qx, x), d1 = __dsub_rn(qy, y), d2 = __dsub_rn(qz, z);
   return __dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2));
-}
-
-// keeps the running (d2, index) minimum AND `second` = the smallest d2 among all other scanned candidates
-__device__ __forceinline__ void scan_range(const GridView& g, int lo, int hi, double qx, double qy, double qz, double& best, int& bi, double& second) {
-#pragma unroll 2
-  for (int j = lo; j < hi; ++j) {
-    const double2* p = reinterpret_cast<const double2*>(g.srec + j);  // two 16-B loads per candidate
-    const double2 a = p[0], b = p[1];
-    const double d = dist2(qx, qy, qz, a.x, a.y, b.x);
-    const int oi = (int)__double_as_longlong(b.y);
-    if (d < best || (d == best && oi < bi)) {
-      if (bi != 0x7fffffff) second = fmin(second, best);
-      best = d; bi = oi;
-    } else {
-      second = fmin(second, d);
-    }
-  }
 }
 
 // sum over the ACTIVE lanes of the wave (lanes may have exited early)
@@ -304,7 +291,7 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
       for (;;) {
         while (j == je && c < 7) { ++c; const uint2 r = s_rng[c][threadIdx.x]; j = r.x; je = r.x + r.y; }
         if (j == je) break;
-        const double2* p = reinterpret_cast<const double2*>(g.srec + j);  // two 16-B loads per candidate
+        const double2* p = reinterpret_cast<const double2*>(g.crec + j);  // two 16-B loads per candidate
         const double2 a = p[0], b = p[1];
         const double d = dist2(qx, qy, qz, a.x, a.y, b.x);
         const int oi = (int)__double_as_longlong(b.y);
@@ -890,6 +877,57 @@ void make_grid(HostGrid& g, const double* lo, const double* hi, double h) {
   }
 }
 
+
+// Balanced k-d ORDER of the cloud (grid_curve 2): recursive split at a multiple of 32 points (the tile size of nn_tile.hip) along the
+// widest axis of the range's bounding box, left part = the largest power-of-two number of tiles below the range's tile count, so
+// every aligned run of 32 * 2^k points is one subtree.  Tiles of 32 consecutive points then have ~1.5x smaller boxes than runs of
+// a space-filling curve over the hash cells, and a wave of 64 consecutive queries a tighter patch: ~40 % fewer tiles opened per
+// wave in the moving rounds (profiles/r02_kd_order_sim.txt).  Ties on the split coordinate break on the original index and the
+// recursion runs down to single points, so the order is a pure function of the cloud.
+struct KdItem { double x, y, z; int idx; int pad; };
+void kd_split(KdItem* a, long long lo, long long hi, int par) {   // par: levels that still fork a host thread
+  for (;;) {
+    const long long m = hi - lo;
+    if (m <= 1) return;
+    double bl[3] = {a[lo].x, a[lo].y, a[lo].z}, bh[3] = {a[lo].x, a[lo].y, a[lo].z};
+    for (long long i = lo + 1; i < hi; ++i) {
+      bl[0] = std::min(bl[0], a[i].x); bh[0] = std::max(bh[0], a[i].x);
+      bl[1] = std::min(bl[1], a[i].y); bh[1] = std::max(bh[1], a[i].y);
+      bl[2] = std::min(bl[2], a[i].z); bh[2] = std::max(bh[2], a[i].z);
+    }
+    int ax = 0;
+    if (bh[1] - bl[1] > bh[ax] - bl[ax]) ax = 1;
+    if (bh[2] - bl[2] > bh[ax] - bl[ax]) ax = 2;
+    // above a tile: whole tiles on the left; inside a tile: keep halving down to single points, so that ANY short run of
+    // consecutive points is compact (the leaves of the 8-ary box tree are runs of ~6) and the order is unique
+    const long long units = m > 32 ? (m + 31) / 32 : m, unit = m > 32 ? 32 : 1;
+    long long left = 1;
+    while (left * 2 < units) left *= 2;
+    const long long mid = lo + left * unit;
+    auto less = [ax](const KdItem& p, const KdItem& q) {
+      const double u = ax == 0 ? p.x : ax == 1 ? p.y : p.z, v = ax == 0 ? q.x : ax == 1 ? q.y : q.z;
+      return u != v ? u < v : p.idx < q.idx;
+    };
+    std::nth_element(a + lo, a + mid, a + hi, less);
+    if (par > 0 && m > (1 << 15)) {
+      std::thread t(kd_split, a, lo, mid, par - 1);
+      kd_split(a, mid, hi, par - 1);
+      t.join();
+      return;
+    }
+    // recurse into the smaller part, loop on the larger (bounded stack)
+    if (mid - lo < hi - mid) { kd_split(a, lo, mid, 0); lo = mid; }
+    else { kd_split(a, mid, hi, 0); hi = mid; }
+  }
+}
+void kd_order(const double* xyz, int n, std::vector<int>& order) {
+  std::vector<KdItem> a((size_t)n);
+  for (int i = 0; i < n; ++i) a[i] = KdItem{xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], i, 0};
+  kd_split(a.data(), 0, n, 3);
+  order.resize(n);
+  for (int i = 0; i < n; ++i) order[i] = a[i].idx;
+}
+
 }  // namespace
 
 int build_grid(mvicp_ctx* c, FrameDev& f, const double* xyz) {
@@ -938,9 +976,15 @@ int build_grid(mvicp_ctx* c, FrameDev& f, const double* xyz) {
                                  : hilbert3((unsigned)cc[0], (unsigned)cc[1], (unsigned)cc[2], hbits);
     ckey[i] = cell_key(cc[0], cc[1], cc[2]);
   }
-  std::vector<int> order(n);
-  std::iota(order.begin(), order.end(), 0);
-  std::sort(order.begin(), order.end(), [&](int a, int b) { return mkey[a] != mkey[b] ? mkey[a] < mkey[b] : a < b; });
+  // CELL order: the hash table's {start, count} runs index the records in this order (G.crec)
+  std::vector<int> corder(n);
+  std::iota(corder.begin(), corder.end(), 0);
+  std::sort(corder.begin(), corder.end(), [&](int a, int b) { return mkey[a] != mkey[b] ? mkey[a] < mkey[b] : a < b; });
+  // CANONICAL order ("sorted positions": what every index of the pipeline means, and what the tile hierarchy and the box tree are
+  // built over): the cell order itself for the two curves, the k-d order otherwise
+  const bool split_orders = c->grid_curve >= 2 && n > 64;
+  std::vector<int> order;
+  if (split_orders) kd_order(xyz, n, order); else order = corder;
   std::vector<double> spts(3 * (size_t)n);
   for (int i = 0; i < n; ++i) std::memcpy(&spts[3 * (size_t)i], xyz + 3 * (size_t)order[i], 24);
 
@@ -948,8 +992,8 @@ int build_grid(mvicp_ctx* c, FrameDev& f, const double* xyz) {
   std::vector<HashEntry> runs;
   for (int i = 0; i < n;) {
     int j = i + 1;
-    while (j < n && ckey[order[j]] == ckey[order[i]]) ++j;
-    runs.push_back(HashEntry{ckey[order[i]], (unsigned)i, (unsigned)(j - i)});
+    while (j < n && ckey[corder[j]] == ckey[corder[i]]) ++j;
+    runs.push_back(HashEntry{ckey[corder[i]], (unsigned)i, (unsigned)(j - i)});
     i = j;
   }
   int log2size = 4;
@@ -969,7 +1013,7 @@ int build_grid(mvicp_ctx* c, FrameDev& f, const double* xyz) {
     const long long bd[3] = {(g.d[0] + 3) / 4, (g.d[1] + 3) / 4, (g.d[2] + 3) / 4};
     const long long nb = bd[0] * bd[1] * bd[2];
     const bool capped = g.d[0] >= (1 << 21) - 1 || g.d[1] >= (1 << 21) - 1 || g.d[2] >= (1 << 21) - 1;
-    if (!capped && nb <= (1ll << 24) && n < (1 << 30)) {
+    if (!split_orders && !capped && nb <= (1ll << 24) && n < (1 << 30)) {   // nn_cell_kernel stages runs of the CANONICAL arrays
       std::vector<BrickEntry> bricks((size_t)nb, BrickEntry{0ull, 0xffffffffu, 0u});
       std::vector<uint2> celltab;
       unsigned int n_tab = 0;
@@ -1029,6 +1073,12 @@ int build_grid(mvicp_ctx* c, FrameDev& f, const double* xyz) {
     for (int i = 0; i < n; ++i) { rec[i].x = spts[3 * (size_t)i]; rec[i].y = spts[3 * (size_t)i + 1]; rec[i].z = spts[3 * (size_t)i + 2]; rec[i].idx = order[i]; }
     MV_HIP(hipMalloc((void**)&G.srec, sizeof(PointRec) * (size_t)std::max(n, 1)));
     MV_HIP(hipMemcpy(G.srec, rec.data(), sizeof(PointRec) * (size_t)n, hipMemcpyHostToDevice));
+    G.crec = G.srec;
+    if (split_orders) {
+      for (int i = 0; i < n; ++i) { const double* p = xyz + 3 * (size_t)corder[i]; rec[i].x = p[0]; rec[i].y = p[1]; rec[i].z = p[2]; rec[i].idx = corder[i]; }
+      MV_HIP(hipMalloc((void**)&G.crec, sizeof(PointRec) * (size_t)n));
+      MV_HIP(hipMemcpy(G.crec, rec.data(), sizeof(PointRec) * (size_t)n, hipMemcpyHostToDevice));
+    }
   }
   MV_HIP(hipMalloc((void**)&G.spts, sizeof(double) * 3 * (size_t)n));
   MV_HIP(hipMalloc((void**)&G.sidx, sizeof(int) * (size_t)n));
@@ -1050,6 +1100,7 @@ int build_grid(mvicp_ctx* c, FrameDev& f, const double* xyz) {
 void free_grid(GridDev& g) {
   if (g.spts) (void)hipFree(g.spts);
   if (g.sidx) (void)hipFree(g.sidx);
+  if (g.crec && g.crec != g.srec) (void)hipFree(g.crec);
   if (g.srec) (void)hipFree(g.srec);
   if (g.snor) (void)hipFree(g.snor);
   if (g.inv) (void)hipFree(g.inv);
@@ -1065,7 +1116,7 @@ namespace {
 GridView view_of(const FrameDev& f) {
   GridView v;
   const GridDev& g = f.grid;
-  v.spts = g.spts; v.sidx = g.sidx; v.srec = (const PointRec*)g.srec; v.n = f.n;
+  v.spts = g.spts; v.sidx = g.sidx; v.srec = (const PointRec*)g.srec; v.crec = (const PointRec*)g.crec; v.n = f.n;
   v.table = (const HashEntry*)g.table; v.mask = g.table_mask; v.shift = g.table_shift;
   v.ox = g.origin[0]; v.oy = g.origin[1]; v.oz = g.origin[2]; v.h = g.cell; v.inv_h = g.inv_cell;
   v.dx = g.dims[0]; v.dy = g.dims[1]; v.dz = g.dims[2];

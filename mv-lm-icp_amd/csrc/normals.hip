@@ -27,7 +27,8 @@ __device__ __forceinline__ unsigned long long cell_key(int ix, int iy, int iz) {
 __device__ __forceinline__ unsigned int hash_slot(unsigned long long k, int shift) { return (unsigned int)((k * 0x9E3779B97F4A7C15ull) >> shift); }
 
 struct NormJob {
-  const PointRec* srec; int n;
+  const PointRec* srec; int n;   // records in hash-CELL order (GridDev::crec)
+  const int* inv;                // original index -> sorted (canonical) position
   const HashEntry* table; unsigned int mask; int shift;
   double ox, oy, oz, h, inv_h;
   int dx, dy, dz;
@@ -79,12 +80,12 @@ __device__ __forceinline__ void jacobi_min_eigvec(double a00, double a01, double
 }
 
 __global__ __launch_bounds__(NT) void normals_kernel(NormJob job) {
-  const int i = blockIdx.x * NT + threadIdx.x;  // sorted position
+  const int i = blockIdx.x * NT + threadIdx.x;  // position in cell order
   if (i >= job.n) return;
   const PointRec me = job.srec[i];
   const int K = job.k;
   double bd[KMAX];
-  int bj[KMAX];       // sorted positions of the current k best
+  int bj[KMAX];       // cell-order positions of the current k best
   long long bo[KMAX]; // their original indices (tie rule)
   const int cx = min(max((int)floor((me.x - job.ox) * job.inv_h), 0), job.dx - 1);
   const int cy = min(max((int)floor((me.y - job.oy) * job.inv_h), 0), job.dy - 1);
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(NT) void normals_kernel(NormJob job) {
   jacobi_min_eigvec(c00, c01, c02, c11, c12, c22, nv);
   double* o = job.nor_out + 3 * (size_t)me.idx;
   o[0] = nv[0]; o[1] = nv[1]; o[2] = nv[2];
-  double* os = job.snor_out + 3 * (size_t)i;
+  double* os = job.snor_out + 3 * (size_t)job.inv[me.idx];
   os[0] = nv[0]; os[1] = nv[1]; os[2] = nv[2];
   if (job.knn_out) {
 #pragma unroll
@@ -163,7 +164,7 @@ int launch_normals(mvicp_ctx* c, FrameDev& f, int k, int* d_knn) {
   if (k < 3 || k > KMAX) { set_error("k = %d outside [3, %d]", k, KMAX); return MVICP_ERR_ARG; }
   NormJob j;
   const GridDev& g = f.grid;
-  j.srec = (const PointRec*)g.srec; j.n = f.n;
+  j.srec = (const PointRec*)g.crec; j.inv = g.inv; j.n = f.n;
   j.table = (const HashEntry*)g.table; j.mask = g.table_mask; j.shift = g.table_shift;
   j.ox = g.origin[0]; j.oy = g.origin[1]; j.oz = g.origin[2]; j.h = g.cell; j.inv_h = g.inv_cell;
   j.dx = g.dims[0]; j.dy = g.dims[1]; j.dz = g.dims[2];

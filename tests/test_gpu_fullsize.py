@@ -109,9 +109,10 @@ def test_cfg4_full_size_vs_nanoflann(orc, refnn, cfg4):
     eng.close()
 
 
-def test_cfg4_moving_rounds_cache_and_list_reuse_are_bit_identical(cfg4):
+@pytest.mark.parametrize("curve", [2, 1])
+def test_cfg4_moving_rounds_cache_and_list_reuse_are_bit_identical(cfg4, curve):
     """Full-size twin of test_temporal_cache_is_bit_identical_to_full_search: two engines on config 4, one with the temporal NN
-    cache + list reuse + bracket select + cell-staging grid kernel (the product defaults), one with all four off (per-lane hash kernel,
+    cache + list reuse + bracket select (the product defaults; with curve = 1 also the optional cell-staging grid kernel), one with all four off (per-lane hash kernel,
     full search, full compaction and radix select every round), walked through the SAME poses:
     8 rounds of the real ICP trajectory from the noisy initial poses, then 5 rounds of injected pose motion from a few point
     spacings down to 1e-6 m (partial cache hits, partially reused lists).  Every round: identical counts and weights on all 62
@@ -121,7 +122,9 @@ def test_cfg4_moving_rounds_cache_and_list_reuse_are_bit_identical(cfg4):
     engs = []
     for on in (1, 0):
         e = mvicp.Engine(0)
-        e.set_option("nn_cache", on); e.set_option("list_reuse", on); e.set_option("sel_bracket", on); e.set_option("nn_cell", on)
+        e.set_option("nn_cache", on); e.set_option("list_reuse", on); e.set_option("sel_bracket", on)
+        e.set_option("grid_curve", curve)   # 2: the default k-d order; 1: Hilbert order of the cells, which also has the brick map nn_cell needs
+        e.set_option("nn_cell", on if curve == 1 else 0)
         e.set_frames(pb["pts"], pb["nor"]); e.set_graph(pb["src"], pb["dst"])
         engs.append(e)
     a, b = engs
