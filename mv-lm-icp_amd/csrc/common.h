@@ -54,7 +54,7 @@ struct GridDev {
   void* table = nullptr;       // open-addressing hash: cell -> (start, count), 16-B entries
   unsigned int table_mask = 0; int table_shift = 0;
   float* oct = nullptr;        // implicit complete 8-ary box tree, 8 floats per node {lo.xyz, hi.xyz, pad2}
-  int oct_depth = 0; long long oct_first_leaf = 0;
+  int oct_leaf = 0; long long oct_first_leaf = 0;
   // 64-wide box hierarchy over the same sorted array (nn_tile.hip): level 0 = boxes of 64-point leaves,
   // level l+1 = boxes of 64 consecutive level-l boxes; SoA per level: 6 arrays of `wide_cnt[l]` floats.
   float* wide = nullptr;

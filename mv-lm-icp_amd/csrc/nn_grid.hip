@@ -16,8 +16,8 @@
 //   * an open-addressing hash table  cell -> (start, count)  (16-B entries, <= 50 % load): the spatial hash (cell edge
 //     h ~ a few point spacings).  Its runs index `crec`, the records in Hilbert-of-cells order (the same array as `srec`
 //     when that IS the sorted order).
-//   * an implicit complete 8-ary box tree over the sorted array (leaf j = points [j n / 8^D, (j+1) n / 8^D), float
-//     AABBs rounded OUTWARD, 32 B per node, heap-indexed: no pointers).
+//   * an implicit complete 8-ary box tree over the sorted array (leaf j = the aligned run of 8 / 16 / 32 sorted points
+//     [j L, (j+1) L), float AABBs rounded OUTWARD, 32 B per node, heap-indexed: no pointers).
 // Query = (0) temporal cache: if last round's neighbour is provably still nearest, re-evaluate its distance and stop;
 // (1) scan the 2x2x2 cell block around the query through the hash; the best candidate is provably the global NN iff
 // it is closer than the distance to the block's faces (>= h/2); (2) otherwise the query joins a compacted far list
@@ -53,7 +53,7 @@ struct GridView {  // device view of one cloud's structure
   const HashEntry* table; unsigned int mask; int shift;
   double ox, oy, oz, h, inv_h;
   int dx, dy, dz;
-  const float* oct; int oct_depth; long long oct_first_leaf;   // implicit 8-ary box tree (32-B boxes), phase 2
+  const float* oct; int oct_leaf; long long oct_first_leaf;    // implicit 8-ary box tree (32-B boxes), phase 2; leaf j = sorted points [j * oct_leaf, (j + 1) * oct_leaf)
   const BrickEntry* bricks; const uint2* celltab; int bx, by, bz;   // dense brick map (null: none), nn_cell_kernel
 };
 
@@ -668,7 +668,7 @@ __global__ __launch_bounds__(NT, 5) void nn_cell_kernel(const GridJob* __restric
 // points at a time with an octet arg-min.  Compared with one lane per query this divides the number of dependent
 // memory round trips per query by ~3 (8-ary instead of binary), keeps the loads of an octet contiguous, and only the 8
 // octets of a wave can diverge from each other.  Persistent grid-stride launch: the far count lives on the device.
-constexpr int OCT_STACK = 56;  // >= 7 * max depth (depth <= 8 for n < 2^27)
+constexpr int OCT_STACK = 56;  // >= 7 * max depth + 1 (build_grid keeps the depth <= 7)
 
 __device__ __forceinline__ double oct_box_lb(double qx, double qy, double qz, const float4 a, const float4 b) {
   // box = {lo.xyz = a.xyz, hi.xyz = (a.w, b.x, b.y)}
@@ -711,7 +711,7 @@ __global__ __launch_bounds__(NT) void nn_far_kernel(const GridJob* __restrict__ 
     double second = 1.7976931348623157e308;   // smallest d2 among scanned targets other than the running best
     double pruned = 1.7976931348623157e308;   // smallest lower bound among the boxes this lane skipped
     const long long first_leaf = g.oct_first_leaf;
-    const int sh = 3 * g.oct_depth;
+    const int per_leaf = g.oct_leaf;
     int sp = 0;
     if (l == 0) { s_id[oct][0] = 0; s_lb[oct][0] = 0.0; }
     sp = 1;
@@ -722,7 +722,7 @@ __global__ __launch_bounds__(NT) void nn_far_kernel(const GridJob* __restrict__ 
       if (lbp > best) { pruned = fmin(pruned, lbp); continue; }
       if (id >= first_leaf) {
         const long long j = (long long)id - first_leaf;
-        const int lo = (int)((j * g.n) >> sh), hi = (int)(((j + 1) * g.n) >> sh);
+        const int lo = (int)min(j * per_leaf, (long long)g.n), hi = min(lo + per_leaf, g.n);
         double d = 1.7976931348623157e308, ls = 1.7976931348623157e308;  // this lane's best and second best in the leaf
         int oi = 0x7fffffff;
         for (int k = lo + l; k < hi; k += 8) {
@@ -1037,14 +1037,25 @@ int build_grid(mvicp_ctx* c, FrameDev& f, const double* xyz) {
   auto down = [](double v) { float f = (float)v; if ((double)f > v) f = std::nextafterf(f, -std::numeric_limits<float>::infinity()); return f; };
   auto up = [](double v) { float f = (float)v; if ((double)f < v) f = std::nextafterf(f, std::numeric_limits<float>::infinity()); return f; };
   // implicit complete 8-ary box tree over the sorted array (phase 2 of the grid kernel): 32-B boxes {lo.xyz, hi.xyz, pad}
-  int D8 = 0;
-  while ((1ll << (3 * (D8 + 1))) <= (long long)n / 6) ++D8;
+  // leaves are ALIGNED runs of 8, 16 or 32 sorted points (whole k-d subtrees in the default order, so are all their ancestors' runs);
+  // of the (depth, leaf size) pairs that cover n the one with the fewest empty leaves is taken; empty leaves keep inverted boxes
+  // (lower bound +inf: never opened)
+  int D8 = 0, L8 = 8;
+  {
+    long long best_cap = -1;
+    for (int d = 0; d <= 7; ++d)      // OCT_STACK holds 7 entries per level + 1
+      for (int l8 = 8; l8 <= 32; l8 *= 2) {
+        const long long cap = (1ll << (3 * d)) * l8;
+        if (cap >= std::max(n, 1) && (best_cap < 0 || cap < best_cap)) { best_cap = cap; D8 = d; L8 = l8; }
+      }
+    if (best_cap < 0) { D8 = 7; L8 = 64; while ((1ll << 21) * L8 < n) L8 *= 2; }   // > 67 M points: longer leaves
+  }
   const long long leaves8 = 1ll << (3 * D8);
   const long long first_leaf8 = (leaves8 - 1) / 7;
   const long long nodes8 = first_leaf8 + leaves8;
   std::vector<float> oct(8 * (size_t)nodes8, 0.f);
   for (long long j = 0; j < leaves8; ++j) {
-    const int a = (int)((j * n) >> (3 * D8)), b = (int)(((j + 1) * n) >> (3 * D8));
+    const int a = (int)std::min<long long>(j * L8, n), b = (int)std::min<long long>((long long)a + L8, n);
     float* bx = &oct[8 * (size_t)(first_leaf8 + j)];
     bx[0] = bx[1] = bx[2] = finf; bx[3] = bx[4] = bx[5] = -finf;
     for (int k = a; k < b; ++k)
@@ -1058,7 +1069,7 @@ int build_grid(mvicp_ctx* c, FrameDev& f, const double* xyz) {
       for (int ax = 0; ax < 3; ++ax) { bx[ax] = std::min(bx[ax], cb[ax]); bx[3 + ax] = std::max(bx[3 + ax], cb[3 + ax]); }
     }
   }
-  G.oct_depth = D8; G.oct_first_leaf = first_leaf8;
+  G.oct_leaf = L8; G.oct_first_leaf = first_leaf8;
   MV_HIP(hipMalloc((void**)&G.oct, sizeof(float) * oct.size()));
   MV_HIP(hipMemcpy(G.oct, oct.data(), sizeof(float) * oct.size(), hipMemcpyHostToDevice));
 
@@ -1120,7 +1131,7 @@ GridView view_of(const FrameDev& f) {
   v.table = (const HashEntry*)g.table; v.mask = g.table_mask; v.shift = g.table_shift;
   v.ox = g.origin[0]; v.oy = g.origin[1]; v.oz = g.origin[2]; v.h = g.cell; v.inv_h = g.inv_cell;
   v.dx = g.dims[0]; v.dy = g.dims[1]; v.dz = g.dims[2];
-  v.oct = g.oct; v.oct_depth = g.oct_depth; v.oct_first_leaf = g.oct_first_leaf;
+  v.oct = g.oct; v.oct_leaf = g.oct_leaf; v.oct_first_leaf = g.oct_first_leaf;
   v.bricks = (const BrickEntry*)g.bricks; v.celltab = (const uint2*)g.celltab; v.bx = g.bdims[0]; v.by = g.bdims[1]; v.bz = g.bdims[2];
   return v;
 }
