@@ -514,6 +514,7 @@ int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) {
     MV_HIP(hipMalloc(&c->d_far_list, sizeof(int) * 2 * cap));
     c->far_cap = cap;
   }
+  MV_CHECK(warm_nn_grid(c)); MV_CHECK(warm_nn_tile(c));
   MV_CHECK(dev_alloc(&c->d_median, E));
   MV_CHECK(dev_alloc(&c->d_chunk_edge, (size_t)c->n_chunks)); MV_CHECK(dev_alloc(&c->d_chunk_start, (size_t)c->n_chunks));
   MV_CHECK(dev_alloc(&c->d_chunk_first, E + 1));
@@ -642,6 +643,13 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
     for (int e = 0; e < E; ++e)
       if (c->active[e] && (!c->frames[c->edst[e]].has_grid || !c->frames[c->esrc[e]].has_grid)) method = MVICP_NN_BRUTE;
   }
+  // The round in which AUTO hands over to the grid kernel would be an UNCACHED grid round (every query searched through the hash:
+  // 2.4-2.6 ms on cfg4, the slowest round after the first).  Instead the tile kernel runs once more in its BND build (~1.2 ms), which
+  // also leaves the per-query lower bounds the temporal cache needs; the grid kernel takes over one round later, with cache hits.
+  bool tile_lb = false, handed_over = false;
+  if (nn_method == MVICP_NN_AUTO && method == MVICP_NN_GRID && c->auto_last_method == MVICP_NN_TILE && c->tile_bounds >= 1 &&
+      c->nn_cache_enable && !c->nn_cell) { method = MVICP_NN_TILE; tile_lb = true; handed_over = true; }
+  if (method == MVICP_NN_TILE && c->tile_bounds >= 2 && c->nn_cache_enable) tile_lb = true;
   {
     // an edge may keep last round's compacted list only if the grid kernel (which checks every query) runs and the list
     // on the device really is last round's result for this edge
@@ -691,13 +699,14 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   MV_HIP(hipMemcpyAsync(c->d_ctl, hx, sizeof(double) * upload_doubles, hipMemcpyHostToDevice, c->stream));
   if (method == MVICP_NN_BRUTE) MV_CHECK(launch_nn_brute_edges(c));
   else if (method == MVICP_NN_GRID) MV_CHECK(launch_nn_grid_edges(c, bound));
-  else if (method == MVICP_NN_TILE) MV_CHECK(launch_nn_tile_edges(c, bound));
+  else if (method == MVICP_NN_TILE) MV_CHECK(launch_nn_tile_edges(c, bound, tile_lb));
   else { set_error("unknown nn_method %d", nn_method); return MVICP_ERR_ARG; }
-  // only the grid kernel maintains the per-query lower bounds the temporal cache needs; the cutoff must not change either
+  // only the grid kernel and the tile kernel's BND build leave the per-query lower bounds the temporal cache needs; the cutoff must
+  // not change either
   c->last_rms = -1.0;   // consumed: only a solve that follows THIS search may predict the next one
-  c->nn_cache_valid = (method == MVICP_NN_GRID) && !c->nn_tree_only && !c->nn_skip_far;
+  c->nn_cache_valid = ((method == MVICP_NN_GRID) && !c->nn_tree_only && !c->nn_skip_far) || tile_lb;
   c->nn_cache_thresh = thresh;
-  c->auto_last_method = method;
+  c->auto_last_method = handed_over ? MVICP_NN_GRID : method;   // (the policy's "already handed over" state)
   c->nn_cache_edge.assign(c->active.begin(), c->active.end());
   for (int e = 0; e < E; ++e) c->list_valid[e] = c->active[e];
 
@@ -900,6 +909,8 @@ int mvicp_set_option(mvicp_ctx* c, const char* name, double value) {
   if (std::strcmp(name, "auto_switch") == 0) { c->auto_switch = value; return MVICP_OK; }
   if (std::strcmp(name, "nn_cell") == 0) { c->nn_cell = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "tile_seed") == 0) { c->tile_seed = value != 0.0; return MVICP_OK; }
+  if (std::strcmp(name, "tile_bounds") == 0) { c->tile_bounds = (int)value; return MVICP_OK; }
+  if (std::strcmp(name, "tile_mu") == 0) { if (!(value > 0.0 && value <= 1.0)) { set_error("tile_mu outside (0, 1]"); return MVICP_ERR_ARG; } c->tile_mu = value; return MVICP_OK; }
   if (std::strcmp(name, "tile_waves") == 0) { c->tile_waves = (int)value; return MVICP_OK; }
   if (std::strcmp(name, "spin_wait") == 0) { c->spin_wait = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "spec_eval") == 0) { c->spec_enable = value != 0.0; c->spec_ready = false; return MVICP_OK; }

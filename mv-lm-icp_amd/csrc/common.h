@@ -198,6 +198,10 @@ struct mvicp_ctx {
   bool skip_dirty_reduce = false;  // set by mvicp_correspond for a search in which no list can change (see api.cpp)
   bool nn_skip_far = false;        // PROFILING ONLY: leave unresolved queries unresolved (wrong results)
   bool tile_seed = true;           // tile kernel starts from last round's neighbours when there are any
+  int tile_bounds = 1;             // 1: the AUTO round that would hand over to the grid kernel runs the tile kernel's BND build instead (it leaves the
+                                   // temporal-cache bounds, so the grid kernel starts with cache hits one round later and the uncached grid round — the
+                                   // slowest of a registration — never runs); 2: every tile round leaves bounds (tests); 0: off
+  double tile_mu = 0.05;           // BND guard band as a fraction of the target's hash-cell edge (same role as prune_rho in the grid kernel)
   int tile_waves = 0;              // nn_tile_kernel variant: waves per SIMD it is compiled for (0 = the measured best for the depth)
   double auto_prev_dist = 0.0; int auto_last_method = -1; double auto_settle = 0.5;   // MVICP_NN_AUTO policy state (api.cpp)
   double last_rms = -1.0;          // RMS residual at the end of the last mvicp_optimize since the last search (< 0: none): predicts the next NN distances
@@ -221,7 +225,8 @@ namespace mvicp {
 int launch_nn_brute_edges(mvicp_ctx* c);                                             // nn_brute.hip
 int launch_nn_brute_queries(mvicp_ctx* c, const FrameDev& f, const double* d_q, int n, int* d_idx, double* d_d2);
 int launch_nn_grid_edges(mvicp_ctx* c, double d2_bound);                              // nn_grid.hip
-int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound);                              // nn_tile.hip
+int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound, bool with_bounds);
+int warm_nn_tile(mvicp_ctx* c); int warm_nn_grid(mvicp_ctx* c);                                    // code-object load at set-up time (mvicp_set_graph)                              // nn_tile.hip
 int build_wide(FrameDev& f, const double* sorted_pts);                                 // nn_tile.hip (host, called by build_grid)
 int launch_nn_grid_queries(mvicp_ctx* c, const FrameDev& f, const double* d_q, int n, int* d_idx, double* d_d2);
 int build_grid(mvicp_ctx* c, FrameDev& f, const double* h_xyz);

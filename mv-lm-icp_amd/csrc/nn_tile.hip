@@ -19,7 +19,10 @@
 //     reads, conflict-free, four candidates per step in packed fp32), confirming the few that pass in fp64 and
 //     keeping its running (d2, index) minimum.  Children are opened nearest-first (wave arg-min on the DPP network)
 //     so the running minima tighten before the siblings are tested;
-//   * from the second round on every lane starts from last round's neighbour (an ordinary candidate).
+//   * from the second round on every lane starts from last round's neighbour (an ordinary candidate);
+//   * BND build (template flag; used for the one AUTO round that hands over to the grid kernel, api.cpp): the guard band is widened
+//     by mu and the exact second-best distance is tracked, which yields the per-query lower bound the grid kernel's temporal cache
+//     starts from (leaf_scan).  The plain build carries none of that state.
 // The kernel is VALU-issue bound (not memory bound): its design minimises wave instructions per opened tile.
 // No per-lane pointer chasing, no divergence between "near" and "far" queries: the first-round regime
 // (centimetre misalignment) and the converged regime run the same code, the former just opens more leaves.
@@ -55,6 +58,8 @@ struct TileJob {
   int* out_idx; double* out_d2;
   const int* inv;   // target original index -> sorted position
   int seed;         // out_idx still holds last round's neighbours (sorted positions, -1 = none): use them as starting candidates
+  double* out_lb;   // BND builds: per query, a lower bound on the distance to every target other than out_idx (the grid kernel's temporal cache)
+  float mu;         // BND builds: width of the extra guard band (metres) that makes that bound useful
 };
 
 __device__ __forceinline__ void xf_point(const double* __restrict__ x, double p0, double p1, double p2, double& q0, double& q1, double& q2) {
@@ -132,13 +137,15 @@ struct Lane {          // per-lane query state
   // three scratch loads and one scratch store per lane per opened tile — 1.4 GB of memory writes per launch on cfg4 (round-1 PMC).
   f2v qx2, qy2, qz2;
   double pad_;           // (keeps thr away from the pairs: no cross-field vector loads)
-  float thr;             // fp32 screen threshold, always >= (sqrt(best) + slack)^2 (see leaf_scan)
+  float thr;             // fp32 screen threshold, always >= (sqrt(best) + slack + mu)^2 (see leaf_scan; mu = 0 unless BND)
   int bi;
   bool active;
+  double second;         // BND builds only: smallest exact d2 among the fp64-evaluated targets other than the running best
 };
 struct Group {         // wave-uniform patch description
   double lo[3], hi[3], c[3];
   float slack;         // fp32 screening guard band (metres)
+  float mu;            // BND builds: extra guard band (0 otherwise)
 };
 
 // fp32 squared distance from the lane's query to a box.  Same guard-band argument as the point screen in leaf_scan: the
@@ -173,7 +180,13 @@ struct TileLds {   // per wave
   int id[LEAF];
 };
 
-__device__ __forceinline__ void leaf_scan(const TileView& g, int leaf, Lane& L, float slack, TileLds* __restrict__ T, unsigned int* n_cand) {
+// BND (the round that hands over to the grid kernel): the guard band is widened by mu, so everything the screen rejects — points
+// here, boxes in visit() — is farther than sqrt(best) + mu from the query at that moment, hence farther than sqrt(final best) + mu;
+// everything that passes is evaluated exactly and the smallest d2 among those that are NOT the running best is kept in L.second.
+// min(sqrt(second), sqrt(best) + mu) is then a lower bound on the distance to every target other than the answer: the quantity the
+// grid kernel's temporal cache needs (GridJob::out_lb).
+template <bool BND>
+__device__ __forceinline__ void leaf_scan(const TileView& g, int leaf, Lane& L, float slack, float mu, TileLds* __restrict__ T, unsigned int* n_cand) {
   const int lane = threadIdx.x & 63;
   const int lo = leaf * LEAF;
   const int cnt = min(LEAF, g.n - lo);
@@ -216,7 +229,17 @@ __device__ __forceinline__ void leaf_scan(const TileView& g, int leaf, Lane& L, 
         if (((hit >> j) & 1u) && k < cnt) {
           const double d0 = __dsub_rn(L.qx, T->x[k]), d1 = __dsub_rn(L.qy, T->y[k]), d2 = __dsub_rn(L.qz, T->z[k]);
           const double d = __dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2));
-          if (d <= L.best) {
+          if (BND) {
+            const int oi = T->id[k];
+            if (d < L.best || (d == L.best && oi < L.bi)) {
+              L.second = fmin(L.second, L.best);   // the old best (or the cutoff bound: only lowers the bound) is now "another target"
+              L.best = d; L.bi = oi;
+              const float r = __builtin_amdgcn_sqrtf(d32[j]) * 1.000001f + 2.f * slack + mu;
+              thr = fminf(thr, r * r * 1.000002f);
+            } else if (oi != L.bi) {               // (the running best itself comes by again when its tile is scanned after a seed)
+              L.second = fmin(L.second, d);
+            }
+          } else if (d <= L.best) {
             const int oi = T->id[k];
             if (d < L.best || oi < L.bi) {
               L.best = d; L.bi = oi;
@@ -237,7 +260,7 @@ __device__ __forceinline__ void leaf_scan(const TileView& g, int leaf, Lane& L, 
 // is live in all deeper levels.  Levels 1 and 2 therefore park their 64 child boxes in wave-private LDS (32 B each, read
 // back with one uniform-address load per step) and keep only {cull distance, order key, pending} per lane; level 0, the
 // hot one, keeps its boxes in registers and broadcasts them with v_readlane.
-template <int LEVEL>
+template <int LEVEL, bool BND>
 __device__ void visit(const TileView& g, int first, int nchild, Lane& L, const Group& G, TileLds* __restrict__ T,
                       float2* __restrict__ sbox, unsigned int* n_cand, unsigned int* n_box) {
   constexpr bool IN_LDS = LEVEL == 1 || LEVEL == 2;
@@ -295,10 +318,10 @@ __device__ void visit(const TileView& g, int first, int nchild, Lane& L, const G
     if (__ballot(L.active && lb <= L.thr) == 0ull) continue;
     const int child = first + c;
     if (LEVEL == 0) {
-      leaf_scan(g, child, L, G.slack, T, n_cand);
+      leaf_scan<BND>(g, child, L, G.slack, G.mu, T, n_cand);
     } else {
       const int cf = child * FAN;
-      visit<(LEVEL > 0 ? LEVEL - 1 : 0)>(g, cf, min(FAN, g.cnt[LEVEL > 0 ? LEVEL - 1 : 0] - cf), L, G, T, sbox, n_cand, n_box);
+      visit<(LEVEL > 0 ? LEVEL - 1 : 0), BND>(g, cf, min(FAN, g.cnt[LEVEL > 0 ? LEVEL - 1 : 0] - cf), L, G, T, sbox, n_cand, n_box);
     }
     gmax = wave_max_f(L.active ? L.thr : 0.f);
   }
@@ -306,7 +329,7 @@ __device__ void visit(const TileView& g, int first, int nchild, Lane& L, const G
 
 // TOP >= 0: every target of the launch has exactly TOP + 1 hierarchy levels (the common case: clouds of similar size), so
 // only that traversal is compiled in; TOP = -1: generic (per-job switch over the depth).
-template <int WPE, int TOP>
+template <int WPE, int TOP, bool BND>
 __global__ __launch_bounds__(NT, WPE) void nn_tile_kernel(const TileJob* __restrict__ jobs, double bound, unsigned long long* __restrict__ stats) {
   __shared__ TileLds s_tile[NT / 64];
   __shared__ float2 s_box[NT / 64][2 * 3 * FAN];   // levels 1 and 2: 64 child boxes x 24 B each, per wave
@@ -324,6 +347,7 @@ __global__ __launch_bounds__(NT, WPE) void nn_tile_kernel(const TileJob* __restr
   Lane L;
   L.active = i < job.n;
   L.best = bound; L.bi = 0x7fffffff;
+  L.second = 1.7976931348623157e308;
   L.qx = L.qy = L.qz = 0.0;
   if (L.active) {
     const double p0 = job.q[3 * (size_t)i], p1 = job.q[3 * (size_t)i + 1], p2 = job.q[3 * (size_t)i + 2];
@@ -355,25 +379,29 @@ __global__ __launch_bounds__(NT, WPE) void nn_tile_kernel(const TileJob* __restr
     for (int a = 0; a < 3; ++a) m = fmax(m, fmax(fmax(fabs(G.lo[a]), fabs(G.hi[a])), g.maxabs));
     // per axis: |fl32(q) - q| + |fl32(p) - p| + rounding of the fp32 subtraction <= 3 * 2^-24 * m; x sqrt(3) axes, x2 safety
     G.slack = bcast((float)(m * (3.0 * 1.7320508 * 2.0 / 16777216.0)) + 1e-30f, 0);
+    G.mu = BND ? job.mu : 0.f;
   }
   { const float a = (float)L.qx, b = (float)L.qy, c2 = (float)L.qz; L.qx2 = f2v{a, a}; L.qy2 = f2v{b, b}; L.qz2 = f2v{c2, c2}; L.pad_ = 0.0; }
-  L.thr = thr_of(L.best, G.slack);
+  L.thr = thr_of(L.best, G.slack + G.mu);
   unsigned int n_cand = 0, n_box = 0;
   const int top = g.levels - 1;
   TileLds* T = &s_tile[wave];
   float2* sbox = s_box[wave];
-  if (TOP >= 0) visit<(TOP >= 0 ? TOP : 0)>(g, 0, g.cnt[TOP >= 0 ? TOP : 0], L, G, T, sbox, &n_cand, &n_box);
+  if (TOP >= 0) visit<(TOP >= 0 ? TOP : 0), BND>(g, 0, g.cnt[TOP >= 0 ? TOP : 0], L, G, T, sbox, &n_cand, &n_box);
   else switch (top) {
-    case 0: visit<0>(g, 0, g.cnt[0], L, G, T, sbox, &n_cand, &n_box); break;
-    case 1: visit<1>(g, 0, g.cnt[1], L, G, T, sbox, &n_cand, &n_box); break;
-    case 2: visit<2>(g, 0, g.cnt[2], L, G, T, sbox, &n_cand, &n_box); break;
-    case 3: visit<3>(g, 0, g.cnt[3], L, G, T, sbox, &n_cand, &n_box); break;
-    default: visit<4>(g, 0, g.cnt[4], L, G, T, sbox, &n_cand, &n_box); break;
+    case 0: visit<0, BND>(g, 0, g.cnt[0], L, G, T, sbox, &n_cand, &n_box); break;
+    case 1: visit<1, BND>(g, 0, g.cnt[1], L, G, T, sbox, &n_cand, &n_box); break;
+    case 2: visit<2, BND>(g, 0, g.cnt[2], L, G, T, sbox, &n_cand, &n_box); break;
+    case 3: visit<3, BND>(g, 0, g.cnt[3], L, G, T, sbox, &n_cand, &n_box); break;
+    default: visit<4, BND>(g, 0, g.cnt[4], L, G, T, sbox, &n_cand, &n_box); break;
   }
   if (L.active) {
     const int out = i;   // sorted order of the source cloud
     job.out_idx[out] = L.bi == 0x7fffffff ? -1 : (job.inv ? job.inv[L.bi] : L.bi);
     job.out_d2[out] = L.best;
+    // every other target was evaluated exactly (>= second) or rejected by a screen (> sqrt(best) + mu away); 1e-9 relative covers the
+    // fp64 roundings of this line.  No neighbour inside the cutoff: 0 forces a full search next round, like the grid kernel does.
+    if (BND) job.out_lb[out] = L.bi == 0x7fffffff ? 0.0 : fmin(sqrt(L.second), sqrt(L.best) + (double)G.mu) * (1.0 - 1e-9);
   }
   if (stats && (threadIdx.x & 63) == 0) {
     // wave-uniform counters: candidates examined PER LANE x active lanes, boxes tested per wave
@@ -455,7 +483,15 @@ int build_wide(FrameDev& f, const double* spts) {
   return MVICP_OK;
 }
 
-int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound) {
+namespace { __global__ void tile_warm_kernel() {} }
+
+int warm_nn_tile(mvicp_ctx* c) {   // see warm_nn_grid (nn_grid.hip): loads this file's code object at set-up time
+  hipLaunchKernelGGL(tile_warm_kernel, dim3(1), dim3(64), 0, c->stream);
+  MV_HIP(hipGetLastError());
+  return MVICP_OK;
+}
+
+int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound, bool with_bounds) {
   std::vector<TileJob> jobs;
   int max_n = 0;
   double nq = 0;
@@ -471,6 +507,7 @@ int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound) {
     j.out_idx = c->d_nn_idx + c->cap_off[e]; j.out_d2 = c->d_nn_d2 + c->cap_off[e];
     j.inv = d.grid.inv;
     j.seed = (c->tile_seed && (int)c->nn_cache_edge.size() == c->E && c->nn_cache_edge[e]) ? 1 : 0;
+    if (with_bounds) { j.out_lb = c->d_nn_lb + c->cap_off[e]; j.mu = (float)(c->tile_mu * d.grid.cell); }
     jobs.push_back(j);
     max_n = std::max(max_n, s.n);
     nq += s.n;
@@ -495,11 +532,15 @@ int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound) {
     const dim3 grid((max_n + NT - 1) / NT, (unsigned)jobs.size());
     int top = jobs[0].dst.levels - 1;   // same depth everywhere -> the traversal specialised for it
     for (const TileJob& j : jobs) if (j.dst.levels - 1 != top) top = -1;
-#define MVICP_TILE_LAUNCH(W, T) hipLaunchKernelGGL((nn_tile_kernel<W, T>), grid, dim3(NT), 0, c->stream, d_jobs, d2_bound, d_stats)
+#define MVICP_TILE_LAUNCH(W, T) hipLaunchKernelGGL((nn_tile_kernel<W, T, false>), grid, dim3(NT), 0, c->stream, d_jobs, d2_bound, d_stats)
+#define MVICP_TILE_LAUNCH_BND(W, T) hipLaunchKernelGGL((nn_tile_kernel<W, T, true>), grid, dim3(NT), 0, c->stream, d_jobs, d2_bound, d_stats)
     const int waves = c->tile_waves;   // 0 = pick: 7 waves per SIMD for the depth-3 build, 6 otherwise
     // depth-3 build: 7 waves per SIMD measures the same as 8 (cfg4 rounds 1-4: 6.6 / 2.72 / 2.12 / 1.68 vs 6.5 / 2.73 / 2.13 / 1.67 ms) with 2
     // spilled registers instead of 10; 6 waves (no spill at all) is 3-5 % slower
-    if (top == 2 && (waves == 0 || waves == 7)) MVICP_TILE_LAUNCH(7, 2);
+    if (with_bounds) {   // hand-over round: one more fp64 register pair per lane, so one wave per SIMD fewer
+      if (top == 2) MVICP_TILE_LAUNCH_BND(6, 2); else MVICP_TILE_LAUNCH_BND(6, -1);
+    }
+    else if (top == 2 && (waves == 0 || waves == 7)) MVICP_TILE_LAUNCH(7, 2);
     else if (top == 2 && waves == 8) MVICP_TILE_LAUNCH(8, 2);
     else if (top == 2 && waves == 6) MVICP_TILE_LAUNCH(6, 2);
     else if (top == 1 && (waves == 0 || waves == 6)) MVICP_TILE_LAUNCH(6, 1);
@@ -510,6 +551,7 @@ int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound) {
       default: MVICP_TILE_LAUNCH(6, -1); break;
     }
 #undef MVICP_TILE_LAUNCH
+#undef MVICP_TILE_LAUNCH_BND
   }
   MV_HIP(hipGetLastError());
   if (d_stats) {

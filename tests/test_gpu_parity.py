@@ -542,11 +542,71 @@ def test_temporal_cache_is_bit_identical_to_full_search(orc):
         e.close()
 
 
+@pytest.mark.parametrize("mu", [0.05, 0.4, 0.003])
+def test_tile_kernel_lower_bounds_feed_the_temporal_cache(orc, mu):
+    """The tile kernel's BND build (the round in which AUTO hands over to the grid kernel) leaves, per query, a lower bound on the
+    distance to every target other than the answer; the next grid search trusts it (temporal cache).  Engine A: tile search WITH
+    bounds at poses P, then a grid search at P moved by a random rigid motion of a given size; engine B does the same with the cache
+    off (full searches).  For motions from 1e-7 m (nearly every query is a cache hit) to millimetres (hardly any) the lists, counts,
+    weights and normal-equation blocks must be identical, the first and last also to the oracle's; and the cache must really engage
+    for the small motions — otherwise the test proves nothing."""
+    pb = synth.make_problem(4, 6000)
+    engs = []
+    for cache in (1, 0):
+        e = mvicp.Engine(0)
+        e.set_option("nn_cache", cache); e.set_option("list_reuse", cache)
+        e.set_option("tile_bounds", 2); e.set_option("tile_mu", mu)
+        e.set_frames(pb["pts"], pb["nor"]); e.set_graph(pb["src"], pb["dst"])
+        e.profile(True); e.set_option("nn_census", 1)
+        engs.append(e)
+    rng = np.random.default_rng(5)
+    poses = pb["init"].copy()
+    for r in range(3):   # get near the fixed point first: the hand-over happens in a nearly converged registration
+        for e in engs:
+            e.correspond(poses, pb["fixed"], 0.05, L.NN_TILE)
+        poses, _ = engs[0].optimize(poses, pb["fixed"], L.PARAM_SOPHUS_SE3, 1, True, 50)
+    mags = [1e-7, 1e-6, 1e-5, 1e-4, 5e-4, 3e-3, 0.0]
+    hit_frac = []
+    for it, mag in enumerate(mags):
+        for e in engs:   # tile search (A: leaves bounds) at the current poses
+            e.correspond(poses, pb["fixed"], 0.05, L.NN_TILE)
+        moved = poses.copy()
+        for k in range(1, len(moved)):
+            T = np.eye(4); T[:3, :3] = synth.so3_exp(rng.normal(0, mag / 0.4, 3)); T[:3, 3] = rng.normal(0, mag, 3)
+            moved[k] = moved[k] @ T
+        res = []
+        for e in engs:
+            e.profile_reset()
+            c, w = e.correspond(moved, pb["fixed"], 0.05, L.NN_GRID)
+            res.append((c, w, [e.get_correspondences(k) for k in range(e.E)], e.nn_census()))
+        (c1, w1, l1, s1), (c0, w0, l0, s0) = res
+        assert np.array_equal(c1, c0) and w1.tobytes() == w0.tobytes(), (mu, mag)
+        for a, b in zip(l1, l0):
+            assert all(np.array_equal(x, y) for x, y in zip(a, b)), (mu, mag)
+        assert np.array_equal(engs[0].linearize(moved, 1, 1), engs[1].linearize(moved, 1, 1)), (mu, mag)
+        hit_frac.append(s1["hits"] / s1["queries"])
+        assert s0["hits"] == 0
+        if it in (0, len(mags) - 2):
+            for k, (s_, d_) in enumerate(zip(pb["src"], pb["dst"])):
+                f, sec, dist, wt, _, _ = orc.correspond_edge(pb["pts"][s_], moved[s_], pb["pts"][d_], moved[d_], 0.05)
+                assert np.array_equal(l1[k][0], f) and np.array_equal(l1[k][1], sec) and np.array_equal(l1[k][2], dist) and w1[k] == wt
+        # a second cached grid round on top (bounds now partly the tile kernel's, partly the grid kernel's own)
+        for e in engs:
+            e.correspond(poses, pb["fixed"], 0.05, L.NN_GRID)
+        for k in range(engs[0].E):
+            assert all(np.array_equal(x, y) for x, y in zip(engs[0].get_correspondences(k), engs[1].get_correspondences(k))), (mu, mag)
+    # the bounds are useful: tiny motions are answered from the cache, millimetre motions are not (0.0 = identical poses: all hits
+    # except exact ties / queries without a neighbour)
+    assert hit_frac[0] > 0.5 and hit_frac[-1] > 0.5 and hit_frac[-2] < hit_frac[0], hit_frac
+    for e in engs:
+        e.close()
+
+
 @pytest.mark.parametrize("opts", [
     {"tile_seed": 0}, {"tile_waves": 4}, {"tile_waves": 8}, {"prune_rho": 0.0}, {"prune_rho": 0.6},
     {"auto_settle": 0.05}, {"auto_settle": 5.0}, {"nn_cache": 0, "list_reuse": 0}, {"spin_wait": 1}, {"sel_bracket": 0},
     {"grid_curve": 0}, {"grid_curve": 1}, {"grid_target": 2.5}, {"nn_cell": 1}, {"nn_cell": 1, "auto_switch": 0.2}, {"nn_cell": 1, "auto_switch": 50.0}, {"nn_cell": 1, "prune_rho": 0.0},
-    {"prune_rho": 3.0}, {"spec_eval": 0}, {"lin_share_p": 0},
+    {"prune_rho": 3.0}, {"spec_eval": 0}, {"lin_share_p": 0}, {"tile_bounds": 0}, {"tile_bounds": 2}, {"tile_bounds": 2, "tile_mu": 0.5}, {"tile_mu": 0.005},
 ])
 def test_tuning_options_never_change_results(opts):
     """Every speed knob (kernel variants, seeding, cell pruning, AUTO hand-over policy, caches) must leave the whole ICP
