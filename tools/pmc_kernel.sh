@@ -19,7 +19,7 @@ if not f:
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(int)
 seen = set()
 for r in csv.DictReader(open(f[0])):
-    k = r["Kernel_Name"].split("(")[0][-60:]
+    k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][-60:]
     acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
     key = (r["Dispatch_Id"], k)
     if key not in seen:
