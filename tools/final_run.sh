@@ -1,3 +1,11 @@
+#!/bin/bash
+# Round-end evidence in ONE gpurun call (GPU box):  gpurun --timeout 500 -- 'bash tools/final_run.sh'
+#   1. the GPU test suite — everything below is skipped unless it is green;
+#   2. tools/profile.sh for both bench protocols (rocprofv3 kernel trace + the two PMC passes) -> gpurun_out/prof/<tag>/: copy <tag>_kernels.json and
+#      <tag>_summary.txt into profiles/ afterwards (bench.py quotes `traffic` from them only while their source hash matches);
+#   3. one bench line per workload -> gpurun_out/fin2_<workload>.json (re-run the two cfg4 lines once the new profiles are in profiles/ if their
+#      `traffic` field is wanted in the committed lines);
+#   4. the per-round NN trace of the AUTO method.
 timeout 330 python -m pytest tests -m gpu -x -q 2>&1 | grep -a "passed\|failed\|Error\|assert" | tail -8 > gpurun_out/fin2_tests.txt
 cat gpurun_out/fin2_tests.txt
 if grep -q "failed\|Error" gpurun_out/fin2_tests.txt || ! grep -q "passed" gpurun_out/fin2_tests.txt; then echo TESTS_NOT_GREEN; exit 0; fi
