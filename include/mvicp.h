@@ -32,7 +32,8 @@ enum mvicp_status {
   MVICP_ERR_HIP = -2,      /* HIP runtime error (no GPU, OOM, launch failure) */
   MVICP_ERR_STATE = -3,    /* frames/graph/correspondences not set */
   MVICP_ERR_COMM = -4,     /* RCCL failure */
-  MVICP_ERR_NUMERIC = -5   /* LM solve failed (non-finite / not positive definite) */
+  MVICP_ERR_NUMERIC = -5,  /* LM solve failed (non-finite / not positive definite) */
+  MVICP_ERR_INTERNAL = -6  /* a host-side C++ exception (out of memory, thread creation, ...) was caught at the boundary */
 };
 
 /* Rotation parameterization of the LM solve = which reference optimizer is mirrored. */

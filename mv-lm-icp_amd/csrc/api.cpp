@@ -5,6 +5,8 @@
 #include <cmath>
 #include <cstring>
 #include <ctime>
+#include <exception>
+#include <new>
 
 #include "common.h"
 #include "comm.h"
@@ -19,6 +21,14 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+int abi_exception() noexcept {
+  try { throw; }
+  catch (const std::bad_alloc&) { set_error("out of host memory"); }
+  catch (const std::exception& e) { set_error("internal error: %s", e.what()); }
+  catch (...) { set_error("internal error (unknown exception)"); }
+  return MVICP_ERR_INTERNAL;
 }
 
 int cached_upload(mvicp_ctx* c, const char* key, const void* src, size_t bytes, void** dptr) {
@@ -286,7 +296,7 @@ extern "C" {
 const char* mvicp_last_error(void) { return g_err; }
 const char* mvicp_version(void) { return "mvicp_hip 0.1 (gfx950)"; }
 
-int mvicp_create(int device, mvicp_ctx** out) {
+int mvicp_create(int device, mvicp_ctx** out) try {
   if (!out) { set_error("out is null"); return MVICP_ERR_ARG; }
   *out = nullptr;
   int ndev = 0;
@@ -302,9 +312,9 @@ int mvicp_create(int device, mvicp_ctx** out) {
   MV_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   *out = c;
   return MVICP_OK;
-}
+} MVICP_GUARD_ABI
 
-int mvicp_destroy(mvicp_ctx* c) {
+int mvicp_destroy(mvicp_ctx* c) try {
   if (!c) return MVICP_OK;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
@@ -324,9 +334,9 @@ int mvicp_destroy(mvicp_ctx* c) {
   (void)hipStreamDestroy(c->stream);
   delete c;
   return MVICP_OK;
-}
+} MVICP_GUARD_ABI
 
-int mvicp_set_num_frames(mvicp_ctx* c, int n_frames) {
+int mvicp_set_num_frames(mvicp_ctx* c, int n_frames) try {
   MV_CHECK(bind(c));
   if (n_frames < 0) { set_error("n_frames < 0"); return MVICP_ERR_ARG; }
   if (c->E) free_graph(c);
@@ -334,9 +344,9 @@ int mvicp_set_num_frames(mvicp_ctx* c, int n_frames) {
   c->frames.assign(n_frames, FrameDev());
   c->n_frames = n_frames;
   return MVICP_OK;
-}
+} MVICP_GUARD_ABI
 
-int mvicp_set_frame(mvicp_ctx* c, int frame, const double* xyz, const double* nrm, int n) {
+int mvicp_set_frame(mvicp_ctx* c, int frame, const double* xyz, const double* nrm, int n) try {
   MV_CHECK(bind(c));
   if (frame < 0 || frame >= c->n_frames) { set_error("frame %d out of range [0,%d)", frame, c->n_frames); return MVICP_ERR_ARG; }
   if (n < 0 || (n > 0 && !xyz)) { set_error("bad cloud (n=%d)", n); return MVICP_ERR_ARG; }
@@ -364,9 +374,9 @@ int mvicp_set_frame(mvicp_ctx* c, int frame, const double* xyz, const double* nr
     MV_HIP(hipMemcpy(f.grid.snor, sn.data(), sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice));
   }
   return MVICP_OK;
-}
+} MVICP_GUARD_ABI
 
-int mvicp_recompute_normals(mvicp_ctx* c, int frame, int k, double* nrm_out, int* knn_out) {
+int mvicp_recompute_normals(mvicp_ctx* c, int frame, int k, double* nrm_out, int* knn_out) try {
   MV_CHECK(bind(c));
   if (frame < 0 || frame >= c->n_frames) { set_error("frame %d out of range", frame); return MVICP_ERR_ARG; }
   FrameDev& f = c->frames[frame];
@@ -400,17 +410,17 @@ int mvicp_recompute_normals(mvicp_ctx* c, int frame, int k, double* nrm_out, int
   }
   if (c->profile) prof_collect(c);
   return st;
-}
+} MVICP_GUARD_ABI
 
-int mvicp_set_shard(mvicp_ctx* c, int rank, int world) {
+int mvicp_set_shard(mvicp_ctx* c, int rank, int world) try {
   MV_CHECK(bind(c));
   if (world < 1 || rank < 0 || rank >= world) { set_error("bad shard %d/%d", rank, world); return MVICP_ERR_ARG; }
   if (c->E) { set_error("call mvicp_set_shard before mvicp_set_graph"); return MVICP_ERR_STATE; }
   c->rank = rank; c->world = world;
   return MVICP_OK;
-}
+} MVICP_GUARD_ABI
 
-int mvicp_edge_owner(int n_edges, const int* n_src, int world, int* owner) {
+int mvicp_edge_owner(int n_edges, const int* n_src, int world, int* owner) try {
   if (n_edges < 0 || world < 1 || (n_edges > 0 && (!n_src || !owner))) { set_error("bad arguments"); return MVICP_ERR_ARG; }
   double total = 0, cum = 0;
   for (int e = 0; e < n_edges; ++e) total += n_src[e];
@@ -421,9 +431,9 @@ int mvicp_edge_owner(int n_edges, const int* n_src, int world, int* owner) {
     cum += n;
   }
   return MVICP_OK;
-}
+} MVICP_GUARD_ABI
 
-int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) {
+int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) try {
   MV_CHECK(bind(c));
   if (n_edges < 0 || (n_edges > 0 && (!src || !dst))) { set_error("bad edge list"); return MVICP_ERR_ARG; }
   for (int e = 0; e < n_edges; ++e)
@@ -551,9 +561,9 @@ int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) {
   c->prev_xf.assign((size_t)E * 24, 0.0);
   if (!c->h_census) MV_HIP(hipHostMalloc((void**)&c->h_census, 8 * sizeof(unsigned long long), hipHostMallocDefault));
   return MVICP_OK;
-}
+} MVICP_GUARD_ABI
 
-int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fixed, float thresh, int nn_method, int* counts, float* weights) {
+int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fixed, float thresh, int nn_method, int* counts, float* weights) try {
   MV_CHECK(bind(c));
   if (!poses) { set_error("poses is null"); return MVICP_ERR_ARG; }
   if (c->E == 0) { set_error("no graph: call mvicp_set_graph first"); return MVICP_ERR_STATE; }
@@ -779,9 +789,9 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   mark("host.corr.finish");
   if (c->profile) prof_collect(c);
   return MVICP_OK;
-}
+} MVICP_GUARD_ABI
 
-int mvicp_get_correspondences(mvicp_ctx* c, int edge, int cap, int* first, int* second, double* dist) {
+int mvicp_get_correspondences(mvicp_ctx* c, int edge, int cap, int* first, int* second, double* dist) try {
   MV_CHECK(bind(c));
   if (edge < 0 || edge >= c->E) { set_error("edge %d out of range", edge); return MVICP_ERR_ARG; }
   if (!c->have_corr) { set_error("no correspondences yet"); return MVICP_ERR_STATE; }
@@ -811,9 +821,9 @@ int mvicp_get_correspondences(mvicp_ctx* c, int edge, int cap, int* first, int* 
     if (dist) dist[i] = std::sqrt(d[k]);  // frame.cpp:139 pointDist = sqrt(pointDistSquared), IEEE on the host
   }
   return n;
-}
+} MVICP_GUARD_ABI
 
-int mvicp_set_correspondences(mvicp_ctx* c, int edge, int n, const int* first, const int* second, float weight) {
+int mvicp_set_correspondences(mvicp_ctx* c, int edge, int n, const int* first, const int* second, float weight) try {
   MV_CHECK(bind(c));
   if (edge < 0 || edge >= c->E) { set_error("edge %d out of range", edge); return MVICP_ERR_ARG; }
   if (!c->owned[edge]) { set_error("edge %d is owned by another rank", edge); return MVICP_ERR_STATE; }
@@ -853,9 +863,9 @@ int mvicp_set_correspondences(mvicp_ctx* c, int edge, int n, const int* first, c
   MV_CHECK(launch_gather_stream(c));
   MV_HIP(hipStreamSynchronize(c->stream));
   return MVICP_OK;
-}
+} MVICP_GUARD_ABI
 
-int mvicp_nn_query(mvicp_ctx* c, int frame, const double* queries, int n, int nn_method, int* idx, double* d2) {
+int mvicp_nn_query(mvicp_ctx* c, int frame, const double* queries, int n, int nn_method, int* idx, double* d2) try {
   MV_CHECK(bind(c));
   if (frame < 0 || frame >= c->n_frames) { set_error("frame %d out of range", frame); return MVICP_ERR_ARG; }
   if (n < 0 || (n && (!queries || !idx || !d2))) { set_error("bad query buffers"); return MVICP_ERR_ARG; }
@@ -881,18 +891,18 @@ int mvicp_nn_query(mvicp_ctx* c, int frame, const double* queries, int n, int nn
   dev_free(dq); dev_free(di); dev_free(dd);
   if (c->profile) prof_collect(c);
   return st;
-}
+} MVICP_GUARD_ABI
 
-int mvicp_linearize(mvicp_ctx* c, const double* poses, int point_to_plane, int robust, double* out) {
+int mvicp_linearize(mvicp_ctx* c, const double* poses, int point_to_plane, int robust, double* out) try {
   MV_CHECK(bind(c));
   if (!poses || !out) { set_error("null argument"); return MVICP_ERR_ARG; }
   if (c->E == 0) { set_error("no graph"); return MVICP_ERR_STATE; }
   MV_CHECK(evaluate_blocks(c, poses, point_to_plane, robust, out));
   if (c->profile) prof_collect(c);
   return MVICP_OK;
-}
+} MVICP_GUARD_ABI
 
-int mvicp_set_option(mvicp_ctx* c, const char* name, double value) {
+int mvicp_set_option(mvicp_ctx* c, const char* name, double value) try {
   MV_CHECK(bind(c));
   if (!name) { set_error("null option name"); return MVICP_ERR_ARG; }
   if (std::strcmp(name, "nn_tree_only") == 0) { c->nn_tree_only = value != 0.0; return MVICP_OK; }
@@ -921,29 +931,29 @@ int mvicp_set_option(mvicp_ctx* c, const char* name, double value) {
   }
   set_error("unknown option '%s'", name);
   return MVICP_ERR_ARG;
-}
-int mvicp_nn_census(mvicp_ctx* c, double* out6) {
+} MVICP_GUARD_ABI
+int mvicp_nn_census(mvicp_ctx* c, double* out6) try {
   MV_CHECK(bind(c));
   if (!out6) { set_error("null output"); return MVICP_ERR_ARG; }
   out6[0] = c->nn_queries; out6[1] = c->nn_candidates; out6[2] = c->nn_nodes; out6[3] = c->nn_far; out6[4] = c->nn_hits; out6[5] = c->nn_fetched;
   return MVICP_OK;
-}
+} MVICP_GUARD_ABI
 
-int mvicp_profile_enable(mvicp_ctx* c, int on) {
+int mvicp_profile_enable(mvicp_ctx* c, int on) try {
   MV_CHECK(bind(c));
   c->profile = on != 0;
   c->profile_level = on;
   return MVICP_OK;
-}
-int mvicp_profile_reset(mvicp_ctx* c) {
+} MVICP_GUARD_ABI
+int mvicp_profile_reset(mvicp_ctx* c) try {
   MV_CHECK(bind(c));
   MV_HIP(hipStreamSynchronize(c->stream));
   prof_collect(c);
   for (auto& kv : c->prof) { kv.second.ms = 0; kv.second.launches = 0; kv.second.bytes = 0; }
   c->nn_candidates = c->nn_nodes = c->nn_far = c->nn_queries = c->nn_hits = c->nn_fetched = 0;
   return MVICP_OK;
-}
-int mvicp_profile_get(mvicp_ctx* c, const char* kernel, double* total_ms, long long* launches, double* alg_bytes) {
+} MVICP_GUARD_ABI
+int mvicp_profile_get(mvicp_ctx* c, const char* kernel, double* total_ms, long long* launches, double* alg_bytes) try {
   MV_CHECK(bind(c));
   MV_HIP(hipStreamSynchronize(c->stream));
   prof_collect(c);
@@ -958,12 +968,12 @@ int mvicp_profile_get(mvicp_ctx* c, const char* kernel, double* total_ms, long l
   if (launches) *launches = it->second.launches;
   if (alg_bytes) *alg_bytes = it->second.bytes;
   return MVICP_OK;
-}
+} MVICP_GUARD_ABI
 void* mvicp_stream(mvicp_ctx* c) { return c ? (void*)c->stream : nullptr; }
-int mvicp_sync(mvicp_ctx* c) {
+int mvicp_sync(mvicp_ctx* c) try {
   MV_CHECK(bind(c));
   MV_HIP(hipStreamSynchronize(c->stream));
   return MVICP_OK;
-}
+} MVICP_GUARD_ABI
 
 }  // extern "C"

@@ -117,19 +117,19 @@ int comm_allreduce_host(mvicp_ctx* c, double* h_buf, size_t n) {
 
 using namespace mvicp;
 extern "C" {
-int mvicp_comm_unique_id(const char* librccl_path, void* unique_id_128) {
+int mvicp_comm_unique_id(const char* librccl_path, void* unique_id_128) try {
   if (!unique_id_128) { set_error("null id"); return MVICP_ERR_ARG; }
   return comm_unique_id(librccl_path, unique_id_128);
-}
-int mvicp_comm_set_callback(mvicp_ctx* c, mvicp_allreduce_fn fn, void* user) {
+} MVICP_GUARD_ABI
+int mvicp_comm_set_callback(mvicp_ctx* c, mvicp_allreduce_fn fn, void* user) try {
   if (!c) { set_error("null context"); return MVICP_ERR_ARG; }
   c->ar_fn = fn; c->ar_user = user;
   return MVICP_OK;
-}
-int mvicp_comm_init(mvicp_ctx* c, const char* librccl_path, const void* unique_id_128, int rank, int world) {
+} MVICP_GUARD_ABI
+int mvicp_comm_init(mvicp_ctx* c, const char* librccl_path, const void* unique_id_128, int rank, int world) try {
   if (!c || !unique_id_128) { set_error("null argument"); return MVICP_ERR_ARG; }
   hipError_t e = hipSetDevice(c->device);
   if (e != hipSuccess) { set_error("hipSetDevice failed"); return MVICP_ERR_HIP; }
   return comm_init(c, librccl_path, unique_id_128, rank, world);
-}
+} MVICP_GUARD_ABI
 }

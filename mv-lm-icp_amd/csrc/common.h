@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../include/mvicp.h"
+#include "abi_guard.h"
 
 namespace mvicp {
 

@@ -31,6 +31,7 @@
 #include <cstring>
 #include <limits>
 #include <numeric>
+#include <system_error>
 #include <thread>
 #include <unordered_set>
 
@@ -910,10 +911,13 @@ void kd_split(KdItem* a, long long lo, long long hi, int par) {   // par: levels
     };
     std::nth_element(a + lo, a + mid, a + hi, less);
     if (par > 0 && m > (1 << 15)) {
-      std::thread t(kd_split, a, lo, mid, par - 1);
-      kd_split(a, mid, hi, par - 1);
-      t.join();
-      return;
+      std::thread t;
+      try { t = std::thread(kd_split, a, lo, mid, par - 1); } catch (const std::system_error&) {}   // no thread to be had: do both halves here
+      if (t.joinable()) {
+        kd_split(a, mid, hi, par - 1);
+        t.join();
+        return;
+      }
     }
     // recurse into the smaller part, loop on the larger (bounded stack)
     if (mid - lo < hi - mid) { kd_split(a, lo, mid, 0); lo = mid; }

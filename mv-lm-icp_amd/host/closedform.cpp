@@ -13,6 +13,7 @@
 #include <cstring>
 
 #include "../../include/mvicp.h"
+#include "../csrc/abi_guard.h"
 
 namespace mvicp {
 void set_error(const char* fmt, ...);
@@ -52,7 +53,7 @@ void set_pose(double* P, const double R[3][3], const double t[3]) {
 
 extern "C" {
 
-int mvicp_closedform_point_to_point(const double* src, const double* dst, int n, double* pose_out) {
+int mvicp_closedform_point_to_point(const double* src, const double* dst, int n, double* pose_out) try {
   if (!src || !dst || !pose_out || n < 3) { mvicp::set_error("closedform_point_to_point: need >= 3 pairs and non-null buffers"); return MVICP_ERR_ARG; }
   double pm[3] = {0, 0, 0}, qm[3] = {0, 0, 0};
   for (int i = 0; i < n; ++i) for (int a = 0; a < 3; ++a) { pm[a] += src[3 * (size_t)i + a]; qm[a] += dst[3 * (size_t)i + a]; }
@@ -85,9 +86,9 @@ int mvicp_closedform_point_to_point(const double* src, const double* dst, int n,
   for (int a = 0; a < 3; ++a) t[a] = qm[a] - (R[a][0] * pm[0] + R[a][1] * pm[1] + R[a][2] * pm[2]);
   set_pose(pose_out, R, t);
   return MVICP_OK;
-}
+} MVICP_GUARD_ABI
 
-int mvicp_closedform_point_to_plane(const double* src, const double* dst, const double* nor, int n, double* pose_out) {
+int mvicp_closedform_point_to_plane(const double* src, const double* dst, const double* nor, int n, double* pose_out) try {
   if (!src || !dst || !nor || !pose_out || n < 6) { mvicp::set_error("closedform_point_to_plane: need >= 6 pairs and non-null buffers"); return MVICP_ERR_ARG; }
   double C[6][6], d[6];
   for (int i = 0; i < 6; ++i) { d[i] = 0.0; for (int j = 0; j < 6; ++j) C[i][j] = 0.0; }
@@ -122,6 +123,6 @@ int mvicp_closedform_point_to_plane(const double* src, const double* dst, const 
   const double t[3] = {x[3], x[4], x[5]};
   set_pose(pose_out, R, t);
   return MVICP_OK;
-}
+} MVICP_GUARD_ABI
 
 }  // extern "C"

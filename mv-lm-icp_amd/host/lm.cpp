@@ -301,12 +301,12 @@ int ctx_eval(void* user, const double* poses, double* blocks) {
 extern "C" {
 
 int mvicp_lm_solve(int n_frames, int n_edges, const int* src, const int* dst, double* poses, unsigned char* fixed, int param, int max_iterations,
-                   mvicp_eval_fn eval, void* user, mvicp_summary* summary) {
+                   mvicp_eval_fn eval, void* user, mvicp_summary* summary) try {
   return lm_solve(n_frames, n_edges, src, dst, poses, fixed, param, max_iterations, eval, user, summary);
-}
+} MVICP_GUARD_ABI
 
 int mvicp_optimize(mvicp_ctx* c, double* poses, unsigned char* fixed, int param, int point_to_plane, int robust, int max_iterations,
-                   mvicp_summary* summary) {
+                   mvicp_summary* summary) try {
   if (!c) { set_error("null context"); return MVICP_ERR_ARG; }
   hipError_t e = hipSetDevice(c->device);
   if (e != hipSuccess) { set_error("hipSetDevice: %s", hipGetErrorString(e)); return MVICP_ERR_HIP; }
@@ -323,6 +323,6 @@ int mvicp_optimize(mvicp_ctx* c, double* poses, unsigned char* fixed, int param,
   }
   if (c->profile) prof_collect(c);
   return st;
-}
+} MVICP_GUARD_ABI
 
 }  // extern "C"
