@@ -492,12 +492,32 @@ struct Summary {
 
 // Ceres TrustRegionMinimizer + LevenbergMarquardtStrategy with the options of icp-ceres.cpp:66-89
 // (getOptionsMedium: max_num_iterations 50; everything else default) [upstream].
+//
+// Schedule-sensitivity knobs (tests/test_oracle_lm.py::test_schedule_sensitivity_*): Ceres is absent from this image, so nothing can
+// prove that the loop below matches the real trust-region schedule in every detail.  What CAN be measured is how far the converged
+// poses move if it does not: every constant / rule that is [upstream] knowledge can be perturbed through orc_set_lm_options and the
+// 20-round registration re-run.  Defaults = Ceres defaults as used by icp-ceres.cpp:66-95.
+struct LmOptions {
+  double initial_radius = 1e4;           // Solver::Options::initial_trust_region_radius
+  double min_relative_decrease = 1e-3;   // Solver::Options::min_relative_decrease
+  double function_tolerance = 1e-6;
+  double parameter_tolerance = 1e-8;
+  double gradient_tolerance = 1e-10;
+  int jacobi_scaling = 1;                // Solver::Options::jacobi_scaling
+  int radius_rule = 0;                   // 0: radius /= max(1/3, 1 - (2 rho - 1)^3) (levenberg_marquardt_strategy.cc StepAccepted);
+                                         // 1: radius *= 3 on every accepted step (the rule's upper envelope); 2: radius unchanged on accept
+  int legacy_minimizer = 0;              // 1: pre-1.12 control flow — the step that meets the function tolerance is TAKEN before stopping
+                                         //    (the 1.12+ TrustRegionMinimizer returns without taking it)
+  double min_diag = 1e-6;                // Solver::Options::min_lm_diagonal
+};
+static LmOptions g_lm;
+
 static void lm_solve(const Problem& pb, double* x /* K x ambient, in/out */, int max_iterations, Summary* sm) {
-  const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
-  const double max_radius = 1e16, min_radius = 1e-32, min_relative_decrease = 1e-3;
-  const double min_diag = 1e-6, max_diag = 1e32;
+  const double function_tolerance = g_lm.function_tolerance, gradient_tolerance = g_lm.gradient_tolerance, parameter_tolerance = g_lm.parameter_tolerance;
+  const double max_radius = 1e16, min_radius = 1e-32, min_relative_decrease = g_lm.min_relative_decrease;
+  const double min_diag = g_lm.min_diag, max_diag = 1e32;
   const int max_invalid = 5;
-  double radius = 1e4, decrease_factor = 2.0;
+  double radius = g_lm.initial_radius, decrease_factor = 2.0;
   bool reuse_diagonal = false;
   int consecutive_invalid = 0;
 
@@ -514,7 +534,7 @@ static void lm_solve(const Problem& pb, double* x /* K x ambient, in/out */, int
   sm->initial_cost = cost;
   double x_norm = xnorm(x);
   double gmax = 0; for (int i = 0; i < n; ++i) gmax = std::max(gmax, std::fabs(g[i]));
-  for (int i = 0; i < n; ++i) scale[i] = 1.0 / (1.0 + std::sqrt(H[(size_t)i * n + i]));  // jacobi_scaling, computed once
+  for (int i = 0; i < n; ++i) scale[i] = g_lm.jacobi_scaling ? 1.0 / (1.0 + std::sqrt(H[(size_t)i * n + i])) : 1.0;  // jacobi_scaling, computed once
   auto rescale = [&]() {
     for (int i = 0; i < n; ++i) { gs[i] = g[i] * scale[i]; for (int j = 0; j < n; ++j) Hs[(size_t)i * n + j] = H[(size_t)i * n + j] * scale[i] * scale[j]; }
   };
@@ -566,8 +586,10 @@ static void lm_solve(const Problem& pb, double* x /* K x ambient, in/out */, int
     if (trace) std::fprintf(stderr, "[orc lm] it %d cost %.6e cand %.6e step_norm %.3e x_norm %.3e radius %.3e model_change %.3e\n", iter, cost, cand_cost, step_norm, x_norm, radius, model_cost_change);
     if (step_norm <= parameter_tolerance * (x_norm + parameter_tolerance)) { sm->termination = 2; break; }
     const double cost_change = cost - cand_cost;
-    if (std::fabs(cost_change) <= function_tolerance * cost) { sm->termination = 3; break; }
+    const bool ftol = std::fabs(cost_change) <= function_tolerance * cost;
+    if (ftol && !g_lm.legacy_minimizer) { sm->termination = 3; break; }
     const double relative_decrease = cost_change / model_cost_change;
+    if (ftol && !(relative_decrease > min_relative_decrease)) { sm->termination = 3; break; }   // (legacy flow: a rejected step that meets the tolerance still stops)
     if (relative_decrease > min_relative_decrease) {
       std::memcpy(x, xc.data(), sizeof(double) * (size_t)K * A);
       x_norm = xnorm(x);
@@ -576,12 +598,14 @@ static void lm_solve(const Problem& pb, double* x /* K x ambient, in/out */, int
       sm->successful_steps++;
       gmax = 0; for (int i = 0; i < n; ++i) gmax = std::max(gmax, std::fabs(g[i]));
       rescale();
-      radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * relative_decrease - 1.0, 3));
+      if (g_lm.radius_rule == 0) radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * relative_decrease - 1.0, 3));
+      else if (g_lm.radius_rule == 1) radius *= 3.0;
       radius = std::min(max_radius, radius);
       decrease_factor = 2.0;
       reuse_diagonal = false;
       sm->final_cost = cost;
       if (gmax <= gradient_tolerance) { sm->termination = 1; break; }
+      if (ftol) { sm->termination = 3; break; }   // legacy flow only (ftol && !legacy never reaches this point)
     } else {
       radius /= decrease_factor; decrease_factor *= 2.0;
       if (radius < min_radius) { sm->termination = 4; break; }
@@ -629,6 +653,21 @@ double orc_evaluate_x(const orc_problem* p, const double* x, double* H, double* 
   Problem pb = to_problem(p);
   Evaluator ev(pb);
   return ev.evaluate(x, H, g);
+}
+
+// Perturb the LM schedule (sensitivity tests only).  v = {initial_radius, min_relative_decrease, function_tolerance, parameter_tolerance,
+// jacobi_scaling, radius_rule, legacy_minimizer, min_diag, gradient_tolerance}; n = how many leading entries are given; n = 0 restores the defaults.
+void orc_set_lm_options(const double* v, int n) {
+  g_lm = LmOptions();
+  if (n > 0) g_lm.initial_radius = v[0];
+  if (n > 1) g_lm.min_relative_decrease = v[1];
+  if (n > 2) g_lm.function_tolerance = v[2];
+  if (n > 3) g_lm.parameter_tolerance = v[3];
+  if (n > 4) g_lm.jacobi_scaling = v[4] != 0.0;
+  if (n > 5) g_lm.radius_rule = (int)v[5];
+  if (n > 6) g_lm.legacy_minimizer = v[6] != 0.0;
+  if (n > 7) g_lm.min_diag = v[7];
+  if (n > 8) g_lm.gradient_tolerance = v[8];
 }
 
 struct orc_summary { double initial_cost, final_cost; int iterations, successful_steps, termination, jacobian_evals, cost_evals; };

@@ -135,6 +135,21 @@ class Oracle:
     def ambient(self, param):
         return self.lib.orc_ambient(param)
 
+    LM_OPTION_ORDER = ("initial_radius", "min_relative_decrease", "function_tolerance", "parameter_tolerance", "jacobi_scaling", "radius_rule",
+                       "legacy_minimizer", "min_diag", "gradient_tolerance")
+    LM_DEFAULTS = {"initial_radius": 1e4, "min_relative_decrease": 1e-3, "function_tolerance": 1e-6, "parameter_tolerance": 1e-8, "jacobi_scaling": 1,
+                   "radius_rule": 0, "legacy_minimizer": 0, "min_diag": 1e-6, "gradient_tolerance": 1e-10}
+
+    def set_lm_options(self, **kw):
+        """Perturb the oracle's trust-region schedule (sensitivity tests only); no arguments = Ceres defaults."""
+        unknown = set(kw) - set(self.LM_OPTION_ORDER)
+        assert not unknown, unknown
+        if not kw:
+            self.lib.orc_set_lm_options(None, C.c_int(0))
+            return
+        v = np.array([float(kw.get(k, self.LM_DEFAULTS[k])) for k in self.LM_OPTION_ORDER], dtype=np.float64)
+        self.lib.orc_set_lm_options(_p(v), C.c_int(len(v)))
+
     def pose_to_param(self, param, pose):
         x = np.zeros(self.ambient(param))
         P = to_c([pose])[0]

@@ -164,6 +164,68 @@ def test_pairwise_known_answer_reference_inputs(orc, param, plane):
     assert sm["termination"] == 2 and 5 <= sm["iterations"] <= 10, sm
     assert dt <= 1e-9 and dr_deg <= 2e-6, (param, plane, dt, dr_deg)
     assert synth.pose_diff(P, Pout[1])[1] <= 3e-9   # radians, atan2 form (no acos floor)
+    # the value this restatement actually reaches is recorded in the golden (3.2e-10 / 4.0e-10 / 8.2e-10 point-to-point, 5.1e-11 / 6.6e-11 /
+    # 1.6e-10 point-to-plane): a drift towards the 1e-9 bar shows up here long before the bar itself fails
+    assert dt <= 1.25 * K["reached_dt"][plane, param] + 1e-13 and sm["iterations"] == K["reached_iters"][plane, param], (param, plane, dt, sm)
+
+
+# ---------------------------------------------------------------- how much could an unpinned detail of Ceres' schedule matter?
+def _registration(orc, ref, pb, param, rounds=20):
+    import cpupath
+    cp = cpupath.CpuPath(pb["pts"], pb["nor"], pb["src"], pb["dst"], pb["fixed"], param, 1, orc=orc, ref=ref)
+    P = pb["init"].copy()
+    its = []
+    for _ in range(rounds):
+        P, sm = cp.round(P)
+        its.append(sm["iterations"])
+    cp.close()
+    return P, sm["final_cost"], its
+
+
+def test_schedule_sensitivity_of_the_20_round_registration(orc, refnn):
+    """VERDICT r2 item 3.  Ceres is not installed, so the trust-region schedule of oracle.cpp / host/lm.cpp is restated from upstream
+    and pinned to nothing.  This bounds what a wrong detail could do to the reference's whole loop (main_multiview.cpp:150-169: 20
+    rounds) on a reduced config 3 (8 views, angle-axis, point-to-plane, robust).  Measured (tools/schedule_sensitivity.py,
+    profiles/r03_schedule_sensitivity.txt):
+      * min_relative_decrease x/÷ 10, Jacobi scaling off, min_lm_diagonal, parameter_tolerance, a x3 radius rule: final poses move by
+        0 .. 1e-14 — the solve never rejects a step here and Marquardt's diag(J^T J) damping is scale-invariant;
+      * initial radius x/÷ 10, function_tolerance ÷ 2, a frozen radius, or the pre-1.12 control flow (the tolerance-meeting step is
+        taken): 4e-5 .. 4e-4 m / rad.  NOT within north_star's 1e-5: every solve stops on `|cost change| <= 1e-6 cost`, the outer loop
+        stalls as soon as the first candidate of a round meets that, so the registration's set of fixed points is a basin of that
+        diameter on this weakly constrained scene (all end states agree in cost to ~1.5e-3 relative).
+    Consequence stated in DESIGN.md §6: GPU-vs-CPU-path parity (1e-8) holds because both sides run the SAME restated schedule; parity
+    with a real Ceres build to 1e-5 additionally needs initial radius, function tolerance and control flow to be Ceres' — they are
+    upstream's documented defaults, but only a Ceres-linked run could confirm it.  The well-conditioned pairwise KAT is immune
+    (every variant <= 5e-9 m, see the profile)."""
+    pb = synth.make_problem(8, 1500)
+    P0, c0, its0 = _registration(orc, refnn, pb, orclib.PARAM_ANGLEAXIS)
+    dev = {}
+    try:
+        for name, kw in (("min_relative_decrease", {"min_relative_decrease": 1e-2}), ("jacobi_scaling", {"jacobi_scaling": 0}),
+                         ("radius_x3", {"radius_rule": 1}),
+                         ("initial_radius", {"initial_radius": 1e3}), ("function_tolerance", {"function_tolerance": 5e-7}),
+                         ("legacy_flow", {"legacy_minimizer": 1})):
+            orc.set_lm_options(**kw)
+            P, c, its = _registration(orc, refnn, pb, orclib.PARAM_ANGLEAXIS)
+            dev[name] = (max(max(synth.pose_diff(P[k], P0[k])) for k in range(8)), abs(c - c0) / c0, its)
+    finally:
+        orc.set_lm_options()
+    print(dev)
+    for name in ("min_relative_decrease", "jacobi_scaling", "radius_x3"):
+        assert dev[name][0] <= 1e-9, (name, dev[name])
+    for name in ("initial_radius", "function_tolerance", "legacy_flow"):
+        assert dev[name][0] <= 2e-3 and dev[name][1] <= 1e-2, (name, dev[name])   # bounded by the function-tolerance basin, not by 1e-5
+
+
+def test_lm_options_default_restores_the_pinned_schedule(orc):
+    """orc_set_lm_options with no arguments = the schedule every other test is pinned on."""
+    pb, prob = small_problem(orc, orclib.PARAM_SOPHUS, 1, 1)
+    a, sa = orc.optimize(prob, pb["init"], 50)
+    orc.set_lm_options(initial_radius=10.0)
+    b, sb = orc.optimize(prob, pb["init"], 50)
+    orc.set_lm_options()
+    c, sc = orc.optimize(prob, pb["init"], 50)
+    assert np.array_equal(a, c) and sa == sc and not np.array_equal(a, b)
 
 
 def test_closed_form_point_to_point_is_kabsch():
