@@ -3,11 +3,16 @@
 
 One "step" = one outer ICP iteration = the loop body of the reference's src/main_multiview.cpp:150-169 without
 visualisation: correspondence search over all E edges (NN + cutoff + median) followed by one LM solve (<= 50 iterations;
-one device linearization per LM iteration + the host solve).  The timed rounds are rounds warmup+1 .. warmup+steps of ONE
-registration that starts from the noisy initial poses, so how many of them still move the poses depends on --warmup/--steps:
-the JSON line reports the two regimes separately (`regimes`) next to `value` (all timed rounds).
+one device linearization per LM iteration + the host solve).  The reference program IS 20 such rounds from the noisy initial
+poses (main_multiview.cpp:150), so the rounds of this bench walk through that registration again and again: global round g
+(warm-up first, then timed) is round g mod 20 + 1 of registration g div 20 + 1; every registration starts from the same noisy
+initial poses (the reference's noise generator is default-seeded: every run of the program draws the same poses) after
+mvicp_reset_history() has dropped everything the library remembers (NN cache, seeds, lists, medians, AUTO state) — inside
+the timed region when it falls there.  With the driver's `--warmup 5 --steps 20` the timed window is rounds 6-20 of
+registration 1 and rounds 1-5 of registration 2: each of the reference's 20 rounds exactly once.  `regimes` splits the timed
+rounds by whether the LM solve still moved the poses.
 
-    python bench.py [--gpus N --steps K --warmup W] [--workload cfg2|cfg3|cfg4|cfg5|tiny|shard8]
+    python bench.py [--gpus N --steps K --warmup W] [--workload cfg2|cfg3|cfg4|cfg5|tiny|shard8|shard8_cfg5]
 
 N > 1: launched by torch.distributed.run, one rank per GPU; edges are sharded across ranks and the per-edge normal-equation
 blocks are summed with an RCCL all-reduce per LM evaluation (strong scaling: the problem is fixed).  Rank 0 prints ONE JSON line.
@@ -33,9 +38,11 @@ WORKLOADS = {
     "cfg4": (32, 200_000, 1, 2, "cfg4: multiview 32 views x 200k pts, point-to-plane, SophusSE3 (E=62)"),
     "cfg5": (64, 1_000_000, 1, 2, "cfg5: multiview 64 views x 1M pts, point-to-plane, SophusSE3 (E=126)"),
     "shard8": (5, 200_000, 1, 2, "shard8: 5 views x 200k pts (E=8): the per-rank share of cfg4 on 8 GPUs, for fixed-cost analysis"),
+    "shard8_cfg5": (9, 1_000_000, 1, 2, "shard8_cfg5: 9 views x 1M pts (E=16): the per-rank share of cfg5 on 8 GPUs, for fixed-cost analysis"),
 }
+ROUNDS_PER_REGISTRATION = 20   # main_multiview.cpp:150
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 
 def source_sha16():
@@ -52,129 +59,99 @@ def source_sha16():
     return h.hexdigest()[:16]
 
 
-def cpu_features():
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("flags"):
-                return set(line.split(":", 1)[1].split())
-    except OSError:
-        pass
-    return set()
+def cpu_reference_legs(pb, plane, param, gpu_poses_after, gpu_iters, window_rounds, moved_by_round, cpu_rounds):
+    """The two CPU legs of the line, both on tests/cpupath.py = the reference-equivalent CPU path (real vendored nanoflann from
+    oracle/_ref + the oracle's Jet/autodiff restatement of Ceres; Ceres itself is not installed).  Run AFTER the timed region.
 
-
-def cpu_baseline(pb, plane, param, n_edges_full, round_poses, moved, sample_views=3):
-    """Reference-equivalent CPU path timed on a bounded sample of the SAME workload and the SAME rounds: the first `sample_views`
-    views (their edges), started from the poses the GPU run had at the beginning of (a) its first timed round that moved the poses
-    and (b) its last timed round; per-round time = NN for the sample's edges (real vendored nanoflann, oracle/_ref) + one LM solve
-    (the oracle's Jet/autodiff restatement of Ceres; Ceres itself is not installed), scaled by the edge count and weighted by how
-    many timed rounds were of each kind.  Variants: -O2 single thread (the reference's build: CMakeLists.txt:14-22, Ceres
-    num_threads 1), -O3 AVX2 single thread, -O3 AVX2 + OpenMP on every core."""
-    import ctypes as C
-    import orclib
-    Ks = min(sample_views, len(pb["pts"]))
-    keep = [e for e, (s, d) in enumerate(zip(pb["src"], pb["dst"])) if s < Ks and d < Ks]
-    src = pb["src"][keep]; dst = pb["dst"][keep]
-    pts, nor = pb["pts"][:Ks], pb["nor"][:Ks]
-    fixed = pb["fixed"][:Ks]
-    moving_rounds = [r for r, m in enumerate(moved) if m]
-    fixed_rounds = [r for r, m in enumerate(moved) if not m]
-    samples = {}
-    if moving_rounds:
-        samples["moving"] = moving_rounds[0]
-    if fixed_rounds:
-        samples["fixed_point"] = fixed_rounds[-1]
-
-    def load_variant(fast):
-        osuf = "_fast" if fast else ""
-        orc_so = os.path.join(ROOT, "oracle", "_build", f"liborc{osuf}.so")
-        ref_so = os.path.join(ROOT, "oracle", "_ref", f"libref_nanoflann{osuf}.so")
-        if not os.path.exists(orc_so):
-            return None
-        orc = orclib.Oracle(C.CDLL(orc_so))
-        ref = orclib.RefNN(C.CDLL(ref_so)) if os.path.exists(ref_so) else None
-        return orc, ref
-
-    def one_round(orc, ref, poses0):
-        t0 = time.perf_counter()
-        corr, w = [], []
-        for s, d in zip(src, dst):
-            if ref is not None:
-                q = orc.query_transform(poses0[s], poses0[d], pts[s])
-                idx = np.empty(len(q), dtype=np.int32); d2 = np.empty(len(q), dtype=np.float64)
-                ref.lib.ref_nn_query(trees[d], q.ctypes.data_as(C.c_void_p), C.c_int(len(q)), idx.ctypes.data_as(C.c_void_p), d2.ctypes.data_as(C.c_void_p))
-                f, sec, dist, wt = orc.filter_median(idx, d2, 0.05)
-            else:
-                f, sec, dist, wt, _, _ = orc.correspond_edge(pts[s], poses0[s], pts[d], poses0[d], 0.05)
-            corr.append((f, sec)); w.append(wt)
-        t1 = time.perf_counter()
-        prob = orc.make_problem(pts, nor, fixed, src, dst, corr, w, param, plane, 1)
-        _, sm = orc.optimize(prob, poses0, 50)
-        t2 = time.perf_counter()
-        return t1 - t0, t2 - t1, sm["iterations"]
-
-    feats = cpu_features()
-    fast_ok = {"avx2", "fma", "bmi2"} <= feats
-    # cores this process may really use: affinity mask and cgroup CPU quota (a container often shows every host core in cpu_count())
-    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if q != "max":
-            ncores = max(1, min(ncores, int(float(q) / float(per))))
-    except (OSError, ValueError):
-        pass
-    ncores = min(ncores, 64)   # the sample is 3 edges x 200k queries: more threads than that only add fork/join cost
+    (1) `pose_diff_vs_cpu_path` (SURVEY.md §8(d) secondary metric) and the all-cores CPU timing: the CPU path walks rounds
+        1..cpu_rounds of the SAME registration from the same noisy initial poses on ALL edges (its own trajectory: its own
+        correspondences, its own solves), -O3 AVX2 + OpenMP on every usable core; after every round its poses are compared with the
+        GPU run's poses after the same round, and its LM iteration count is listed next to the GPU's.
+    (2) `cpu_baseline.value` = the reference's own build and threading (-O2, 1 thread; CMakeLists.txt:14-22, Ceres num_threads 1):
+        too slow for all edges inside a bench run, so a bounded sample — the first 3 views' edges, one moving round (round 2, started
+        from the GPU run's poses) and one fixed-point round (the last compared round) — scaled by edge count.
+    Both are weighted over the rounds of the timed window: a window round r <= cpu_rounds uses the measured round r, later rounds (all
+    fixed-point rounds) use the last measured fixed-point round."""
+    import cpupath
+    K = len(pb["pts"])
+    E = len(pb["src"])
+    ncores = cpupath.usable_cores(64)
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
-    try:
-        gomp = C.CDLL("libgomp.so.1")
-    except OSError:
-        gomp = None
-    variants = [("O2_1thread", False, 1)]
-    if fast_ok and gomp is not None:
-        variants += [("O3_avx2_1thread", True, 1), ("O3_avx2_allcores", True, ncores)]
-    scale = n_edges_full / max(1, len(keep))
-    out_var = {}
-    tree_build_s = None
-    for name, fast, threads in variants:
-        lv = load_variant(fast)
-        if lv is None:
-            continue
-        orc, ref = lv
-        if gomp is not None:
-            gomp.omp_set_num_threads(C.c_int(threads))
-        trees = {}
-        tb = time.perf_counter()
-        if ref is not None:
-            ref.lib.ref_nn_build.restype = C.c_void_p
-            for d in sorted(set(dst.tolist())):
-                p = np.ascontiguousarray(pts[d])
-                trees[d] = C.c_void_p(ref.lib.ref_nn_build(p.ctypes.data_as(C.c_void_p), C.c_int(len(p))))
-        if tree_build_s is None:
-            tree_build_s = time.perf_counter() - tb
-        per_kind = {}
-        for kind, r in samples.items():
-            nn_s, lm_s, iters = one_round(orc, ref, np.ascontiguousarray(round_poses[r][:Ks]))
-            per_kind[kind] = {"round": r, "nn_s_sample": nn_s, "lm_s_sample": lm_s, "lm_iterations": iters, "s_per_round_full": (nn_s + lm_s) * scale}
-        if ref is not None:
-            for h in trees.values():
-                ref.lib.ref_nn_free(h)
-        n_m, n_f = len(moving_rounds), len(fixed_rounds)
+    out = {}
+    per_round = []
+    fast = cpupath.fast_build_usable()
+    # ---- (1) all edges, every usable core
+    cp = cpupath.CpuPath(pb["pts"], pb["nor"], pb["src"], pb["dst"], pb["fixed"], param, plane, fast=fast, threads=ncores)
+    P = pb["init"].copy()
+    dev_t, dev_r = [], []
+    for r in range(cpu_rounds):
+        P, sm = cp.round(P)
+        dts = [synth_pose_diff(P[k], gpu_poses_after[r][k]) for k in range(K)]
+        dev_t.append(max(d[0] for d in dts)); dev_r.append(max(d[1] for d in dts))
+        per_round.append({"round": r + 1, "nn_s": cp.last["nn_s"], "lm_s": cp.last["lm_s"], "lm_iterations_cpu": sm["iterations"], "lm_iterations_gpu": gpu_iters[r],
+                          "moved": sm["successful_steps"] > 0, "correspondences": int(cp.last["counts"].sum())})
+    tree_build_s = cp.tree_build_s
+    cp.close()
+    out["pose_diff_vs_cpu_path"] = {
+        "rounds_compared": cpu_rounds, "max_translation_m": max(dev_t), "max_rotation_rad": max(dev_r),
+        "per_round_max_translation_m": dev_t, "per_round_max_rotation_rad": dev_r,
+        "lm_iterations_gpu": [p["lm_iterations_gpu"] for p in per_round], "lm_iterations_cpu": [p["lm_iterations_cpu"] for p in per_round],
+        "note": ("GPU path vs the reference-equivalent CPU path (real nanoflann + oracle LM, all edges), each on its own trajectory from the same noisy initial "
+                 "poses, compared after each of the first rounds of the registration; target 1e-5 m / rad.  The CPU path's LM is a restatement of Ceres "
+                 "(parity unpinned: Ceres is not installed), see DESIGN.md section 6")}
+
+    def window_rate(sec_of_round):
         tot = 0.0
-        for kind, n in (("moving", n_m), ("fixed_point", n_f)):
-            if n:
-                tot += n * per_kind[kind]["s_per_round_full"]
-        s_per_round = tot / max(1, n_m + n_f)
-        out_var[name] = {"value": 1.0 / s_per_round, "unit": "iterations/s", "cores": threads, "s_per_round": s_per_round, "by_regime": per_kind}
-    base = out_var["O2_1thread"]
-    return {
+        for r in window_rounds:                       # r = 1-based round index inside its registration
+            tot += sec_of_round(r)
+        return len(window_rounds) / tot, tot / len(window_rounds)
+
+    fixed_meas = [p for p in per_round if not p["moved"]]
+    last_fixed = fixed_meas[-1] if fixed_meas else per_round[-1]
+
+    def sec_all(r):
+        p = per_round[r - 1] if r <= len(per_round) else last_fixed
+        return p["nn_s"] + p["lm_s"]
+
+    rate_all, spr_all = window_rate(sec_all)
+    variants = {("O3_avx2_allcores" if fast else "O2_threadpool_nn"): {
+        "value": rate_all, "unit": "iterations/s", "cores": ncores, "s_per_round": spr_all, "edges": E, "sample": "ALL edges, rounds 1..%d measured one by one" % cpu_rounds,
+        "per_round": per_round, "tree_build_s_once": tree_build_s}}
+    # ---- (2) the reference's build and threading on a bounded sample
+    Ks = min(3, K)
+    keep = [e for e, (s_, d_) in enumerate(zip(pb["src"], pb["dst"])) if s_ < Ks and d_ < Ks]
+    scale = E / max(1, len(keep))
+    r_mov = 2 if cpu_rounds >= 2 and per_round[1]["moved"] else 1
+    r_fix = last_fixed["round"]
+    starts = {"moving": (r_mov, pb["init"] if r_mov == 1 else gpu_poses_after[r_mov - 2]), "fixed_point": (r_fix, pb["init"] if r_fix == 1 else gpu_poses_after[r_fix - 2])}
+    for name, use_fast in (("O2_1thread", False),) + ((("O3_avx2_1thread", True),) if fast else ()):
+        c1 = cpupath.CpuPath(pb["pts"][:Ks], pb["nor"][:Ks], pb["src"][keep], pb["dst"][keep], pb["fixed"][:Ks], param, plane, fast=use_fast, threads=1)
+        c1.correspond(np.ascontiguousarray(pb["init"][:Ks]))   # build the trees outside the timed rounds
+        kinds = {}
+        for kind, (r, P0) in starts.items():
+            _, sm = c1.round(np.ascontiguousarray(P0[:Ks]))
+            kinds[kind] = {"round": r, "nn_s_sample": c1.last["nn_s"], "lm_s_sample": c1.last["lm_s"], "lm_iterations": sm["iterations"],
+                           "s_per_round_full": (c1.last["nn_s"] + c1.last["lm_s"]) * scale}
+        c1.close()
+        rate, spr = window_rate(lambda r: kinds["moving" if (r <= len(moved_by_round) and moved_by_round[r - 1]) else "fixed_point"]["s_per_round_full"])
+        variants[name] = {"value": rate, "unit": "iterations/s", "cores": 1, "s_per_round": spr, "by_regime": kinds,
+                          "sample": f"first {Ks} views ({len(keep)} of {E} edges), scaled x{scale:.2f}"}
+    base = variants["O2_1thread"]
+    out["cpu_baseline"] = {
         "value": base["value"], "unit": "iterations/s", "cores": 1, "kind": "port",
-        "sample": (f"first {Ks} views of the same clouds ({len(keep)} of {n_edges_full} edges, N={len(pts[0])}); started from the GPU run's poses at the "
-                   f"start of timed round {samples.get('moving', '-')} (first timed round that moved the poses) and of timed round {samples.get('fixed_point', '-')} "
-                   f"(last timed round, poses stationary); each = NN of the sample's edges (real vendored nanoflann, oracle/_ref) + one LM solve (oracle "
-                   f"Jet/autodiff restatement of Ceres; Ceres is not installed); scaled x{scale:.2f} by edge count and weighted {len(moving_rounds)} moving : "
-                   f"{len(fixed_rounds)} stationary rounds like the timed GPU window.  value = -O2, 1 thread (the reference's build and threading)"),
-        "variants": out_var, "tree_build_s_sample": tree_build_s, "host_cores": ncores,
+        "sample": (f"reference-equivalent CPU path (real vendored nanoflann + oracle Jet/LM restatement of Ceres; Ceres is not installed).  value = -O2, 1 thread (the "
+                   f"reference's build and threading) on the first {Ks} views ({len(keep)} of {E} edges, N={len(pb['pts'][0])}): one moving round (round {r_mov}) and one "
+                   f"fixed-point round (round {r_fix}) started from the GPU run's poses, scaled x{scale:.2f} by edge count and weighted over the rounds of the timed window.  "
+                   f"variants.{'O3_avx2_allcores' if fast else 'O2_threadpool_nn'} = ALL {E} edges, rounds 1..{cpu_rounds} of the registration measured one by one on {ncores} cores"),
+        "variants": variants, "host_cores": ncores,
         "fast_build_note": "-O3 -march=x86-64-v3 (AVX2/FMA, portable stand-in for -march=native: the .so is built off-box), -ffp-contract=off; all-cores = OpenMP over correspondences / queries",
     }
+    return out
+
+
+def synth_pose_diff(A, B):
+    from mvicp import synth
+    return synth.pose_diff(A, B)
 
 
 def main():
@@ -185,6 +162,7 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("MVICP_WORKLOAD", "cfg4"))
     ap.add_argument("--nn", default="auto", choices=["auto", "brute", "grid", "tile"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rounds", type=int, default=None, help="rounds of the registration the CPU reference path walks after the timed region (default 8; 2 for cfg5-sized problems)")
     ap.add_argument("--no-replay", action="store_true", help="skip the untimed census replay pass (profiling runs: keeps the kernel trace to the timed protocol)")
     ap.add_argument("--allow-host-exchange", action="store_true", help="N > 1 only: if the RCCL communicator cannot be created, fall back to a host-staged gloo all-reduce instead of failing")
     ap.add_argument("--grid-target", type=float, default=None)
@@ -257,19 +235,32 @@ def main():
 
     poses = pb["init"].copy()
     log = []
-    round_poses = []
+    state = {"g": 0}              # global round counter (warm-up + timed): round g % 20 + 1 of registration g // 20 + 1
+    poses_after = {}              # registration 1 only: poses after round r (1-based), for the CPU-path comparison
+    iters_of = {}
 
     def step():
         nonlocal poses
-        before = poses
-        round_poses.append(before)
+        g = state["g"]
+        reg, rnd = divmod(g, ROUNDS_PER_REGISTRATION)
         t0 = time.perf_counter()
+        if rnd == 0 and g > 0:
+            # a new run of the reference program on the same clouds: same noisy initial poses (default-seeded noise), no memory of the last run
+            eng.reset_history()
+            poses = pb["init"].copy()
+        before = poses
         counts, weights = eng.correspond(poses, pb["fixed"], 0.05, method)
         t1 = time.perf_counter()
         poses, sm = eng.optimize(poses, pb["fixed"], param, plane, True, 50)
         t2 = time.perf_counter()
-        log.append({"nn_ms": (t1 - t0) * 1e3, "lm_ms": (t2 - t1) * 1e3, "lm_iters": sm["iterations"], "evals": sm["evaluations"], "corr": int(counts.sum()),
-                    "steps_taken": sm["successful_steps"], "moved": sm["successful_steps"] > 0, "poses_bit_identical": bool(np.array_equal(before, poses))})
+        log.append({"registration": reg + 1, "round": rnd + 1, "nn_ms": (t1 - t0) * 1e3, "lm_ms": (t2 - t1) * 1e3, "lm_iters": sm["iterations"], "evals": sm["evaluations"],
+                    "corr": int(counts.sum()), "steps_taken": sm["successful_steps"], "moved": sm["successful_steps"] > 0,
+                    "poses_bit_identical": bool(np.array_equal(before, poses))})
+        if reg == 0:
+            poses_after[rnd + 1] = poses.copy(); iters_of[rnd + 1] = sm["iterations"]
+        elif rnd + 1 in poses_after and not np.array_equal(poses_after[rnd + 1], poses):
+            state["replay_mismatch"] = True      # a later registration must retrace registration 1 bit for bit
+        state["g"] = g + 1
 
     def fence():
         if world > 1:
@@ -279,30 +270,31 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    eng.profile(2)   # live HIP-event scopes around the two roofline kernels only ("nn", "linearize"); everything else: replay pass below
+    eng.profile(2)   # live HIP-event scopes around the two roofline kernels only ("nn", "linearize") + the collective; everything else: replay pass below
     eng.profile_reset()
-    log.clear(); round_poses.clear()
+    log.clear()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    local_elapsed = elapsed
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    timed = {k: eng.profile_get(k) for k in ("nn", "linearize")}
+    timed = {k: eng.profile_get(k) for k in ("nn", "linearize", "comm")}
     spec_hits = eng.profile_get("spec.hit")[1]
     host = {k: eng.profile_get(k)[0] / args.steps for k in ("host.correspond", "host.corr.setup", "host.corr.nn_launch", "host.corr.post_launch", "host.corr.wait",
                                                             "host.corr.finish", "host.optimize", "host.evaluate")}
     eng.profile(False)
     timed_log = list(log)
-    timed_poses = list(round_poses)
     final_poses = poses.copy()
+    g_end = state["g"]
 
-    # Replay pass (UNTIMED): the same rounds again from the same initial poses, now with every profiling scope and the NN
+    # Replay pass (UNTIMED): the same global rounds again (same registrations, same resets), now with every profiling scope and the NN
     # census on (per-launch candidate / box / cache-hit counts = the algorithmic bytes of every NN launch).  The engine is
     # deterministic, so the replay walks through exactly the same poses and launches as the timed loop (checked below);
     # keeping the census kernels, their memsets and 20 extra event packets per round out of the timed region.
@@ -310,8 +302,9 @@ def main():
     census = None
     replay_identical = None
     if not args.no_replay:
-        eng.set_graph(pb["src"], pb["dst"])   # forget the NN history (temporal cache, seeds, AUTO state)
+        eng.reset_history()
         poses = pb["init"].copy()
+        state["g"] = 0
         for _ in range(args.warmup):
             step()
         eng.profile(1)
@@ -324,8 +317,18 @@ def main():
         census = eng.nn_census()
         eng.set_option("nn_census", 0)
         eng.profile(False)
-        replay_identical = bool(np.array_equal(poses, final_poses))
+        replay_identical = bool(np.array_equal(poses, final_poses)) and not state.get("replay_mismatch", False)
+    # registration 1 beyond the rounds the loop walked (untimed): the CPU-path comparison needs its first rounds
+    cpu_rounds = args.cpu_rounds if args.cpu_rounds is not None else (8 if 2.0 * K * N <= 3e7 else 2)
+    cpu_rounds = max(1, min(cpu_rounds, ROUNDS_PER_REGISTRATION))
+    if world == 1 and not args.no_cpu_baseline and max(poses_after, default=0) < cpu_rounds:
+        eng.reset_history()
+        poses = pb["init"].copy()
+        state["g"] = 0
+        for _ in range(cpu_rounds):
+            step()
     log[:] = timed_log
+    window_rounds = [l["round"] for l in log]
 
     # ---- roofline.  Time and launch count: live HIP events in the timed region.  Algorithmic bytes:
     #   linearize  56 B (point-to-plane: p, n, n.q) / 48 B (point-to-point: p, q) per correspondence per evaluation  [library scope bytes]
@@ -387,6 +390,16 @@ def main():
                 "optimize_ms": float(np.mean([l["lm_ms"] for l in rows])), "lm_iterations": float(np.mean([l["lm_iters"] for l in rows])),
                 "device_evaluations": float(np.mean([l["evals"] for l in rows]))}
 
+    per_rank = None
+    if world > 1:
+        # per-rank phase times (ms per step) so that a first real multi-GPU run is diagnosable: who waits for whom
+        mine = torch.tensor([local_elapsed / args.steps * 1e3, float(np.mean([l["nn_ms"] for l in log])), float(np.mean([l["lm_ms"] for l in log])),
+                             timed["nn"][0] / args.steps, timed["linearize"][0] / args.steps, timed["comm"][0] / args.steps, host["host.corr.wait"], host["host.evaluate"]],
+                            dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        keys = ("ms_per_step", "correspond_ms", "optimize_ms", "nn_kernel_ms", "linearize_kernel_ms", "comm_ms", "host_corr_wait_ms", "host_evaluate_ms")
+        per_rank = [{k: float(v) for k, v in zip(keys, t.cpu().tolist())} for t in allr]
     if rank == 0:
         rejected = sum(l["lm_iters"] - l["steps_taken"] for l in log)
         out = {
@@ -395,12 +408,19 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "views": K, "pts_per_view": N, "edges": int(eng.E), "cutoff": 0.05, "knn": 2, "robust": True,
                        "parallelism": f"edge-sharded x{world}, {exchange}" if world > 1 else "single GPU", "nn": args.nn},
-            "protocol": {"timed_rounds": [args.warmup + 1, args.warmup + args.steps], "start": "noisy initial poses of the synthetic registration (round 1)",
-                         "note": "value = all timed rounds; `regimes` splits them by whether the LM solve took a step (moving) or ended without stepping "
-                                 "(fixed point: the registration has converged and a round re-verifies it)"},
+            "protocol": {"rounds_per_registration": ROUNDS_PER_REGISTRATION,
+                         "registrations": [{"registration": int(r), "timed_rounds": [int(min(l["round"] for l in log if l["registration"] == r)),
+                                                                                   int(max(l["round"] for l in log if l["registration"] == r))]}
+                                           for r in sorted({l["registration"] for l in log})],
+                         "start": "every registration starts from the same noisy initial poses (the reference's noise generator is default-seeded, common.h:36) "
+                                  "after mvicp_reset_history() — inside the timed region when the boundary falls there",
+                         "later_registrations_retrace_the_first_bit_for_bit": not state.get("replay_mismatch", False),
+                         "note": "global round g (warm-up, then timed) = round g % 20 + 1 of registration g // 20 + 1 (main_multiview.cpp:150: 20 rounds); value = all timed "
+                                 "rounds; `regimes` splits them by whether the LM solve took a step (moving) or ended without stepping (fixed point: the registration "
+                                 "has converged and a round re-verifies it)"},
             "regimes": {"moving_rounds": regime(lambda l: l["moved"]), "fixed_point_rounds": regime(lambda l: not l["moved"]),
                         "rounds_with_bit_identical_poses": int(sum(l["poses_bit_identical"] for l in log))},
-            "round_ms": [round(l["nn_ms"] + l["lm_ms"], 4) for l in log],
+            "round_ms": [round(l["nn_ms"] + l["lm_ms"], 4) for l in log], "round_index": window_rounds,
             "roofline": roof(dominant), "roofline_nn": roof("nn"), "roofline_linearize": roof("linearize"),
             "phase_ms_per_step": {"correspond": float(np.mean([l["nn_ms"] for l in log])), "optimize": float(np.mean([l["lm_ms"] for l in log])),
                                   "lm_iterations": float(np.mean([l["lm_iters"] for l in log])), "device_evaluations": float(np.mean([l["evals"] for l in log])),
@@ -420,11 +440,19 @@ def main():
             out["nn_census_per_query"] = {"candidates_examined": census["candidates"] / q, "candidate_points_fetched": census["fetched"] / q,
                                           "cells_or_boxes": census["nodes"] / q, "tree_fallback_fraction": census["far"] / q,
                                           "temporal_cache_hit_fraction": census["hits"] / q}
+        if world > 1:
+            out["comm_ms_per_step"] = timed["comm"][0] / args.steps
+            out["comm_launches_per_step"] = timed["comm"][1] / args.steps
+            out["per_rank"] = per_rank
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(pb, plane, param, int(eng.E), timed_poses, [l["moved"] for l in log])
+                moved_by_round = [bool(np.any(poses_after[r] != (pb["init"] if r == 1 else poses_after[r - 1]))) for r in sorted(poses_after)]
+                legs = cpu_reference_legs(pb, plane, param, [poses_after[r] for r in range(1, cpu_rounds + 1)], [iters_of[r] for r in range(1, cpu_rounds + 1)],
+                                          window_rounds, moved_by_round, cpu_rounds)
+                out.update(legs)
                 out["speedup_vs_cpu_baseline"] = {"value": out["value"] / out["cpu_baseline"]["value"],
-                                                  "note": "GPU whole-job rate / extrapolated single-thread CPU port rate over the same timed rounds; a reported baseline, not a kernel-quality figure"}
+                                                  "vs_all_cores": out["value"] / [v for k, v in out["cpu_baseline"]["variants"].items() if "allcores" in k or "threadpool" in k][0]["value"],
+                                                  "note": "GPU whole-job rate / CPU path rate over the same timed rounds (1 thread -O2 sampled and scaled; all cores measured on all edges); a reported baseline, not a kernel-quality figure"}
             except Exception as ex:  # the baseline is a reported extra, never the measurement
                 out["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(out))

@@ -105,6 +105,10 @@ int mvicp_comm_set_callback(mvicp_ctx* ctx, mvicp_allreduce_fn fn, void* user);
  *            (float)(1.5 * upper median distance) (frame.cpp:166-176).  weight of an empty edge = 0. */
 int mvicp_correspond(mvicp_ctx* ctx, const double* poses, const unsigned char* fixed, float thresh, int nn_method,
                      int* counts, float* weights);
+/* Start a new registration on the same clouds and graph: forget everything earlier searches left behind (temporal NN cache, seeds,
+ * reusable lists, settled medians, MVICP_NN_AUTO state, the queued evaluation).  The next mvicp_correspond behaves like the first one
+ * after mvicp_set_graph — the state of a fresh run of the reference program (main_multiview.cpp:130-148).  Host-only bookkeeping. */
+int mvicp_reset_history(mvicp_ctx* ctx);
 /* Copy edge e's list back as Frame::neighbours[j].correspondances (frame.h:18-22): ascending `first`.
  * RETURNS THE NUMBER OF TRIPLES WRITTEN (>= 0, = counts[e] of the last mvicp_correspond) or a negative mvicp_status;
  * cap is the capacity of the three output arrays (each may be NULL to skip that field). */
@@ -137,6 +141,12 @@ typedef struct mvicp_summary {
   int termination;       /* 0 max-iterations, 1 gradient tol, 2 parameter tol, 3 function tol, 4 radius, -1 failure */
   int evaluations;       /* device linearize launches */
 } mvicp_summary;
+/* One deliberate deviation from the reference's write-back (icp-ceres.cpp:312-321,386-394,472-474 always converts the parameter
+ * blocks back to poses, which re-orthonormalises R): a solve that ends WITHOUT taking a step (successful_steps == 0) returns the
+ * caller's poses bit for bit.  pose -> parameters -> pose is a last-bit 2-cycle for some rotations, and the round trip would keep a
+ * converged registration from being a fixed point of the round.  Costs in the summary are those of the round-tripped poses the
+ * solver evaluates at (they differ from the returned ones by that last bit at most).  Callers that hand in a NON-orthonormal
+ * rotation and rely on the write-back to repair it must orthonormalise it themselves. */
 int mvicp_optimize(mvicp_ctx* ctx, double* poses, unsigned char* fixed, int param, int point_to_plane, int robust,
                    int max_iterations /* reference: 50, icp-ceres.cpp:81 */, mvicp_summary* summary);
 
@@ -175,10 +185,12 @@ int mvicp_closedform_point_to_plane(const double* src, const double* dst, const 
  * 1 / 0 = Hilbert / Morton index of the hash cell (nn_cell needs 0 or 1).  Tuning knobs: correspondences are
  * bit-identical for every setting. */
 int mvicp_set_option(mvicp_ctx* ctx, const char* name, double value);
-/* NN census accumulated while profiling and the "nn_census" option are on: out[0..5] = queries, candidate points
+/* NN census accumulated while profiling and the "nn_census" option are on: counters in this order — queries, candidate points
  * examined, tree boxes / grid cells looked up, queries that needed the tree fallback, queries answered by the temporal cache,
  * candidate points fetched from memory (a wave-cooperative kernel fetches a point once and examines it from LDS many times). */
-int mvicp_nn_census(mvicp_ctx* ctx, double* out6);
+int mvicp_nn_census(mvicp_ctx* ctx, double* out5);              /* the first five counters (the 0.1 contract) */
+/* All counters the build has, at most `cap` of them; returns how many were written (6 in version 0.3) or a negative status. */
+int mvicp_nn_census_ex(mvicp_ctx* ctx, double* out, int cap);
 
 /* ---- profiling (HIP events on the library's own stream) ------------------------------------------ */
 /* on = 0: off; 1: every scope below; 2: only "nn" and "linearize" (fewer event packets between the kernels of a

@@ -70,7 +70,7 @@ int scratch_upload(mvicp_ctx* c, const void* src, size_t bytes, void** dptr) {
 
 ProfScope::ProfScope(mvicp_ctx* ctx, const char* nm, double bytes) : c(ctx), name(nm), on(ctx->profile) {
   // level 2: only the two roofline scopes (every event pair is two extra queue packets between kernels)
-  if (on && ctx->profile_level >= 2 && std::strcmp(nm, "nn") != 0 && std::strcmp(nm, "linearize") != 0) on = false;
+  if (on && ctx->profile_level >= 2 && std::strcmp(nm, "nn") != 0 && std::strcmp(nm, "linearize") != 0 && std::strcmp(nm, "comm") != 0) on = false;
   if (!on) return;
   ProfEntry& pe = c->prof[name];
   auto get = [&]() {
@@ -137,7 +137,7 @@ void free_graph(mvicp_ctx* c) {
   dev_free(c->d_chunk_first); dev_free(c->d_partials); dev_free(c->d_out);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   c->h_pin = nullptr; c->h_pin_doubles = 0; c->d_res_host = nullptr; c->d_blocks_host = nullptr; c->lin_out = nullptr;
-  c->census_pending = false; c->spec_ready = false; c->spec_arm = false; c->d_spec_host = nullptr; c->d_adev_host = nullptr;
+  c->census_pending = false; c->spec_ready = false; c->spec_arm = false; c->d_spec_host = nullptr; c->d_adev_host = nullptr; c->d_res_target = nullptr;
   c->E = 0; c->total_cap = 0; c->n_cblocks = 0; c->n_chunks = 0; c->have_corr = false;
 }
 
@@ -276,7 +276,7 @@ int evaluate_blocks(mvicp_ctx* c, const double* poses, int plane, int robust, do
   if (c->comm || c->ar_fn) {
     c->lin_out = c->d_out;
     MV_CHECK(launch_linearize(c, plane, robust));
-    MV_CHECK(comm_allreduce_sum(c, c->d_out, n));
+    { ProfScope pc(c, "comm", 8.0 * (double)n); MV_CHECK(comm_allreduce_sum(c, c->d_out, n)); }
     MV_HIP(hipMemcpyAsync(h, c->d_out, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
   } else {
     c->lin_out = c->d_blocks_host;   // 8 * 91 * E bytes: the reduce kernel stores them straight into mapped host memory
@@ -294,7 +294,7 @@ using namespace mvicp;
 extern "C" {
 
 const char* mvicp_last_error(void) { return g_err; }
-const char* mvicp_version(void) { return "mvicp_hip 0.1 (gfx950)"; }
+const char* mvicp_version(void) { return "mvicp_hip 0.3 (gfx950)"; }
 
 int mvicp_create(int device, mvicp_ctx** out) try {
   if (!out) { set_error("out is null"); return MVICP_ERR_ARG; }
@@ -528,7 +528,9 @@ int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) t
   MV_CHECK(dev_alloc(&c->d_median, E));
   MV_CHECK(dev_alloc(&c->d_chunk_edge, (size_t)c->n_chunks)); MV_CHECK(dev_alloc(&c->d_chunk_start, (size_t)c->n_chunks));
   MV_CHECK(dev_alloc(&c->d_chunk_first, E + 1));
-  MV_CHECK(dev_alloc(&c->d_partials, (size_t)c->n_chunks * kLinPartial)); MV_CHECK(dev_alloc(&c->d_out, (size_t)E * MVICP_EDGE_BLOCK));
+  MV_CHECK(dev_alloc(&c->d_partials, (size_t)c->n_chunks * kLinPartial));
+  MV_CHECK(dev_alloc(&c->d_out, (size_t)E * (MVICP_EDGE_BLOCK + 3) + 2));   // blocks | (count, median d2) x E | armed | a x E  (see common.h)
+  MV_HIP(hipMemset(c->d_out, 0, sizeof(double) * ((size_t)E * (MVICP_EDGE_BLOCK + 3) + 2)));
   if (E) {
     MV_HIP(hipMemcpy(c->d_esrc, src, sizeof(int) * E, hipMemcpyHostToDevice));
     MV_HIP(hipMemcpy(c->d_edst, dst, sizeof(int) * E, hipMemcpyHostToDevice));
@@ -544,9 +546,9 @@ int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) t
   // pinned, device-mapped staging: control-block mirror | blocks | results | misc
   c->pin_blocks_off = c->ctl_r2_off + c->ctl_r2;
   c->pin_res_off = c->pin_blocks_off + (size_t)E * MVICP_EDGE_BLOCK;
-  c->pin_misc_off = c->pin_res_off + 2 * (size_t)E;
-  c->pin_spec_off = c->pin_misc_off + 4 * (size_t)E + 64;          // blocks of the speculative first evaluation
-  c->pin_adev_off = c->pin_spec_off + (size_t)E * MVICP_EDGE_BLOCK; // SoftLOne scales as the device computed them
+  c->pin_misc_off = c->pin_res_off + 2 * (size_t)E + 2;           // (+ the "armed" slot the select kernels write behind the E pairs)
+  c->pin_spec_off = c->pin_misc_off + 4 * (size_t)E + 64;          // blocks of the speculative first evaluation (+ the exchanged tail with N > 1 ranks)
+  c->pin_adev_off = c->pin_spec_off + (size_t)E * (MVICP_EDGE_BLOCK + 3) + 2; // SoftLOne scales as the device computed them (single rank)
   if (c->h_pin) { MV_HIP(hipHostFree(c->h_pin)); c->h_pin = nullptr; c->h_pin_doubles = 0; }
   MV_CHECK(ensure_pin(c, c->pin_adev_off + (size_t)E + 8));
   {
@@ -560,6 +562,22 @@ int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) t
   c->spec_ready = false; c->spec_arm = false; c->bracket_counters_clean = false;
   c->prev_xf.assign((size_t)E * 24, 0.0);
   if (!c->h_census) MV_HIP(hipHostMalloc((void**)&c->h_census, 8 * sizeof(unsigned long long), hipHostMallocDefault));
+  return MVICP_OK;
+} MVICP_GUARD_ABI
+
+int mvicp_reset_history(mvicp_ctx* c) try {
+  MV_CHECK(bind(c));
+  const int E = c->E;
+  MV_HIP(hipStreamSynchronize(c->stream));
+  c->nn_cache_valid = false; c->nn_cache_thresh = -1.f;
+  c->prev_q.assign((size_t)E * 12, 0.0); c->prev_xf.assign((size_t)E * 24, 0.0);
+  c->nn_cache_edge.assign(E, 0);                      // no seeds, no temporal cache: d_nn_idx / d_nn_lb are dead until the next search rewrites them
+  c->auto_prev_dist = 0.0; c->auto_last_method = -1; c->last_rms = -1.0;
+  c->list_valid.assign(E, 0);                          // every list is re-compacted and re-gathered
+  c->sel_med1.assign(E, -1.0); c->sel_med2.assign(E, -1.0);
+  c->spec_ready = false; c->spec_arm = false; c->spec_flags_valid = false;
+  c->have_corr = false;
+  std::fill(c->h_count.begin(), c->h_count.end(), 0); std::fill(c->h_weight.begin(), c->h_weight.end(), 0.f);
   return MVICP_OK;
 } MVICP_GUARD_ABI
 
@@ -688,12 +706,17 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   for (int e = 0; e < E && nothing_can_change; ++e)
     if (c->active[e] && !(same_edge[e] && hd[e] == 0)) nothing_can_change = false;
   c->skip_dirty_reduce = nothing_can_change;
-  // Speculative first evaluation of the solve that follows (see common.h): same decision on every rank (the launch carries a
-  // collective), so it only looks at replicated state.  Not with the host-staged callback transport (that one blocks).
+  // Speculative first evaluation of the solve that follows (see common.h).  Every rank decides for itself (its own last solve set
+  // the flags); with N > 1 ranks the decisions are SUMMED in the "armed" slot of the one exchanged buffer and the queued blocks are
+  // used only if every rank armed — a rank whose last solve failed or was skipped still takes part in the same collective (no hang).
+  const bool exchange = c->comm != nullptr || c->ar_fn != nullptr;
   c->spec_ready = false;
-  c->spec_arm = c->spec_enable && c->spec_flags_valid && !c->ar_fn;
+  c->spec_arm = c->spec_enable && c->spec_flags_valid;
   if (c->spec_arm && c->spec_plane)
     for (int e = 0; e < E; ++e) if (!(fixed && fixed[c->esrc[e]]) && c->frames[c->edst[e]].n > 0 && c->frames[c->edst[e]].grid.snor == nullptr) c->spec_arm = false;
+  const size_t nb = (size_t)E * MVICP_EDGE_BLOCK, ntail = 3 * (size_t)E + 1;   // tail = (count, median d2) x E | armed | a x E
+  c->d_res_target = exchange ? c->d_out + nb : nullptr;
+  double* const a_chk_dev = exchange ? c->d_out + nb + 2 * (size_t)E + 1 : c->d_adev_host;
   size_t upload_doubles = c->ctl_r1;
   if (c->spec_arm) {
     // the solve evaluates at x_to_pose(pose_to_x(P)) (host/lm.cpp): the same round trip here, so the poses match bit for bit.  The
@@ -725,56 +748,73 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
     MV_CHECK(launch_compact(c, bound));
     MV_CHECK(launch_gather_stream(c));
   }
-  if (use_bracket) MV_CHECK(launch_select_bracket(c)); else MV_CHECK(launch_select_median(c));
-  if (c->spec_arm) {   // the queued first evaluation (its relative transforms went up with the control block)
-    const size_t nb = (size_t)E * MVICP_EDGE_BLOCK;
-    if (c->comm) {
-      c->lin_out = c->d_out;
-      MV_CHECK(launch_linearize(c, c->spec_q_plane, c->spec_q_robust));
-      MV_CHECK(comm_allreduce_sum(c, c->d_out, nb));
-      MV_HIP(hipMemcpyAsync(c->h_pin + c->pin_spec_off, c->d_out, sizeof(double) * nb, hipMemcpyDeviceToHost, c->stream));
-    } else {
-      c->lin_out = c->d_spec_host;
-      MV_CHECK(launch_linearize(c, c->spec_q_plane, c->spec_q_robust));
+  double* const a_chk_saved = c->d_adev_host;
+  c->d_adev_host = a_chk_dev;   // (the select kernels copy the scales they derive to this address; restored below)
+  int st_sel = use_bracket ? launch_select_bracket(c) : launch_select_median(c);
+  if (st_sel != MVICP_OK) { c->d_adev_host = a_chk_saved; c->spec_flags_valid = false; return st_sel; }
+  // the queued first evaluation (its relative transforms went up with the control block).  With N > 1 ranks: ONE collective per
+  // search — [E x 91 blocks | (count, median d2) x E | armed | a x E], always the full buffer — and ONE wait.
+  int st_q = MVICP_OK;
+  if (exchange) {
+    c->lin_out = c->d_out;
+    if (c->spec_arm) st_q = launch_linearize(c, c->spec_q_plane, c->spec_q_robust);
+    if (st_q == MVICP_OK) { ProfScope pc(c, "comm", 8.0 * (double)(nb + ntail)); st_q = comm_allreduce_sum(c, c->d_out, nb + ntail); }
+    if (st_q == MVICP_OK && hipMemcpyAsync(c->h_pin + c->pin_spec_off, c->d_out, sizeof(double) * (nb + ntail), hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
+      set_error("hipMemcpyAsync of the exchanged buffer failed"); st_q = MVICP_ERR_HIP;
     }
+  } else if (c->spec_arm) {
+    c->lin_out = c->d_spec_host;
+    st_q = launch_linearize(c, c->spec_q_plane, c->spec_q_robust);
   }
   mark("host.corr.post_launch");
-  // (count, median d2) per edge arrive in mapped host memory, written by select_final_kernel;
-  // weight = (float)(1.5 * sqrt(median d2))  (frame.cpp:168-176)
-  MV_CHECK(stream_wait(c));
+  // (count, median d2) per edge arrive in mapped host memory, written by select_final_kernel (single rank), or summed over ranks
+  // behind the blocks; weight = (float)(1.5 * sqrt(median d2))  (frame.cpp:168-176)
+  if (st_q == MVICP_OK) st_q = stream_wait(c);
+  if (st_q != MVICP_OK) { c->d_adev_host = a_chk_saved; c->spec_flags_valid = false; c->spec_arm = false; return st_q; }
   census_resolve(c);
   mark("host.corr.wait");
-  const double* hr = c->h_pin + c->pin_res_off;
-  double spec_bad = 0.0;
-  if (use_bracket) {
+  const double* hr = exchange ? c->h_pin + c->pin_spec_off + nb : c->h_pin + c->pin_res_off;
+  bool spec_bad = false;
+  {
+    // a median that left its bracket is flagged -1 in its slot; with N > 1 ranks every rank sees the summed slots, so every rank takes
+    // the same decision: full select for everything (rare once the registration has settled) and a second, tail-only exchange
     bool redo = false;
-    for (int e = 0; e < E; ++e) if (c->owned[e] && c->active[e] && hr[2 * e + 1] < 0.0) redo = true;
-    if (redo) {   // some median left its bracket: full select for everything (rare once the registration has settled)
-      spec_bad = 1.0;   // the queued evaluation used the scales of the failed select
-      MV_CHECK(launch_select_median(c));
-      MV_CHECK(stream_wait(c));
+    for (int e = 0; e < E; ++e) if (hr[2 * e + 1] < 0.0) redo = true;
+    if (redo) {
+      spec_bad = true;   // the queued evaluation used the scales of the failed select
+      int st_r = launch_select_median(c);
+      if (st_r == MVICP_OK && exchange) {
+        ProfScope pc(c, "comm", 8.0 * (double)ntail);
+        st_r = comm_allreduce_sum(c, c->d_out + nb, ntail);
+        if (st_r == MVICP_OK && hipMemcpyAsync(c->h_pin + c->pin_spec_off + nb, c->d_out + nb, sizeof(double) * ntail, hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
+          set_error("hipMemcpyAsync of the exchanged tail failed"); st_r = MVICP_ERR_HIP;
+        }
+      }
+      if (st_r == MVICP_OK) st_r = stream_wait(c);
+      if (st_r != MVICP_OK) { c->d_adev_host = a_chk_saved; c->spec_flags_valid = false; c->spec_arm = false; return st_r; }
     }
   }
+  c->d_adev_host = a_chk_saved;
   for (int e = 0; e < E; ++e) {
     if (!(c->owned[e] && c->active[e])) { c->sel_med1[e] = c->sel_med2[e] = -1.0; continue; }
     c->sel_med2[e] = c->sel_med1[e];
     c->sel_med1[e] = hr[2 * e] > 0 ? hr[2 * e + 1] : -1.0;
   }
-  std::vector<double> pack(2 * (size_t)E + 1, 0.0);
+  std::vector<double> pack(2 * (size_t)E, 0.0);
   for (int e = 0; e < E; ++e)
-    if (c->owned[e] && c->active[e]) { pack[2 * e] = hr[2 * e]; pack[2 * e + 1] = hr[2 * e] > 0 ? hr[2 * e + 1] : 0.0; }
+    if (exchange || (c->owned[e] && c->active[e])) { pack[2 * e] = hr[2 * e]; pack[2 * e + 1] = hr[2 * e] > 0 ? hr[2 * e + 1] : 0.0; }
   if (c->spec_arm) {
-    // trust the queued evaluation only if the scales the device derived from the medians are the host's (IEEE sqrt) bit for bit
-    const double* ad = c->h_pin + c->pin_adev_off;
-    for (int e = 0; e < E; ++e)
-      if (c->owned[e] && c->active[e]) {
+    // trust the queued evaluation only if (i) every rank queued one, and (ii) the scales the device derived from the medians are the
+    // host's (IEEE sqrt) bit for bit — checked on ALL edges from exchanged data, so every rank reaches the same verdict
+    const double* ad = exchange ? hr + 2 * (size_t)E + 1 : c->h_pin + c->pin_adev_off;
+    if (hr[2 * (size_t)E] != (double)(exchange ? c->world : 1)) spec_bad = true;
+    for (int e = 0; e < E && !spec_bad; ++e)
+      if (exchange || (c->owned[e] && c->active[e])) {
         const double a_host = pack[2 * e] > 0 ? (double)(float)(std::sqrt(pack[2 * e + 1]) * 1.5) : 0.0;
-        if (ad[e] != a_host) spec_bad = 1.0;
+        if (ad[e] != a_host) spec_bad = true;
       }
-    pack[2 * (size_t)E] = spec_bad;   // rides on the counts / medians exchange: every rank takes the same decision
   }
-  if (c->comm || c->ar_fn) MV_CHECK(comm_allreduce_host(c, pack.data(), pack.size()));
-  c->spec_ready = c->spec_arm && pack[2 * (size_t)E] == 0.0;
+  c->spec_ready = c->spec_arm && !spec_bad;
   c->spec_arm = false;
   double* ha = c->h_pin + c->ctl_r2_off + (size_t)E * kEdgeRel;   // `a` slice of region 2: uploaded with rel by the next evaluation
   for (int e = 0; e < E; ++e) {
@@ -932,11 +972,17 @@ int mvicp_set_option(mvicp_ctx* c, const char* name, double value) try {
   set_error("unknown option '%s'", name);
   return MVICP_ERR_ARG;
 } MVICP_GUARD_ABI
-int mvicp_nn_census(mvicp_ctx* c, double* out6) try {
+int mvicp_nn_census_ex(mvicp_ctx* c, double* out, int cap) try {
   MV_CHECK(bind(c));
-  if (!out6) { set_error("null output"); return MVICP_ERR_ARG; }
-  out6[0] = c->nn_queries; out6[1] = c->nn_candidates; out6[2] = c->nn_nodes; out6[3] = c->nn_far; out6[4] = c->nn_hits; out6[5] = c->nn_fetched;
-  return MVICP_OK;
+  if (!out || cap < 0) { set_error("bad output buffer"); return MVICP_ERR_ARG; }
+  const double v[6] = {c->nn_queries, c->nn_candidates, c->nn_nodes, c->nn_far, c->nn_hits, c->nn_fetched};
+  const int n = std::min(cap, 6);
+  for (int i = 0; i < n; ++i) out[i] = v[i];
+  return n;
+} MVICP_GUARD_ABI
+int mvicp_nn_census(mvicp_ctx* c, double* out5) try {   // the original 5-counter contract (a caller's 5-element buffer is never overrun)
+  const int n = mvicp_nn_census_ex(c, out5, 5);
+  return n < 0 ? n : MVICP_OK;
 } MVICP_GUARD_ABI
 
 int mvicp_profile_enable(mvicp_ctx* c, int on) try {

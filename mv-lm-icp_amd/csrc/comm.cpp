@@ -1,6 +1,6 @@
 // RCCL over xGMI: the only collective on the path is an in-place fp64 sum all-reduce of the per-edge
-// normal-equation blocks (E x 91 doubles, <= 92 KB at 126 edges) once per LM evaluation, plus one
-// E x 2 all-reduce per ICP round for counts / median d2.  Every edge slot is written by exactly one
+// normal-equation blocks (E x 91 doubles, <= 92 KB at 126 edges) once per LM evaluation; the per-round counts / median d2 /
+// "use the queued evaluation" decision ride in the tail of the same buffer (api.cpp).  Every edge slot is written by exactly one
 // rank (the others contribute +0.0), so the sum is exact and the result is bit-identical for any
 // number of GPUs.  Latency-bound, not link-bound: one collective per evaluation, nothing to bucket.
 #include "comm.h"
@@ -20,7 +20,6 @@ struct RcclApi {
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
-  double* d_small = nullptr; size_t small_n = 0;
 };
 
 namespace {
@@ -91,25 +90,6 @@ int comm_allreduce_sum(mvicp_ctx* c, double* d_buf, size_t n) {
   if (!c->comm) return MVICP_OK;
   const int r = c->rccl->AllReduce(d_buf, d_buf, n, /*ncclFloat64*/ 8, /*ncclSum*/ 0, c->comm, c->stream);
   if (r != 0) { set_error("ncclAllReduce: %s", errstr(c->rccl, r)); return MVICP_ERR_COMM; }
-  return MVICP_OK;
-}
-
-int comm_allreduce_host(mvicp_ctx* c, double* h_buf, size_t n) {
-  if (c->ar_fn) {
-    if (c->ar_fn(c->ar_user, h_buf, n) != 0) { set_error("all-reduce callback failed"); return MVICP_ERR_COMM; }
-    return MVICP_OK;
-  }
-  if (!c->comm) return MVICP_OK;
-  RcclApi* a = c->rccl;
-  if (a->small_n < n) {
-    if (a->d_small) (void)hipFree(a->d_small);
-    MV_HIP(hipMalloc((void**)&a->d_small, sizeof(double) * n));
-    a->small_n = n;
-  }
-  MV_HIP(hipMemcpyAsync(a->d_small, h_buf, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-  MV_CHECK(comm_allreduce_sum(c, a->d_small, n));
-  MV_HIP(hipMemcpyAsync(h_buf, a->d_small, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
-  MV_HIP(hipStreamSynchronize(c->stream));
   return MVICP_OK;
 }
 

@@ -9,6 +9,4 @@ int comm_init(mvicp_ctx* c, const char* path, const void* id128, int rank, int w
 void comm_destroy(mvicp_ctx* c);
 // in-place sum over ranks of a device fp64 buffer, on the context's stream
 int comm_allreduce_sum(mvicp_ctx* c, double* d_buf, size_t n);
-// same for a small host buffer (staged through device memory)
-int comm_allreduce_host(mvicp_ctx* c, double* h_buf, size_t n);
 }  // namespace mvicp

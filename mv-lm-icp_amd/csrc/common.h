@@ -154,7 +154,9 @@ struct mvicp_ctx {
   std::vector<int> chunk_first;     // E+1
   int* d_chunk_edge = nullptr; int* d_chunk_start = nullptr; int* d_chunk_first = nullptr;
   double* d_partials = nullptr;     // n_chunks x kLinPartial
-  double* d_out = nullptr;          // E x 91
+  double* d_out = nullptr;          // E x 91 blocks | E x 2 (count, median d2) | 1 "armed" slot: ONE buffer, so that with N > 1 ranks a round's
+                                    // counts / medians / use-the-queued-evaluation decision travel in the same all-reduce as the queued blocks
+  double* d_res_target = nullptr;   // where the select kernels put (count, median d2): null = mapped host memory (single rank), else d_out's tail
   // pinned (device-mapped) host staging: [control-block mirror | blocks E x 91 | results E x 2 | misc]
   double* h_pin = nullptr; size_t h_pin_doubles = 0;
   size_t pin_blocks_off = 0, pin_res_off = 0, pin_misc_off = 0;

@@ -341,7 +341,7 @@ __global__ __launch_bounds__(NT) void select_final_kernel(int E, const int* __re
                                                           const double* __restrict__ keys2, const unsigned int* __restrict__ cnt2,
                                                           const unsigned int* __restrict__ hist, const SelState* __restrict__ state,
                                                           double* __restrict__ median, double* __restrict__ host_res,
-                                                          double* __restrict__ a_dev, double* __restrict__ a_host) {
+                                                          double* __restrict__ a_dev, double* __restrict__ a_host, double armed) {
   __shared__ unsigned int lh[1024];
   __shared__ int wave_tot[NT / 64];
   __shared__ int sh_pick[2];
@@ -376,7 +376,10 @@ __global__ __launch_bounds__(NT) void select_final_kernel(int E, const int* __re
   }
   if (threadIdx.x == 0) {
     median[e] = med;
-    if (host_res) { host_res[2 * e] = (double)(cnt > 0 ? cnt : 0); host_res[2 * e + 1] = med; }
+    if (host_res) {
+      host_res[2 * e] = (double)(cnt > 0 ? cnt : 0); host_res[2 * e + 1] = med;
+      if (e == 0) host_res[2 * E] = armed;   // slot behind the E pairs: 1 if this rank queued the speculative evaluation (summed over ranks)
+    }
     write_a_scale(cnt, med, e, a_dev, a_host);
   }
 }
@@ -446,7 +449,7 @@ __global__ __launch_bounds__(NT) void bracket_pass_kernel(const int* __restrict_
 __global__ __launch_bounds__(NT) void bracket_final_kernel(int E, const int* __restrict__ count, const long long* __restrict__ cap_off,
                                                            const double* __restrict__ keys1, unsigned int* __restrict__ cnt_lt,
                                                            unsigned int* __restrict__ cnt_mid, double* __restrict__ median,
-                                                           double* __restrict__ host_res, double* __restrict__ a_dev, double* __restrict__ a_host) {
+                                                           double* __restrict__ host_res, double* __restrict__ a_dev, double* __restrict__ a_host, double armed) {
   __shared__ unsigned int lh[kSelBins];
   __shared__ int wave_tot[NT / 64];
   __shared__ int sh_pick[2];
@@ -504,6 +507,7 @@ __global__ __launch_bounds__(NT) void bracket_final_kernel(int E, const int* __r
     if (ok) median[e] = med;
     host_res[2 * e] = (double)(cnt > 0 ? cnt : 0);
     host_res[2 * e + 1] = ok ? med : -1.0;   // -1: rank outside the bracket -> the host falls back to the full select
+    if (e == 0) host_res[2 * E] = armed;
     write_a_scale(ok ? cnt : 0, med, e, a_dev, a_host);
   }
   // leave the two counters zeroed for the next round's bracket pass (no memset in the steady-state launch sequence)
@@ -562,7 +566,8 @@ int launch_select_bracket(mvicp_ctx* c) {
                        (const double*)c->d_sel_lohi, cnt_lt, c->d_sel_keys1, cnt_mid);
   }
   hipLaunchKernelGGL(bracket_final_kernel, dim3(c->E), dim3(NT), 0, c->stream, c->E, c->d_count, c->d_cap_off, c->d_sel_keys1, cnt_lt,
-                     cnt_mid, c->d_median, c->d_res_host, c->spec_arm ? c->d_a : (double*)nullptr, c->spec_arm ? c->d_adev_host : (double*)nullptr);
+                     cnt_mid, c->d_median, c->d_res_target ? c->d_res_target : c->d_res_host, c->spec_arm ? c->d_a : (double*)nullptr,
+                     c->spec_arm ? c->d_adev_host : (double*)nullptr, c->spec_arm ? 1.0 : 0.0);
   MV_HIP(hipGetLastError());
   return MVICP_OK;
 }
@@ -591,8 +596,8 @@ int launch_select_median(mvicp_ctx* c) {
                        hist, (const SelState*)st, c->d_sel_keys2, cnt2);
   }
   hipLaunchKernelGGL(select_final_kernel, dim3(c->E), dim3(NT), 0, c->stream, c->E, c->d_count, c->d_cap_off, c->d_sel_keys2, (const unsigned int*)cnt2,
-                     (const unsigned int*)hist, (const SelState*)st, c->d_median, c->d_res_host, c->spec_arm ? c->d_a : (double*)nullptr,
-                     c->spec_arm ? c->d_adev_host : (double*)nullptr);
+                     (const unsigned int*)hist, (const SelState*)st, c->d_median, c->d_res_target ? c->d_res_target : c->d_res_host,
+                     c->spec_arm ? c->d_a : (double*)nullptr, c->spec_arm ? c->d_adev_host : (double*)nullptr, c->spec_arm ? 1.0 : 0.0);
   MV_HIP(hipGetLastError());
   return MVICP_OK;
 }

@@ -886,7 +886,7 @@ void make_grid(HostGrid& g, const double* lo, const double* hi, double h) {
 // wave in the moving rounds (profiles/r02_kd_order_sim.txt).  Ties on the split coordinate break on the original index and the
 // recursion runs down to single points, so the order is a pure function of the cloud.
 struct KdItem { double x, y, z; int idx; int pad; };
-void kd_split(KdItem* a, long long lo, long long hi, int par) {   // par: levels that still fork a host thread
+void kd_split(KdItem* a, long long lo, long long hi, int par) noexcept {   // par: levels that still fork a host thread
   for (;;) {
     const long long m = hi - lo;
     if (m <= 1) return;
@@ -911,12 +911,13 @@ void kd_split(KdItem* a, long long lo, long long hi, int par) {   // par: levels
     };
     std::nth_element(a + lo, a + mid, a + hi, less);
     if (par > 0 && m > (1 << 15)) {
-      std::thread t;
-      try { t = std::thread(kd_split, a, lo, mid, par - 1); } catch (const std::system_error&) {}   // no thread to be had: do both halves here
-      if (t.joinable()) {
+      // kd_split itself never throws (nth_element on PODs with a noexcept comparator; every thread construction is guarded here), so
+      // neither the child's entry point nor the parent can unwind past a joinable thread; the guard joins on every path regardless.
+      struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } j;
+      try { j.t = std::thread(kd_split, a, lo, mid, par - 1); } catch (...) {}   // no thread to be had (system_error, bad_alloc, ...): do both halves here
+      if (j.t.joinable()) {
         kd_split(a, mid, hi, par - 1);
-        t.join();
-        return;
+        return;   // ~Joiner joins
       }
     }
     // recurse into the smaller part, loop on the larger (bounded stack)

@@ -15,7 +15,7 @@ SYMBOLS = [
     "mvicp_last_error", "mvicp_version", "mvicp_create", "mvicp_destroy", "mvicp_set_num_frames", "mvicp_set_frame",
     "mvicp_recompute_normals", "mvicp_set_graph", "mvicp_set_shard", "mvicp_edge_owner", "mvicp_comm_unique_id", "mvicp_comm_init", "mvicp_comm_set_callback", "mvicp_correspond",
     "mvicp_get_correspondences", "mvicp_set_correspondences", "mvicp_nn_query", "mvicp_linearize", "mvicp_optimize",
-    "mvicp_lm_solve", "mvicp_set_option", "mvicp_nn_census", "mvicp_profile_enable", "mvicp_profile_reset", "mvicp_profile_get", "mvicp_stream", "mvicp_sync",
+    "mvicp_lm_solve", "mvicp_set_option", "mvicp_nn_census", "mvicp_nn_census_ex", "mvicp_reset_history", "mvicp_profile_enable", "mvicp_profile_reset", "mvicp_profile_get", "mvicp_stream", "mvicp_sync",
     "mvicp_closedform_point_to_point", "mvicp_closedform_point_to_plane",
 ]
 
@@ -70,6 +70,8 @@ def load_library(path=None):
     lib.mvicp_lm_solve.argtypes = [C.c_int, C.c_int, ip, ip, dp, u8p, C.c_int, C.c_int, EVAL_FN, vp, C.POINTER(Summary)]
     lib.mvicp_set_option.argtypes = [vp, C.c_char_p, C.c_double]
     lib.mvicp_nn_census.argtypes = [vp, dp]
+    lib.mvicp_nn_census_ex.argtypes = [vp, dp, C.c_int]
+    lib.mvicp_reset_history.argtypes = [vp]
     lib.mvicp_profile_enable.argtypes = [vp, C.c_int]
     lib.mvicp_profile_reset.argtypes = [vp]
     lib.mvicp_profile_get.argtypes = [vp, C.c_char_p, dp, C.POINTER(C.c_longlong), dp]
@@ -211,6 +213,10 @@ class Engine:
         self.E = len(self.src)
         _check(self.lib, self.lib.mvicp_set_graph(self.h, self.E, _ip(self.src), _ip(self.dst)))
 
+    def reset_history(self):
+        """New registration on the same clouds / graph: the next correspond() behaves like the first one after set_graph()."""
+        _check(self.lib, self.lib.mvicp_reset_history(self.h))
+
     def comm_init(self, unique_id, librccl_path=None):
         buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
         path = librccl_path.encode() if librccl_path else None
@@ -297,7 +303,7 @@ class Engine:
 
     def nn_census(self):
         out = np.zeros(6)
-        _check(self.lib, self.lib.mvicp_nn_census(self.h, _dp(out)))
+        _check(self.lib, self.lib.mvicp_nn_census_ex(self.h, _dp(out), 6))
         return {"queries": out[0], "candidates": out[1], "nodes": out[2], "far": out[3], "hits": out[4], "fetched": out[5]}
 
     # ---- profiling

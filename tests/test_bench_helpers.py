@@ -1,5 +1,5 @@
-"""bench.py pieces that do not need a GPU: the CPU-baseline leg (oracle + real nanoflann on a bounded sample, started from given round
-poses) and the source hash that ties a committed rocprofv3 summary to the code it measured."""
+"""bench.py pieces that do not need a GPU: the CPU legs (reference-equivalent CPU path = oracle + real nanoflann: pose comparison on all
+edges, all-cores timing, single-thread sample) and the source hash that ties a committed rocprofv3 summary to the code it measured."""
 import json
 import os
 import sys
@@ -13,14 +13,28 @@ import bench  # noqa: E402
 from mvicp import synth  # noqa: E402
 
 
-def test_cpu_baseline_runs_on_a_bounded_sample_and_reports_every_variant():
+def test_cpu_reference_legs_run_and_report_every_variant():
+    """bench.py's CPU legs on a small problem: the all-edge CPU-path walk (pose_diff_vs_cpu_path, all-cores timing, LM iteration counts per
+    round) and the single-thread sample, weighted over a timed window that spans a registration boundary (rounds 6..20 then 1..5)."""
+    import cpupath
     pb = synth.make_problem(4, 1500)
-    round_poses = [pb["init"], pb["gt"], pb["gt"]]
-    out = bench.cpu_baseline(pb, 1, 2, len(pb["src"]), round_poses, [True, False, False], sample_views=3)
-    assert out["kind"] == "port" and out["cores"] == 1 and out["value"] > 0
-    v = out["variants"]
+    cp = cpupath.CpuPath(pb["pts"], pb["nor"], pb["src"], pb["dst"], pb["fixed"], 2, 1)
+    P = pb["init"].copy(); after = []; iters = []
+    for _ in range(4):                                   # stands in for the GPU run's poses after rounds 1..4
+        P, sm = cp.round(P); after.append(P.copy()); iters.append(sm["iterations"])
+    cp.close()
+    window = list(range(6, 21)) + list(range(1, 6))
+    moved = [bool(np.any(after[r] != (pb["init"] if r == 0 else after[r - 1]))) for r in range(4)]
+    out = bench.cpu_reference_legs(pb, 1, 2, after, iters, window, moved, 4)
+    pd = out["pose_diff_vs_cpu_path"]
+    assert pd["rounds_compared"] == 4 and pd["max_translation_m"] < 1e-9 and pd["max_rotation_rad"] < 1e-9     # the same CPU path twice (other build: last bits)
+    assert pd["lm_iterations_gpu"] == pd["lm_iterations_cpu"] == iters
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0
+    v = cb["variants"]
     assert "O2_1thread" in v and set(v["O2_1thread"]["by_regime"]) == {"moving", "fixed_point"}
-    assert v["O2_1thread"]["by_regime"]["moving"]["round"] == 0 and v["O2_1thread"]["by_regime"]["fixed_point"]["round"] == 2
+    allc = [r for k, r in v.items() if "allcores" in k or "threadpool" in k]
+    assert len(allc) == 1 and len(allc[0]["per_round"]) == 4 and allc[0]["edges"] == len(pb["src"])
     for name, r in v.items():
         assert r["value"] > 0 and r["cores"] >= 1, name
     json.dumps(out)   # must be serialisable into the bench line
@@ -29,7 +43,7 @@ def test_cpu_baseline_runs_on_a_bounded_sample_and_reports_every_variant():
 def test_source_hash_matches_the_committed_profiles_when_present():
     sha = bench.source_sha16()
     assert len(sha) == 16 and sha == bench.source_sha16()
-    for name in ("r02_cfg4_w5s20_kernels.json", "r02_cfg4_w1s19_kernels.json"):
+    for name in ("r03_cfg4_w5s20_kernels.json", "r03_cfg4_w1s19_kernels.json", "r02_cfg4_w5s20_kernels.json"):
         p = os.path.join(ROOT, "profiles", name)
         if os.path.exists(p):
             j = json.load(open(p))

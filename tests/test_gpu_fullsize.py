@@ -9,6 +9,7 @@ import time
 import numpy as np
 import pytest
 
+import cpupath
 import mvicp
 import orclib
 from mvicp import lib as L
@@ -82,10 +83,78 @@ def test_cfg3_full_size_vs_nanoflann_and_oracle_lm(orc, refnn):
     eng.close()
 
 
+def fastest_cpu_path(pb, param, plane):
+    """The CPU reference path (tests/cpupath.py: real nanoflann + oracle LM) in the fastest build this host can run: -O3 AVX2 + OpenMP on
+    every usable core where the CPU has AVX2 (per-thread partial sums: last-bit differences from the -O2 build), else the -O2 build."""
+    fast = cpupath.fast_build_usable()
+    return cpupath.CpuPath(pb["pts"], pb["nor"], pb["src"], pb["dst"], pb["fixed"], param, plane, fast=fast, threads=cpupath.usable_cores(32))
+
+
+def test_cfg3_twenty_rounds_vs_cpu_path():
+    """The reference's WHOLE loop at BASELINE config 3 — 20 rounds (src/main_multiview.cpp:150-169) of computeClosestPoints +
+    ceresOptimizer_ceresAngleAxis on 8 views x 100 000 points — GPU path and CPU path (real nanoflann + oracle LM), each on its
+    OWN trajectory from the same noisy initial poses.  Every round: same LM iteration count, same termination, same number of
+    correspondences; poses within 1e-7 m / rad at every round and at the end (north-star bar 1e-5; measured ~1e-11)."""
+    pb = synth.make_problem(8, 100_000)
+    K = 8
+    eng = mvicp.Engine(0)
+    eng.set_frames(pb["pts"], pb["nor"]); eng.set_graph(pb["src"], pb["dst"])
+    cpu = fastest_cpu_path(pb, orclib.PARAM_ANGLEAXIS, 1)
+    Pg = pb["init"].copy(); Pc = pb["init"].copy()
+    worst = 0.0
+    moved = 0
+    for rnd in range(20):
+        counts, weights = eng.correspond(Pg, pb["fixed"], CUTOFF)
+        Pg, sg = eng.optimize(Pg, pb["fixed"], L.PARAM_ANGLE_AXIS, 1, True, 50)
+        Pc, sc = cpu.round(Pc)
+        assert sg["iterations"] == sc["iterations"] and sg["termination"] == sc["termination"], (rnd, sg, sc)
+        assert sg["successful_steps"] == sc["successful_steps"], (rnd, sg, sc)
+        # the two trajectories differ by ~1e-12, so a query that sits within that of the cutoff sphere may be counted on one side only
+        assert int(np.abs(counts - cpu.last["counts"]).sum()) <= 2, (rnd, counts, cpu.last["counts"])
+        dev = max(max(synth.pose_diff(Pg[k], Pc[k])) for k in range(K))
+        worst = max(worst, dev)
+        assert dev < 1e-7, (rnd, dev)
+        moved += sg["successful_steps"] > 0
+    assert 3 <= moved < 20, moved           # the window really holds both regimes: moving rounds and re-verified fixed-point rounds
+    print(f"cfg3 20 rounds: worst GPU-vs-CPU-path pose deviation over all rounds {worst:.2e} (m | rad), {moved} moving rounds")
+    cpu.close(); eng.close()
+
+
 # ------------------------------------------------------------------------------------------------ cfg4: 32 x 200k
 @pytest.fixture(scope="module")
 def cfg4():
     return synth.make_problem(32, 200_000)
+
+
+def test_cfg4_every_solve_vs_oracle_lm_on_all_edges(cfg4):
+    """BASELINE config 4 (32 x 200 000, E = 62, point-to-plane, SophusSE3), 8 ICP rounds of the product path: EVERY solve is repeated
+    by the oracle's LM on the same 12.4 M residuals (the lists of all 62 edges copied back through mvicp_get_correspondences, the
+    float weights as returned) from the same input poses: same iteration count / termination / step count, output poses within
+    1e-8 m / rad per solve (measured ~1e-12), costs to 1e-10 relative."""
+    pb = cfg4
+    K, E = 32, len(pb["src"])
+    eng = mvicp.Engine(0)
+    eng.set_frames(pb["pts"], pb["nor"]); eng.set_graph(pb["src"], pb["dst"])
+    cpu = fastest_cpu_path(pb, orclib.PARAM_SOPHUS, 1)
+    poses = pb["init"].copy()
+    worst = 0.0
+    for rnd in range(8):
+        counts, weights = eng.correspond(poses, pb["fixed"], CUTOFF)
+        corr = []
+        for e in range(E):
+            f, s2, d = eng.get_correspondences(e)
+            assert len(f) == counts[e]
+            corr.append((f, s2, d, weights[e]))
+        Pg, sg = eng.optimize(poses, pb["fixed"], L.PARAM_SOPHUS_SE3, 1, True, 50)
+        Po, so = cpu.optimize(poses, corr)
+        assert sg["iterations"] == so["iterations"] and sg["termination"] == so["termination"] and sg["successful_steps"] == so["successful_steps"], (rnd, sg, so)
+        assert abs(sg["initial_cost"] - so["initial_cost"]) <= 1e-10 * so["initial_cost"] and abs(sg["final_cost"] - so["final_cost"]) <= 1e-10 * so["final_cost"], (rnd, sg, so)
+        dev = max(max(synth.pose_diff(Pg[k], Po[k])) for k in range(K))
+        worst = max(worst, dev)
+        assert dev < 1e-8, (rnd, dev)
+        poses = Pg
+    print(f"cfg4 8 solves x 62 edges vs oracle LM: worst pose deviation per solve {worst:.2e}")
+    cpu.close(); eng.close()
 
 
 def test_cfg4_full_size_vs_nanoflann(orc, refnn, cfg4):

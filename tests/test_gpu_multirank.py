@@ -1,6 +1,8 @@
-"""-m gpu: the N > 1 DEVICE path on a one-GPU box — two processes share GPU 0, each owns its shard of the edges and runs
-the real kernels; the per-edge blocks / counts are exchanged through the host-staged callback (gloo) instead of RCCL
-(RCCL refuses two ranks on one device).  Poses must be bit-identical to the single-process run."""
+"""-m gpu: the N > 1 DEVICE path on a one-GPU box — `world` processes share GPU 0, each owns its shard of the edges and runs
+the real kernels; the exchanged buffer ([queued blocks | counts | medians | armed | scales] per search, the per-edge blocks per LM
+evaluation) goes through the host-staged callback (gloo) instead of RCCL (RCCL refuses two ranks on one device) — the same code path
+in api.cpp as the RCCL one up to the transport call.  Poses, counts and weights must be bit-identical to the single-process run for
+world = 2, 4 and 8 (62 -> 7-8 edges per rank on config 4; here 18 edges over up to 8 ranks)."""
 import os
 import socket
 import sys
@@ -13,32 +15,37 @@ import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROUNDS = 8
 
 
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _run(rank, world, reduce_fn):
+def _run(rank, world, reduce_fn, spec=1):
     sys.path.insert(0, os.path.join(ROOT, "mv-lm-icp_amd"))
     import mvicp
     from mvicp import synth
-    pb = synth.make_problem(6, 5000)
+    pb = synth.make_problem(10, 4000)
     eng = mvicp.Engine(0, rank=rank, world=world)
+    eng.set_option("spec_eval", spec)
     eng.set_frames(pb["pts"], pb["nor"]); eng.set_graph(pb["src"], pb["dst"])
     if reduce_fn is not None:
         eng.comm_set_callback(reduce_fn)
+    eng.profile(True)
     poses = pb["init"].copy()
     hist = []
-    for _ in range(5):
+    for _ in range(ROUNDS):
         c, w = eng.correspond(poses, pb["fixed"], 0.05)
         poses, sm = eng.optimize(poses, pb["fixed"])
-        hist.append((c.copy(), w.copy(), sm["iterations"]))
+        hist.append((c.copy(), w.copy(), sm["iterations"], sm["evaluations"]))
+    hits = eng.profile_get("spec.hit")[1]
+    comms = eng.profile_get("comm")[1]
     eng.close()
-    return poses, hist
+    return poses, hist, hits, comms
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, spec):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
 
@@ -46,17 +53,44 @@ def _worker(rank, world, port, out):
         t = torch.from_numpy(a)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
-    poses, hist = _run(rank, world, allreduce)
-    if rank == 0:
-        np.save(out, poses)
+    poses, hist, hits, comms = _run(rank, world, allreduce, spec)
+    np.save(f"{out}.{rank}.npy", poses)
+    np.save(f"{out}.{rank}.counts.npy", np.array([h[0] for h in hist]))
+    np.save(f"{out}.{rank}.meta.npy", np.array([hits, comms, sum(h[3] for h in hist)]))
+    dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
-def test_two_ranks_on_one_gpu_match_single_process_bitwise(tmp_path):
-    out = str(tmp_path / "poses.npy")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
-    P2 = np.load(out)
-    P1, hist = _run(0, 1, None)
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,spec", [(2, 1), (2, 0), (4, 1), (8, 1)])
+def test_ranks_on_one_gpu_match_single_process_bitwise(tmp_path, world, spec):
+    sys.path.insert(0, os.path.join(ROOT, "mv-lm-icp_amd"))
+    from mvicp import lib as L
+    from mvicp import synth
+    out = str(tmp_path / "poses")
+    mp.spawn(_worker, args=(world, _free_port(), out, spec), nprocs=world, join=True)
+    P1, hist, hits1, _ = _run(0, 1, None, spec)
     assert hist[-1][2] >= 1
-    assert np.array_equal(P1, P2), np.abs(P1 - P2).max()
+    for r in range(world):
+        P2 = np.load(f"{out}.{r}.npy")
+        assert np.array_equal(P1, P2), (r, np.abs(P1 - P2).max())
+        assert np.array_equal(np.load(f"{out}.{r}.counts.npy"), np.array([h[0] for h in hist]))   # every rank holds the global counts
+        hits, comms, evals = np.load(f"{out}.{r}.meta.npy")
+        assert hits == hits1 == (ROUNDS - 1 if spec else 0), (r, hits, hits1)                     # the queued evaluation is served on every rank
+        assert comms == ROUNDS + evals - hits, (r, comms, evals, hits)                            # one exchange per search + one per evaluated LM step
+    # partition: contiguous, balanced by source points (mvicp_edge_owner)
+    pb = synth.make_poses(10)
+    own = L.edge_owner([4000] * len(pb["src"]), world)
+    assert np.all(np.diff(own) >= 0) and own[0] == 0 and own[-1] == world - 1
+    sizes = np.bincount(own, minlength=world)
+    assert sizes.max() - sizes.min() <= 1, sizes
+
+
+def test_partition_of_config4_and_config5_over_8_ranks():
+    """62 edges -> 7-8 per rank, 126 -> 15-16 per rank, contiguous chunks."""
+    sys.path.insert(0, os.path.join(ROOT, "mv-lm-icp_amd"))
+    from mvicp import lib as L
+    for E, lo, hi in ((62, 7, 8), (126, 15, 16)):
+        own = L.edge_owner([200000] * E, 8)
+        sizes = np.bincount(own, minlength=8)
+        assert sizes.min() >= lo and sizes.max() <= hi and np.all(np.diff(own) >= 0), sizes

@@ -394,14 +394,49 @@ def test_rccl_communicator_single_rank(orc):
     assert np.array_equal(ca, cb) and np.array_equal(wa, wb) and np.array_equal(ba, bb)
     Pa, _ = a.optimize(pb["init"], pb["fixed"]); Pb, _ = b.optimize(pb["init"], pb["fixed"])
     assert np.array_equal(Pa, Pb)
-    # later rounds: the speculative first evaluation goes through the communicator too (device buffer -> all-reduce -> pinned copy)
+    # later rounds: ONE collective per search — [queued first evaluation's blocks | counts | medians | armed | scales] — and one per
+    # further LM evaluation (device buffer -> all-reduce -> pinned copy); through the moving rounds, the bracket select and the fixed point
     b.profile(True)
-    for _ in range(3):
-        a.correspond(Pa, pb["fixed"], 0.05); b.correspond(Pb, pb["fixed"], 0.05)
-        Pa, _ = a.optimize(Pa, pb["fixed"]); Pb, _ = b.optimize(Pb, pb["fixed"])
-        assert np.array_equal(Pa, Pb)
-    assert b.profile_get("spec.hit")[1] == 3
+    rounds = 12
+    for r in range(rounds):
+        b.profile_reset()
+        ca, wa = a.correspond(Pa, pb["fixed"], 0.05); cb, wb = b.correspond(Pb, pb["fixed"], 0.05)
+        assert np.array_equal(ca, cb) and wa.tobytes() == wb.tobytes(), r
+        assert b.profile_get("comm")[1] == 1, (r, b.profile_get("comm"))                 # the search: exactly one exchange
+        Pa, sa = a.optimize(Pa, pb["fixed"]); Pb, sb = b.optimize(Pb, pb["fixed"])
+        assert np.array_equal(Pa, Pb) and sa == sb, r
+        assert b.profile_get("spec.hit")[1] == 1, r
+        assert b.profile_get("comm")[1] == 1 + sb["evaluations"] - 1, (r, sb)            # + one per evaluation the queued launch did not serve
+    assert sb["successful_steps"] == 0                                                   # the loop reached the fixed point
+    # a rank whose history is gone (new registration) does not arm: same collective, nothing queued, same results
+    a.reset_history(); b.reset_history()
+    ca, wa = a.correspond(pb["init"], pb["fixed"], 0.05); cb, wb = b.correspond(pb["init"], pb["fixed"], 0.05)
+    assert np.array_equal(ca, cb) and wa.tobytes() == wb.tobytes()
+    Pa, sa = a.optimize(pb["init"], pb["fixed"]); Pb, sb = b.optimize(pb["init"], pb["fixed"])
+    assert np.array_equal(Pa, Pb) and sa == sb
     a.close(); b.close()
+
+
+def test_reset_history_replays_the_registration_bit_for_bit():
+    """mvicp_reset_history = a fresh run of the reference program on the same clouds and graph: a second registration from the same
+    initial poses walks through exactly the same poses, counts, weights and LM summaries as the first (no cross-registration state)."""
+    pb = synth.make_problem(4, 6000)
+    eng = mvicp.Engine(0)
+    eng.set_frames(pb["pts"], pb["nor"]); eng.set_graph(pb["src"], pb["dst"])
+    runs = []
+    for reg in range(2):
+        if reg:
+            eng.reset_history()
+        P = pb["init"].copy()
+        log = []
+        for _ in range(10):
+            c, w = eng.correspond(P, pb["fixed"], 0.05)
+            P, sm = eng.optimize(P, pb["fixed"])
+            log.append((c.copy(), w.copy(), P.copy(), sm))
+        runs.append(log)
+    for x, y in zip(*runs):
+        assert np.array_equal(x[0], y[0]) and x[1].tobytes() == y[1].tobytes() and np.array_equal(x[2], y[2]) and x[3] == y[3]
+    eng.close()
 
 
 def test_sharded_contexts_sum_to_the_unsharded_blocks():

@@ -3,13 +3,13 @@
 #   pass 1: --kernel-trace --stats                (per-kernel time)
 #   pass 2: --pmc FETCH_SIZE   (+ --kernel-trace) (TCC fetch bytes, own run: 3 of 4 TCC slots)
 #   pass 3: --pmc WRITE_SIZE   (+ --kernel-trace)
-# usage: bash tools/profile.sh <workload> <warmup> <steps>      ->  gpurun_out/prof/r02_<workload>_w<W>s<K>/
+# usage: bash tools/profile.sh <workload> <warmup> <steps>      ->  gpurun_out/prof/r03_<workload>_w<W>s<K>/
 # tools/summarize_prof.py turns the CSVs into <tag>_summary.txt / <tag>_kernels.json (copy those into profiles/): per-kernel tables
 # plus the two bench scopes restricted to the TIMED rounds, and the hash of the device sources (bench.py quotes `traffic` from the
 # JSON only when workload, warm-up, steps and that hash all match its own run).
 set -u
 WL=${1:-cfg4}; W=${2:-1}; K=${3:-19}
-TAG=r02_${WL}_w${W}s${K}
+TAG=${ROUND:-r03}_${WL}_w${W}s${K}
 CMD="python bench.py --workload $WL --warmup $W --steps $K --no-cpu-baseline --no-replay"
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
