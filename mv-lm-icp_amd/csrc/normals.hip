@@ -6,10 +6,22 @@
 // k-NN through the spatial hash built at upload: scan the (2r+1)^3 cell block around the point's own cell keeping the
 // k best (d2, sorted position) in registers; the set is provably exact once the k-th distance is below the distance
 // to the block faces (>= r h); r grows until that holds (r = 1 almost always: cells hold ~6 points).  Distances use
-// the reference metric (include/frame.h:70-76, no fma); ties on the k-th distance are broken by original index.
+// the reference metric (include/frame.h:70-76, no fma).
+// EXACT TIES.  The reference's clouds are range-image lattices (z quantised to 1 mm): 7 % of the Bunny points have a tie at the 10th
+// place, and which of the tied points nanoflann returns is decided by the order in which its KD-tree visits them
+// (KNNResultSet::addPoint keeps what came first, nanoflann.hpp:75-134; searchLevel visits the near child first, :1199-1247).  A
+// "lowest index" rule picks a different neighbour set for 2-4 % of the points (normals up to 20 degrees apart, final Bunny poses 4.5e-5
+// apart after 20 rounds).  So equal distances are ordered the way that tree would visit them: VisitTree below is the split structure
+// nanoflann builds for this cloud (leaf size 1, frame.cpp:189), restated from the published algorithm, and two tied points are ordered by
+// their lowest common ancestor — the child on the query's side of the split plane is visited first.  Result lists then equal
+// knnSearch's element for element (order included: equal distances appear in visit order there too).
 // The 3x3 symmetric eigenproblem is solved by cyclic Jacobi rotations in fp64 (Eigen's SelfAdjointEigenSolver is an
 // iterative QR on the same matrix: the eigenvector agrees to rounding, not bit for bit).
+#include <algorithm>
+#include <vector>
+
 #include "common.h"
+#include "kdvisit.h"
 
 namespace mvicp {
 
@@ -27,6 +39,7 @@ __device__ __forceinline__ unsigned long long cell_key(int ix, int iy, int iz) {
 __device__ __forceinline__ unsigned int hash_slot(unsigned long long k, int shift) { return (unsigned int)((k * 0x9E3779B97F4A7C15ull) >> shift); }
 
 struct NormJob {
+  VisitTree tie;
   const PointRec* srec; int n;   // records in hash-CELL order (GridDev::crec)
   const int* inv;                // original index -> sorted (canonical) position
   const HashEntry* table; unsigned int mask; int shift;
@@ -35,7 +48,7 @@ struct NormJob {
   int k;
   double* nor_out;   // n x 3, original order
   double* snor_out;  // n x 3, sorted order (what the gather kernel reads)
-  int* knn_out;      // n x k original indices (optional, for tests), sorted by (d2, index)
+  int* knn_out;      // n x k original indices (optional, for tests), ascending distance, equal distances in the tree's visit order
 };
 
 __device__ __forceinline__ void jacobi_min_eigvec(double a00, double a01, double a02, double a11, double a12, double a22, double* v) {
@@ -106,12 +119,12 @@ __global__ __launch_bounds__(NT) void normals_kernel(NormJob job) {
             const PointRec p = job.srec[j];
             const double d0 = __dsub_rn(me.x, p.x), d1 = __dsub_rn(me.y, p.y), d2 = __dsub_rn(me.z, p.z);
             const double d = __dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2));
-            if (d < bd[K - 1] || (d == bd[K - 1] && p.idx < bo[K - 1])) {
+            if (d < bd[K - 1] || (d == bd[K - 1] && bj[K - 1] >= 0 && visited_before(job.tie, me.x, me.y, me.z, p.idx, bo[K - 1])) || (d == bd[K - 1] && bj[K - 1] < 0)) {
               // insertion into the sorted top-K (static indexing so the lists stay in registers)
               double cd = d; int cj = (int)j; long long co = p.idx;
 #pragma unroll
               for (int t = 0; t < KMAX; ++t) {
-                if (t < K && (cd < bd[t] || (cd == bd[t] && co < bo[t]))) {
+                if (t < K && (cd < bd[t] || (cd == bd[t] && (bj[t] < 0 || visited_before(job.tie, me.x, me.y, me.z, co, bo[t]))))) {
                   const double td = bd[t]; const int tj = bj[t]; const long long to = bo[t];
                   bd[t] = cd; bj[t] = cj; bo[t] = co;
                   cd = td; cj = tj; co = to;
@@ -153,7 +166,7 @@ __global__ __launch_bounds__(NT) void normals_kernel(NormJob job) {
   if (job.knn_out) {
 #pragma unroll
     for (int t = 0; t < KMAX; ++t)
-      if (t < K) job.knn_out[(size_t)me.idx * K + t] = bj[t] >= 0 ? (int)bo[t] : -1;
+      if (t < K) job.knn_out[(size_t)me.idx * K + t] = bj[t] >= 0 ? (int)bo[t] : -1;   // nanoflann's result order
   }
 }
 
@@ -162,16 +175,33 @@ __global__ __launch_bounds__(NT) void normals_kernel(NormJob job) {
 int launch_normals(mvicp_ctx* c, FrameDev& f, int k, int* d_knn) {
   if (!f.has_grid) { set_error("normals need the per-cloud hash structure"); return MVICP_ERR_STATE; }
   if (k < 3 || k > KMAX) { set_error("k = %d outside [3, %d]", k, KMAX); return MVICP_ERR_ARG; }
+  // tie order: nanoflann's tree for this cloud (host, O(n log n), one-off like the reference's own lazy build, frame.cpp:209-214)
+  std::vector<double> h_xyz(3 * (size_t)f.n);
+  MV_HIP(hipMemcpy(h_xyz.data(), f.pts, sizeof(double) * 3 * (size_t)f.n, hipMemcpyDeviceToHost));
+  std::vector<VisitNode> nodes; std::vector<int> slot;
+  MV_CHECK(build_visit_tree(h_xyz.data(), f.n, nodes, slot));
+  VisitNode* d_nodes = nullptr; int* d_slot = nullptr;
+  MV_HIP(hipMalloc((void**)&d_nodes, sizeof(VisitNode) * nodes.size()));
+  if (hipMalloc((void**)&d_slot, sizeof(int) * (size_t)f.n) != hipSuccess) { (void)hipFree(d_nodes); set_error("out of device memory (visit tree)"); return MVICP_ERR_HIP; }
+  hipError_t e1 = hipMemcpy(d_nodes, nodes.data(), sizeof(VisitNode) * nodes.size(), hipMemcpyHostToDevice);
+  hipError_t e2 = hipMemcpy(d_slot, slot.data(), sizeof(int) * (size_t)f.n, hipMemcpyHostToDevice);
   NormJob j;
   const GridDev& g = f.grid;
+  j.tie.nodes = d_nodes; j.tie.slot = d_slot;
   j.srec = (const PointRec*)g.crec; j.inv = g.inv; j.n = f.n;
   j.table = (const HashEntry*)g.table; j.mask = g.table_mask; j.shift = g.table_shift;
   j.ox = g.origin[0]; j.oy = g.origin[1]; j.oz = g.origin[2]; j.h = g.cell; j.inv_h = g.inv_cell;
   j.dx = g.dims[0]; j.dy = g.dims[1]; j.dz = g.dims[2];
   j.k = k; j.nor_out = f.nor; j.snor_out = f.grid.snor; j.knn_out = d_knn;
-  ProfScope ps(c, "normals", 0.0);
-  hipLaunchKernelGGL(normals_kernel, dim3((f.n + NT - 1) / NT), dim3(NT), 0, c->stream, j);
-  MV_HIP(hipGetLastError());
+  hipError_t e3 = hipSuccess;
+  if (e1 == hipSuccess && e2 == hipSuccess) {
+    ProfScope ps(c, "normals", 0.0);
+    hipLaunchKernelGGL(normals_kernel, dim3((f.n + NT - 1) / NT), dim3(NT), 0, c->stream, j);
+    e3 = hipGetLastError();
+  }
+  const hipError_t e4 = hipStreamSynchronize(c->stream);   // the tree buffers are freed below
+  (void)hipFree(d_nodes); (void)hipFree(d_slot);
+  for (hipError_t e : {e1, e2, e3, e4}) if (e != hipSuccess) { set_error("normals: %s", hipGetErrorString(e)); return MVICP_ERR_HIP; }
   return MVICP_OK;
 }
 

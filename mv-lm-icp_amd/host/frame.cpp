@@ -145,28 +145,43 @@ void Frame::recomputeNormals() {
   ++version;   // a bound session re-uploads this cloud (new normals) at its next bind
 }
 
-double Frame::getClosestPoint(const Vector3d& q, size_t& ret_index) {
-  // frame.cpp:187-206.  The reference builds this frame's KD-tree lazily on first use; here the frame's structure already
-  // lives in the bound session (uploaded by computeClosestPointsToNeighbours / ceresOptimizer*), found by frame index.  A frame
-  // that is not part of the bound vector gets a one-cloud side context owned by the session (built on first use, like the
-  // reference's lazy tree; rebuilt when the cloud changes).
-  Session& S = Session::get();
-  if (pts.empty()) throw std::runtime_error("mvicp: getClosestPoint on an empty cloud (nanoflann throws here: nanoflann.hpp:904)");
-  int idx = -1;
-  double d2 = 0.0;
-  const int fi = S.ctx ? S.frame_index(this) : -1;
-  if (fi >= 0 && S.frame_keys[fi].pts == (const void*)pts[0].data() && S.frame_keys[fi].n == pts.size()) {
-    check(mvicp_nn_query(S.ctx, fi, q.data(), 1, MVICP_NN_AUTO, &idx, &d2));
-  } else {
-    if (S.side_owner != this || S.side_version != version || !S.side_ctx) {
-      if (!S.side_ctx) check(mvicp_create(S.device, &S.side_ctx));
-      check(mvicp_set_num_frames(S.side_ctx, 1));
-      check(mvicp_set_frame(S.side_ctx, 0, pts[0].data(), nullptr, (int)pts.size()));
-      S.side_owner = this; S.side_version = version;
-    }
-    check(mvicp_nn_query(S.side_ctx, 0, q.data(), 1, MVICP_NN_AUTO, &idx, &d2));
+mvicp_ctx* Session::query_context(Frame* f, int* slot) {
+  // frame.cpp:187-206.  The reference builds the frame's KD-tree lazily on first use; here the frame's structure already lives in the
+  // bound session (uploaded by computeClosestPointsToNeighbours / ceresOptimizer*), found by frame index.  A frame that is not part
+  // of the bound vector gets a one-cloud side context owned by the session (built on first use, like the reference's lazy tree;
+  // rebuilt when the cloud changes).
+  if (f->pts.empty()) throw std::runtime_error("mvicp: getClosestPoint on an empty cloud (nanoflann throws here: nanoflann.hpp:904)");
+  const int fi = ctx ? frame_index(f) : -1;
+  if (fi >= 0 && frame_keys[fi].pts == (const void*)f->pts[0].data() && frame_keys[fi].n == f->pts.size()) { *slot = fi; return ctx; }
+  if (side_owner != f || side_version != f->version || !side_ctx) {
+    if (!side_ctx) check(mvicp_create(device, &side_ctx));
+    check(mvicp_set_num_frames(side_ctx, 1));
+    check(mvicp_set_frame(side_ctx, 0, f->pts[0].data(), nullptr, (int)f->pts.size()));
+    side_owner = f; side_version = f->version;
   }
+  *slot = 0;
+  return side_ctx;
+}
+
+double Frame::getClosestPoint(const Vector3d& q, size_t& ret_index) {
+  int slot = 0, idx = -1;
+  double d2 = 0.0;
+  mvicp_ctx* c = Session::get().query_context(this, &slot);
+  check(mvicp_nn_query(c, slot, q.data(), 1, MVICP_NN_AUTO, &idx, &d2));
   ret_index = (size_t)idx;
+  return d2;
+}
+
+std::vector<double> Frame::getClosestPoints(const std::vector<Vector3d>& q, std::vector<size_t>& ret_index) {
+  int slot = 0;
+  mvicp_ctx* c = Session::get().query_context(this, &slot);
+  const int n = (int)q.size();
+  std::vector<double> d2(q.size());
+  std::vector<int> idx(q.size());
+  ret_index.resize(q.size());
+  if (n == 0) return d2;
+  check(mvicp_nn_query(c, slot, q[0].data(), n, MVICP_NN_AUTO, idx.data(), d2.data()));
+  for (int i = 0; i < n; ++i) ret_index[i] = (size_t)idx[i];
   return d2;
 }
 

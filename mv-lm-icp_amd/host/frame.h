@@ -42,6 +42,10 @@ class Frame {
   void computeClosestPointsToNeighbours(std::vector<std::shared_ptr<Frame>>* frames, float thresh);
   // frame.cpp:187-206: query in this frame's local coordinates -> squared distance, index
   double getClosestPoint(const Vector3d& query_pt, size_t& ret_index);
+  // Batched form of the same call (no counterpart in the reference, whose loop asks one query at a time, frame.cpp:138): ONE device
+  // launch + ONE copy for all queries instead of a launch and a synchronisation per query.  ret_index[i] / returned[i] are exactly
+  // what getClosestPoint(query_pts[i], ret_index[i]) returns.  Use this in any loop over queries.
+  std::vector<double> getClosestPoints(const std::vector<Vector3d>& query_pts, std::vector<size_t>& ret_index);
   // frame.cpp:244-255: PCA normals from the 10 nearest points (self included), n_z <= 0; overwrites `nor`
   void recomputeNormals();
 };
@@ -66,6 +70,8 @@ struct Session {
   float last_thresh = -1.f;
   mvicp_ctx* side_ctx = nullptr; const Frame* side_owner = nullptr; unsigned long long side_version = 0;  // getClosestPoint on an unbound frame
   int frame_index(const Frame* f) const;   // position of f in the bound vector, or -1
+  // context + frame slot that hold `f`'s cloud for raw queries: the bound session if f is part of it, else a one-cloud side context
+  mvicp_ctx* query_context(Frame* f, int* slot);
   void invalidate();                       // forget the device copy (forces re-upload + fresh search); for in-place edits of pts/nor data
   std::vector<int> counts;
   std::vector<float> weights;

@@ -81,21 +81,30 @@ int main(int argc, char** argv) {
       if (r == rounds - 1 && F.i("check_nn", 0) > 0) {
         // S1' through the Frame mirror: q = dst.pose^-1 * (src.pose * p) (frame.cpp:131,136) -> dst.getClosestPoint(q) must give
         // the correspondence's neighbour and distance
-        long checked = 0, bad = 0;
+        long checked = 0, bad = 0, single = 0;
         for (size_t i = 0; i < frames.size(); ++i)
           for (const OutgoingEdge& e : frames[i]->neighbours) {
             Frame& d = *frames[e.neighbourIdx];
             const Isometry3d M = d.pose.inverse() * frames[i]->pose;
             const int n = std::min<int>(F.i("check_nn", 0), (int)e.correspondances.size());
+            // the batched form (one launch for the edge's queries) ...
+            std::vector<Vector3d> qs(n);
+            for (int k = 0; k < n; ++k) qs[k] = M * frames[i]->pts[e.correspondances[k].first];
+            std::vector<size_t> idxs;
+            const std::vector<double> d2s = d.getClosestPoints(qs, idxs);
             for (int k = 0; k < n; ++k) {
               const Correspondance& c = e.correspondances[k];
-              size_t idx = 0;
-              const double d2 = d.getClosestPoint(M * frames[i]->pts[c.first], idx);
               ++checked;
-              if ((int)idx != c.second || std::fabs(std::sqrt(d2) - c.dist) > 1e-12) ++bad;
+              if ((int)idxs[k] != c.second || std::fabs(std::sqrt(d2s[k]) - c.dist) > 1e-12) ++bad;
+              if (k < 8) {   // ... and the reference's one-query signature on a few of them: identical answers
+                size_t idx = 0;
+                const double d2 = d.getClosestPoint(qs[k], idx);
+                ++single;
+                if (idx != idxs[k] || d2 != d2s[k]) ++bad;
+              }
             }
           }
-        std::cout << "getClosestPoint check: " << checked << " queries, " << bad << " mismatches" << std::endl;
+        std::cout << "getClosestPoint check: " << checked << " queries, " << bad << " mismatches (" << single << " also asked one by one)" << std::endl;
       }
       if (sophusSE3) ICP_Ceres::ceresOptimizer_sophusSE3(frames, pointToPlane, robust);
       else if (angleAxis) ICP_Ceres::ceresOptimizer_ceresAngleAxis(frames, pointToPlane, robust);

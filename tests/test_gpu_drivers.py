@@ -7,6 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
+import cpupath
 import mvicp
 from mvicp import lib as L
 from mvicp import synth
@@ -43,6 +44,17 @@ def test_multiview_driver_matches_engine_loop(tmp_path, flags, param, plane):
         poses, sm = eng.optimize(poses, pb["fixed"], param, plane, True, 50)
     eng.close()
     assert np.allclose(got, poses, rtol=0, atol=1e-14), np.abs(got - poses).max()
+    # ... and PARITY: the reference-equivalent CPU path (real nanoflann + oracle LM; tests/cpupath.py) on the driver's graph, from the same
+    # files' poses, same 4 rounds — the driver's final poses within 1e-9 m / rad of it
+    cpu = cpupath.CpuPath(pb["pts"], pb["nor"], src, dst, pb["fixed"], param, plane)
+    Pc = pb["init"].copy()
+    for _ in range(4):
+        Pc, smc = cpu.round(Pc)
+    cpu.close()
+    assert smc["iterations"] == sm["iterations"], (smc, sm)
+    for k in range(5):
+        dt, dr = synth.pose_diff(got[k], Pc[k])
+        assert dt < 1e-9 and dr < 1e-9, (k, dt, dr)
 
 
 def test_correspondence_copy_back_through_frame_api(tmp_path):
