@@ -27,7 +27,7 @@ namespace mvicp {
 
 namespace {
 
-constexpr int NT = 256;
+constexpr int NT = 128;     // per-thread candidate lists live in LDS: KMAX x NT x 20 B = 40 KB per workgroup
 constexpr int KMAX = 16;
 constexpr unsigned long long EMPTY = ~0ull;
 
@@ -97,16 +97,21 @@ __global__ __launch_bounds__(NT) void normals_kernel(NormJob job) {
   if (i >= job.n) return;
   const PointRec me = job.srec[i];
   const int K = job.k;
-  double bd[KMAX];
-  int bj[KMAX];       // cell-order positions of the current k best
-  long long bo[KMAX]; // their original indices (tie rule)
+  // the thread's current k best, ascending: distance, cell-order position, original index.  In LDS (one column per thread, no bank
+  // conflicts) rather than in register arrays: the insertion below indexes them at run time, and this kernel runs once per cloud
+  __shared__ double s_bd[KMAX][NT];
+  __shared__ int s_bj[KMAX][NT];
+  __shared__ long long s_bo[KMAX][NT];
+#define bd(t) s_bd[t][threadIdx.x]
+#define bj(t) s_bj[t][threadIdx.x]
+#define bo(t) s_bo[t][threadIdx.x]
   const int cx = min(max((int)floor((me.x - job.ox) * job.inv_h), 0), job.dx - 1);
   const int cy = min(max((int)floor((me.y - job.oy) * job.inv_h), 0), job.dy - 1);
   const int cz = min(max((int)floor((me.z - job.oz) * job.inv_h), 0), job.dz - 1);
   const int rmax = max(job.dx, max(job.dy, job.dz));
   for (int r = 1;; ++r) {
 #pragma unroll
-    for (int t = 0; t < KMAX; ++t) { bd[t] = 1.7976931348623157e308; bj[t] = -1; bo[t] = 0x7fffffffffffffffLL; }
+    for (int t = 0; t < KMAX; ++t) { bd(t) = 1.7976931348623157e308; bj(t) = -1; bo(t) = 0x7fffffffffffffffLL; }
     for (int iz = max(cz - r, 0); iz <= min(cz + r, job.dz - 1); ++iz)
       for (int iy = max(cy - r, 0); iy <= min(cy + r, job.dy - 1); ++iy)
         for (int ix = max(cx - r, 0); ix <= min(cx + r, job.dx - 1); ++ix) {
@@ -119,18 +124,19 @@ __global__ __launch_bounds__(NT) void normals_kernel(NormJob job) {
             const PointRec p = job.srec[j];
             const double d0 = __dsub_rn(me.x, p.x), d1 = __dsub_rn(me.y, p.y), d2 = __dsub_rn(me.z, p.z);
             const double d = __dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2));
-            if (d < bd[K - 1] || (d == bd[K - 1] && bj[K - 1] >= 0 && visited_before(job.tie, me.x, me.y, me.z, p.idx, bo[K - 1])) || (d == bd[K - 1] && bj[K - 1] < 0)) {
-              // insertion into the sorted top-K (static indexing so the lists stay in registers)
-              double cd = d; int cj = (int)j; long long co = p.idx;
-#pragma unroll
-              for (int t = 0; t < KMAX; ++t) {
-                if (t < K && (cd < bd[t] || (cd == bd[t] && (bj[t] < 0 || visited_before(job.tie, me.x, me.y, me.z, co, bo[t]))))) {
-                  const double td = bd[t]; const int tj = bj[t]; const long long to = bo[t];
-                  bd[t] = cd; bj[t] = cj; bo[t] = co;
-                  cd = td; cj = tj; co = to;
-                }
-              }
-
+            // sorted insertion (ascending distance; equal distances in the tree's visit order).  One comparator call site, plain indexed
+            // arrays: this kernel runs once per cloud, simplicity beats register residency here.
+            int pos = K;
+            while (pos > 0) {
+              const double ed = bd(pos - 1);
+              bool before = d < ed;
+              if (!before && d == ed) before = bj(pos - 1) < 0 || visited_before(job.tie, me.x, me.y, me.z, p.idx, bo(pos - 1));
+              if (!before) break;
+              --pos;
+            }
+            if (pos < K) {
+              for (int t = K - 1; t > pos; --t) { bd(t) = bd(t - 1); bj(t) = bj(t - 1); bo(t) = bo(t - 1); }
+              bd(pos) = d; bj(pos) = (int)j; bo(pos) = p.idx;
             }
           }
         }
@@ -139,21 +145,21 @@ __global__ __launch_bounds__(NT) void normals_kernel(NormJob job) {
     const double w = (2 * r + 1) * job.h;
     double m = fmin(fmin(me.x - fx, fx + w - me.x), fmin(fmin(me.y - fy, fy + w - me.y), fmin(me.z - fz, fz + w - me.z)));
     m *= 0.999;
-    const bool full = bj[K - 1] >= 0;
-    if ((full && m > 0.0 && bd[K - 1] < m * m) || r >= rmax) break;
+    const bool full = bj(K - 1) >= 0;
+    if ((full && m > 0.0 && bd(K - 1) < m * m) || r >= rmax) break;
   }
   // PCA of the neighbours (common.h:331-346)
   double mx = 0, my = 0, mz = 0;
   int kk = 0;
 #pragma unroll
   for (int t = 0; t < KMAX; ++t)
-    if (t < K && bj[t] >= 0) { const PointRec p = job.srec[bj[t]]; mx += p.x; my += p.y; mz += p.z; ++kk; }
+    if (t < K && bj(t) >= 0) { const PointRec p = job.srec[bj(t)]; mx += p.x; my += p.y; mz += p.z; ++kk; }
   mx /= kk; my /= kk; mz /= kk;
   double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
 #pragma unroll
   for (int t = 0; t < KMAX; ++t)
-    if (t < K && bj[t] >= 0) {
-      const PointRec p = job.srec[bj[t]];
+    if (t < K && bj(t) >= 0) {
+      const PointRec p = job.srec[bj(t)];
       const double x = p.x - mx, y = p.y - my, z = p.z - mz;
       c00 += x * x; c01 += x * y; c02 += x * z; c11 += y * y; c12 += y * z; c22 += z * z;
     }
@@ -166,9 +172,13 @@ __global__ __launch_bounds__(NT) void normals_kernel(NormJob job) {
   if (job.knn_out) {
 #pragma unroll
     for (int t = 0; t < KMAX; ++t)
-      if (t < K) job.knn_out[(size_t)me.idx * K + t] = bj[t] >= 0 ? (int)bo[t] : -1;   // nanoflann's result order
+      if (t < K) job.knn_out[(size_t)me.idx * K + t] = bj(t) >= 0 ? (int)bo(t) : -1;   // nanoflann's result order
   }
 }
+
+#undef bd
+#undef bj
+#undef bo
 
 }  // namespace
 

@@ -1,0 +1,38 @@
+"""A/B of tile-kernel variants on the GPU box: per-round NN stage ms of the AUTO method (and the forced tile method) for each option set,
+with a bit-exactness check of every variant's counts / weights / poses against the first one.
+    python tools/tile_ab.py K N ROUNDS "name=value,name=value" "..." ...      (an empty string = library defaults)"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mv-lm-icp_amd"))
+import numpy as np
+import mvicp
+from mvicp import lib as L, synth
+K, N, R = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+variants = sys.argv[4:] or [""]
+method = {"auto": L.NN_AUTO, "tile": L.NN_TILE}[os.environ.get("AB_METHOD", "auto")]
+pb = synth.make_problem(K, N)
+ref = None
+for v in variants:
+    eng = mvicp.Engine(0)
+    for kv in [x for x in v.split(",") if x]:
+        k, val = kv.split("="); eng.set_option(k, float(val))
+    eng.set_frames(pb["pts"], pb["nor"]); eng.set_graph(pb["src"], pb["dst"])
+    eng.profile(True)
+    if os.environ.get("AB_CENSUS") == "1":
+        eng.set_option("nn_census", 1)
+    poses = pb["init"].copy(); rows = []; trace = []
+    for r in range(R):
+        eng.profile_reset()
+        c, w = eng.correspond(poses, pb["fixed"], 0.05, method)
+        ms = eng.profile_get("nn")[0]
+        cs = eng.nn_census() if os.environ.get("AB_CENSUS") == "1" else None
+        poses, sm = eng.optimize(poses, pb["fixed"], 2, 1, 1, 50)
+        rows.append(round(ms, 3) if cs is None else (round(ms, 3), round(cs["candidates"] / max(cs["queries"], 1), 1)))
+        trace.append((c.copy(), w.copy(), poses.copy()))
+    same = None
+    if ref is None:
+        ref = trace
+    else:
+        same = all(np.array_equal(a[0], b[0]) and a[1].tobytes() == b[1].tobytes() and np.array_equal(a[2], b[2]) for a, b in zip(ref, trace))
+    print(f"[{v or 'defaults'}] nn_ms per round: {rows}  sum {sum(x if not isinstance(x, tuple) else x[0] for x in rows):.3f}  identical_to_first: {same}", flush=True)
+    eng.close()
