@@ -962,8 +962,6 @@ int mvicp_set_option(mvicp_ctx* c, const char* name, double value) try {
   if (std::strcmp(name, "tile_bounds") == 0) { c->tile_bounds = (int)value; return MVICP_OK; }
   if (std::strcmp(name, "tile_mu") == 0) { if (!(value > 0.0 && value <= 1.0)) { set_error("tile_mu outside (0, 1]"); return MVICP_ERR_ARG; } c->tile_mu = value; return MVICP_OK; }
   if (std::strcmp(name, "tile_waves") == 0) { c->tile_waves = (int)value; return MVICP_OK; }
-  if (std::strcmp(name, "tile_opt") == 0) { c->tile_opt = (int)value; return MVICP_OK; }
-  if (std::strcmp(name, "tile_order") == 0) { c->tile_order = (int)value; return MVICP_OK; }
   if (std::strcmp(name, "spin_wait") == 0) { c->spin_wait = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "spec_eval") == 0) { c->spec_enable = value != 0.0; c->spec_ready = false; return MVICP_OK; }
   if (std::strcmp(name, "grid_target") == 0) {

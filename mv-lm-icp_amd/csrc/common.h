@@ -205,8 +205,6 @@ struct mvicp_ctx {
                                    // temporal-cache bounds, so the grid kernel starts with cache hits one round later and the uncached grid round — the
                                    // slowest of a registration — never runs); 2: every tile round leaves bounds (tests); 0: off
   double tile_mu = 0.05;           // BND guard band as a fraction of the target's hash-cell edge (same role as prune_rho in the grid kernel)
-  int tile_opt = -1;               // nn_tile_kernel OPT bits (A/B builds, depth-3 hierarchy only); -1 = the library default (kTileOpt, nn_tile.hip)
-  int tile_order = 0;              // FAST builds, seeded launches: 0 = children nearest-first only while the bounds are loose, 1 = always, 2 = never (A/B)
   int tile_waves = 0;              // nn_tile_kernel variant: waves per SIMD it is compiled for (0 = the measured best for the depth)
   double auto_prev_dist = 0.0; int auto_last_method = -1; double auto_settle = 0.5;   // MVICP_NN_AUTO policy state (api.cpp)
   double last_rms = -1.0;          // RMS residual at the end of the last mvicp_optimize since the last search (< 0: none): predicts the next NN distances

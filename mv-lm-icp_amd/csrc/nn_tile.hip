@@ -44,7 +44,6 @@ constexpr int NT = 256;
 #endif
 constexpr int LEAF = MVICP_TILE_LEAF;   // points per leaf tile (tuning builds may override; 32 measured best)
 constexpr int FAN = 64;    // children per node = one box per lane
-constexpr int kTileOpt = 3;   // default OPT bits of nn_tile_kernel (see launch_nn_tile_edges)
 
 struct TileView {
   const double* spts; const int* sidx; int n;
@@ -61,7 +60,6 @@ struct TileJob {
   int seed;         // out_idx still holds last round's neighbours (sorted positions, -1 = none): use them as starting candidates
   double* out_lb;   // BND builds: per query, a lower bound on the distance to every target other than out_idx (the grid kernel's temporal cache)
   float mu;         // BND builds: width of the extra guard band (metres) that makes that bound useful
-  int order;        // FAST builds, seeded launches: 0 = visit children nearest-first only while the bounds are loose, 1 = always, 2 = never
 };
 
 __device__ __forceinline__ void xf_point(const double* __restrict__ x, double p0, double p1, double p2, double& q0, double& q1, double& q2) {
@@ -154,17 +152,13 @@ struct Lane {          // per-lane query state
   double pad_;           // (keeps thr away from the pairs: no cross-field vector loads)
   float thr;             // fp32 screen threshold, always >= (sqrt(best) + slack + mu)^2 (see leaf_scan; mu = 0 unless BND)
   int bi;
-  int bpos;              // FAST builds: sorted position of the running best in the target cloud (-1: none) — its slot is not screened again
   bool active;
   double second;         // BND builds only: smallest exact d2 among the fp64-evaluated targets other than the running best
 };
 struct Group {         // wave-uniform patch description
-  double lo[3], hi[3], c[3];
-  float flo[3], fhi[3], fc[3];   // FAST builds: the same box in fp32, rounded OUTWARD (the coarse cull runs in fp32)
+  float lo[3], hi[3], c[3];   // the patch AABB in fp32, rounded OUTWARD, and its centre (the coarse cull runs in fp32)
   float slack;         // fp32 screening guard band (metres)
   float mu;            // BND builds: extra guard band (0 otherwise)
-  bool ordered;        // visit children nearest-first (unseeded launches: the running minima must tighten quickly); seeded FAST launches
-                       // start from tight bounds and take the children in index order (no wave arg-min per child)
 };
 
 // fp32 squared distance from the lane's query to a box.  Same guard-band argument as the point screen in leaf_scan: the
@@ -204,7 +198,7 @@ struct TileLds {   // per wave
 // everything that passes is evaluated exactly and the smallest d2 among those that are NOT the running best is kept in L.second.
 // min(sqrt(second), sqrt(best) + mu) is then a lower bound on the distance to every target other than the answer: the quantity the
 // grid kernel's temporal cache needs (GridJob::out_lb).
-template <bool BND, int OPT>
+template <bool BND>
 __device__ __forceinline__ void leaf_scan(const TileView& g, int leaf, Lane& L, float slack, float mu, TileLds* __restrict__ T, unsigned int* n_cand) {
   const int lane = threadIdx.x & 63;
   const int lo = leaf * LEAF;
@@ -229,12 +223,6 @@ __device__ __forceinline__ void leaf_scan(const TileView& g, int leaf, Lane& L, 
   // L.thr >= (sqrt(best) + slack)^2 at all times.  When a candidate with screen value d32 becomes the best, sqrt(best) <=
   // sqrt(d32) + slack, so (sqrt(d32) + 2 slack)^2 is a valid new threshold: one fp32 sqrt instead of an fp64 one per update.
   float thr = L.thr;
-  // FAST: the slot that holds the lane's running best (its seed, usually) is not screened again — re-confirming it cannot change anything,
-  // and in the seeded rounds it is most of what the confirmation blocks below used to be entered for (a block runs for the whole wave as
-  // soon as ONE lane has a hit in that slot)
-  unsigned allow = ~0u;
-  constexpr bool MASK = (OPT & 2) != 0;
-  if (MASK && L.bpos >= lo && L.bpos < lo + LEAF) allow = ~(1u << (L.bpos - lo));
   const float4* X4 = reinterpret_cast<const float4*>(T->fx);
   const float4* Y4 = reinterpret_cast<const float4*>(T->fy);
   const float4* Z4 = reinterpret_cast<const float4*>(T->fz);
@@ -245,20 +233,7 @@ __device__ __forceinline__ void leaf_scan(const TileView& g, int leaf, Lane& L, 
     const f2v ea = qx2 - xa, eb = qx2 - xb, fa = qy2 - ya, fb = qy2 - yb, ga = qz2 - za, gb = qz2 - zb;
     const f2v da = __builtin_elementwise_fma(ga, ga, __builtin_elementwise_fma(fa, fa, ea * ea));
     const f2v db = __builtin_elementwise_fma(gb, gb, __builtin_elementwise_fma(fb, fb, eb * eb));
-    unsigned hit;
-    if ((OPT & 16) != 0) {
-      // one compare per four candidates on the common path: the four-way minimum against the threshold (v_min3 + v_min + v_cmp instead of
-      // four compares and the mask assembly); the per-candidate bits are only worked out when some lane of the wave has a hit in the group
-      const float m4 = fminf(fminf(da.x, da.y), fminf(db.x, db.y));
-      hit = m4 <= thr ? 1u : 0u;
-      if (__ballot(hit != 0u) != 0ull) {
-        hit = (da.x <= thr ? 1u : 0u) | (da.y <= thr ? 2u : 0u) | (db.x <= thr ? 4u : 0u) | (db.y <= thr ? 8u : 0u);
-        if (MASK) hit &= allow >> (4 * k4);
-      } else hit = 0u;
-    } else {
-      hit = (da.x <= thr ? 1u : 0u) | (da.y <= thr ? 2u : 0u) | (db.x <= thr ? 4u : 0u) | (db.y <= thr ? 8u : 0u);
-      if (MASK) hit &= allow >> (4 * k4);
-    }
+    const unsigned hit = (da.x <= thr ? 1u : 0u) | (da.y <= thr ? 2u : 0u) | (db.x <= thr ? 4u : 0u) | (db.y <= thr ? 8u : 0u);
     if (hit) {
       const float d32[4] = {da.x, da.y, db.x, db.y};
 #pragma unroll
@@ -271,7 +246,7 @@ __device__ __forceinline__ void leaf_scan(const TileView& g, int leaf, Lane& L, 
             const int oi = T->id[k];
             if (d < L.best || (d == L.best && oi < L.bi)) {
               L.second = fmin(L.second, L.best);   // the old best (or the cutoff bound: only lowers the bound) is now "another target"
-              L.best = d; L.bi = oi; if (MASK) L.bpos = lo + k;
+              L.best = d; L.bi = oi;
               const float r = __builtin_amdgcn_sqrtf(d32[j]) * 1.000001f + 2.f * slack + mu;
               thr = fminf(thr, r * r * 1.000002f);
             } else if (oi != L.bi) {               // (the running best itself comes by again when its tile is scanned after a seed)
@@ -280,7 +255,7 @@ __device__ __forceinline__ void leaf_scan(const TileView& g, int leaf, Lane& L, 
           } else if (d <= L.best) {
             const int oi = T->id[k];
             if (d < L.best || oi < L.bi) {
-              L.best = d; L.bi = oi; if (MASK) L.bpos = lo + k;
+              L.best = d; L.bi = oi;
               const float r = __builtin_amdgcn_sqrtf(d32[j]) * 1.000001f + 2.f * slack;
               thr = fminf(thr, r * r * 1.000002f);
             }
@@ -298,12 +273,10 @@ __device__ __forceinline__ void leaf_scan(const TileView& g, int leaf, Lane& L, 
 // is live in all deeper levels.  Levels 1 and 2 therefore park their 64 child boxes in wave-private LDS (32 B each, read
 // back with one uniform-address load per step) and keep only {cull distance, order key, pending} per lane; level 0, the
 // hot one, keeps its boxes in registers and broadcasts them with v_readlane.
-template <int LEVEL, bool BND, int OPT>
+template <int LEVEL, bool BND>
 __device__ void visit(const TileView& g, int first, int nchild, Lane& L, const Group& G, TileLds* __restrict__ T,
                       float2* __restrict__ sbox, unsigned int* n_cand, unsigned int* n_box) {
-  constexpr bool F32CULL = (OPT & 1) != 0, UNORD = (OPT & 4) != 0;
-  constexpr bool LANE_TEST = !((OPT & 8) != 0 && LEVEL > 0);   // per-lane box test of each child (OPT bit 3: at the leaf level only — measured slower, off)
-  constexpr bool IN_LDS = LANE_TEST && (LEVEL == 1 || LEVEL == 2);
+  constexpr bool IN_LDS = LEVEL == 1 || LEVEL == 2;
   const int lane = threadIdx.x & 63;
   const float inf = __int_as_float(0x7f800000);
   float b0 = inf, b1 = inf, b2 = inf, b3 = -inf, b4 = -inf, b5 = -inf;
@@ -314,27 +287,17 @@ __device__ void visit(const TileView& g, int first, int nchild, Lane& L, const G
   }
   // coarse cull: child box vs the patch AABB; valid for every lane because lb_lane >= box-box distance
   float ddf, key;
-  if (F32CULL) {
-    // fp32 against the outward-rounded patch box: every operation rounds by <= 2^-24 relative, (1 - 1e-6) more than covers the five of them
-    const float e0 = fmaxf(fmaxf(b0 - G.fhi[0], G.flo[0] - b3), 0.f);
-    const float e1 = fmaxf(fmaxf(b1 - G.fhi[1], G.flo[1] - b4), 0.f);
-    const float e2 = fmaxf(fmaxf(b2 - G.fhi[2], G.flo[2] - b5), 0.f);
+  {
+    // fp32 against the outward-rounded patch box: every operation rounds by <= 2^-24 relative, (1 - 1e-6) more than covers the five of
+    // them, so ddf stays a lower bound of the box-to-patch distance (round 3: was fp64 — 12 conversions + ~20 fp64 operations per node)
+    const float e0 = fmaxf(fmaxf(b0 - G.hi[0], G.lo[0] - b3), 0.f);
+    const float e1 = fmaxf(fmaxf(b1 - G.hi[1], G.lo[1] - b4), 0.f);
+    const float e2 = fmaxf(fmaxf(b2 - G.hi[2], G.lo[2] - b5), 0.f);
     ddf = (e0 * e0 + e1 * e1 + e2 * e2) * 0.999999f;
-    if (G.ordered) {
-      const float k0 = fmaxf(fmaxf(b0 - G.fc[0], G.fc[0] - b3), 0.f);
-      const float k1 = fmaxf(fmaxf(b1 - G.fc[1], G.fc[1] - b4), 0.f);
-      const float k2 = fmaxf(fmaxf(b2 - G.fc[2], G.fc[2] - b5), 0.f);
-      key = k0 * k0 + k1 * k1 + k2 * k2;   // visiting order only
-    } else key = 0.f;
-  } else {
-    const double e0 = fmax(fmax((double)b0 - G.hi[0], G.lo[0] - (double)b3), 0.0);
-    const double e1 = fmax(fmax((double)b1 - G.hi[1], G.lo[1] - (double)b4), 0.0);
-    const double e2 = fmax(fmax((double)b2 - G.hi[2], G.lo[2] - (double)b5), 0.0);
-    ddf = (float)((e0 * e0 + e1 * e1 + e2 * e2) * (1.0 - 1e-6));   // rounded DOWN (fp32 rounding is 6e-8 relative): still a lower bound
-    const double k0 = fmax(fmax((double)b0 - G.c[0], G.c[0] - (double)b3), 0.0);
-    const double k1 = fmax(fmax((double)b1 - G.c[1], G.c[1] - (double)b4), 0.0);
-    const double k2 = fmax(fmax((double)b2 - G.c[2], G.c[2] - (double)b5), 0.0);
-    key = (float)(k0 * k0 + k1 * k1 + k2 * k2);   // visiting order only
+    const float k0 = fmaxf(fmaxf(b0 - G.c[0], G.c[0] - b3), 0.f);
+    const float k1 = fmaxf(fmaxf(b1 - G.c[1], G.c[1] - b4), 0.f);
+    const float k2 = fmaxf(fmaxf(b2 - G.c[2], G.c[2] - b5), 0.f);
+    key = k0 * k0 + k1 * k1 + k2 * k2;   // visiting order only
   }
   float2* mybox = sbox + (IN_LDS ? (LEVEL - 1) * 3 * FAN : 0);   // [axis][child] -> (lo, hi)
   if (IN_LDS) {
@@ -351,42 +314,29 @@ __device__ void visit(const TileView& g, int first, int nchild, Lane& L, const G
   // largest screen threshold of the wave (>= every lane's best): only shrinks, and only when a tile was scanned below ->
   // refreshed after descents
   float gmax = wave_max_f(L.active ? L.thr : 0.f);
-  unsigned long long todo = __ballot(pend);   // (FAST, unordered) children not yet handled, as a wave-uniform mask
   while (true) {
-    int c;
-    if (UNORD && !G.ordered) {
-      todo &= __ballot(ddf <= gmax);           // the wave's largest threshold only shrinks: re-test what is left, in index order
-      if (todo == 0ull) break;
-      c = __ffsll((long long)todo) - 1;
-      todo &= todo - 1ull;
+    pend = pend && ddf <= gmax;
+    const unsigned long long mask = __ballot(pend);
+    if (mask == 0ull) break;
+    const float kmin = wave_min_f(pend ? key : inf);
+    const unsigned long long pick = __ballot(pend && key == kmin);
+    const int c = __builtin_amdgcn_readfirstlane(__ffsll((long long)pick) - 1);
+    if (lane == c) pend = false;
+    float c0, c1, c2, c3, c4, c5;
+    if (IN_LDS) {
+      const float2 u = mybox[c], v = mybox[FAN + c], w = mybox[2 * FAN + c];
+      c0 = u.x; c3 = u.y; c1 = v.x; c4 = v.y; c2 = w.x; c5 = w.y;
     } else {
-      pend = pend && ddf <= gmax;
-      const unsigned long long mask = __ballot(pend);
-      if (mask == 0ull) break;
-      const float kmin = wave_min_f(pend ? key : inf);
-      const unsigned long long pick = __ballot(pend && key == kmin);
-      c = __builtin_amdgcn_readfirstlane(__ffsll((long long)pick) - 1);
-      if (lane == c) pend = false;
+      c0 = bcast(b0, c); c1 = bcast(b1, c); c2 = bcast(b2, c); c3 = bcast(b3, c); c4 = bcast(b4, c); c5 = bcast(b5, c);
     }
-    // per-lane test of the child against every lane's own threshold.  FAST skips it above the leaf level: a big box that survives the
-    // patch-level cull is almost never rejected by all 64 lanes, and the next level's cull (all children at once) does that work anyway
-    if (LANE_TEST) {
-      float c0, c1, c2, c3, c4, c5;
-      if (IN_LDS) {
-        const float2 u = mybox[c], v = mybox[FAN + c], w = mybox[2 * FAN + c];
-        c0 = u.x; c3 = u.y; c1 = v.x; c4 = v.y; c2 = w.x; c5 = w.y;
-      } else {
-        c0 = bcast(b0, c); c1 = bcast(b1, c); c2 = bcast(b2, c); c3 = bcast(b3, c); c4 = bcast(b4, c); c5 = bcast(b5, c);
-      }
-      const float lb = box_lb32(L, c0, c1, c2, c3, c4, c5);
-      if (__ballot(L.active && lb <= L.thr) == 0ull) continue;
-    }
+    const float lb = box_lb32(L, c0, c1, c2, c3, c4, c5);
+    if (__ballot(L.active && lb <= L.thr) == 0ull) continue;
     const int child = first + c;
     if (LEVEL == 0) {
-      leaf_scan<BND, OPT>(g, child, L, G.slack, G.mu, T, n_cand);
+      leaf_scan<BND>(g, child, L, G.slack, G.mu, T, n_cand);
     } else {
       const int cf = child * FAN;
-      visit<(LEVEL > 0 ? LEVEL - 1 : 0), BND, OPT>(g, cf, min(FAN, g.cnt[LEVEL > 0 ? LEVEL - 1 : 0] - cf), L, G, T, sbox, n_cand, n_box);
+      visit<(LEVEL > 0 ? LEVEL - 1 : 0), BND>(g, cf, min(FAN, g.cnt[LEVEL > 0 ? LEVEL - 1 : 0] - cf), L, G, T, sbox, n_cand, n_box);
     }
     gmax = wave_max_f(L.active ? L.thr : 0.f);
   }
@@ -394,7 +344,7 @@ __device__ void visit(const TileView& g, int first, int nchild, Lane& L, const G
 
 // TOP >= 0: every target of the launch has exactly TOP + 1 hierarchy levels (the common case: clouds of similar size), so
 // only that traversal is compiled in; TOP = -1: generic (per-job switch over the depth).
-template <int WPE, int TOP, bool BND, int OPT>
+template <int WPE, int TOP, bool BND>
 __global__ __launch_bounds__(NT, WPE) void nn_tile_kernel(const TileJob* __restrict__ jobs, double bound, unsigned long long* __restrict__ stats) {
   __shared__ TileLds s_tile[NT / 64];
   __shared__ float2 s_box[NT / 64][2 * 3 * FAN];   // levels 1 and 2: 64 child boxes x 24 B each, per wave
@@ -413,7 +363,6 @@ __global__ __launch_bounds__(NT, WPE) void nn_tile_kernel(const TileJob* __restr
   L.active = i < job.n;
   L.best = bound; L.bi = 0x7fffffff;
   L.second = 1.7976931348623157e308;
-  L.bpos = -1;
   L.qx = L.qy = L.qz = 0.0;
   if (L.active) {
     const double p0 = job.q[3 * (size_t)i], p1 = job.q[3 * (size_t)i + 1], p2 = job.q[3 * (size_t)i + 2];
@@ -428,69 +377,41 @@ __global__ __launch_bounds__(NT, WPE) void nn_tile_kernel(const TileJob* __restr
       const double* p = g.spts + 3 * (size_t)pi;
       const double d0 = __dsub_rn(L.qx, p[0]), d1 = __dsub_rn(L.qy, p[1]), d2 = __dsub_rn(L.qz, p[2]);
       const double d = __dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2));
-      if (d <= L.best) { L.best = d; L.bi = g.sidx[pi]; L.bpos = pi; }
+      if (d <= L.best) { L.best = d; L.bi = g.sidx[pi]; }
     }
   }
   Group G;   // wave-uniform: lives in SGPRs
-  G.ordered = true;   // (decided below, once the thresholds are known)
-  if ((OPT & 1) != 0) {
-    // patch box in fp32, rounded outward: min / max of the lanes' float copies, widened by more than the half ulp a conversion can
-    // have moved a coordinate inwards (six DPP reductions of 7 instructions instead of six fp64 ones of ~30)
+  {
+    // patch box in fp32, rounded outward: min / max of the lanes' float copies, widened by more than the half ulp a conversion can have
+    // moved a coordinate inwards (six DPP reductions of 7 instructions; round 2 reduced the fp64 coordinates: ~30 instructions each)
     const float inf = __int_as_float(0x7f800000);
     const float a = (float)L.qx, b = (float)L.qy, c2 = (float)L.qz;
     float lo[3] = {wave_min_any(L.active ? a : inf), wave_min_any(L.active ? b : inf), wave_min_any(L.active ? c2 : inf)};
     float hi[3] = {wave_max_any(L.active ? a : -inf), wave_max_any(L.active ? b : -inf), wave_max_any(L.active ? c2 : -inf)};
-    float m = (float)g.maxabs * 1.000001f;
+    float m = (float)g.maxabs * 1.000001f;   // largest coordinate magnitude either operand of a difference can have: the cloud's box and the patch
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
       lo[ax] -= fabsf(lo[ax]) * 1.2e-7f + 1e-37f; hi[ax] += fabsf(hi[ax]) * 1.2e-7f + 1e-37f;
-      G.flo[ax] = lo[ax]; G.fhi[ax] = hi[ax]; G.fc[ax] = 0.5f * (lo[ax] + hi[ax]);
-      G.lo[ax] = G.hi[ax] = G.c[ax] = 0.0;
+      G.lo[ax] = lo[ax]; G.hi[ax] = hi[ax]; G.c[ax] = 0.5f * (lo[ax] + hi[ax]);
       m = fmaxf(m, fmaxf(fabsf(lo[ax]), fabsf(hi[ax])));
     }
     // per axis: |fl32(q) - q| + |fl32(p) - p| + rounding of the fp32 subtraction <= 3 * 2^-24 * m; x sqrt(3) axes, x2 safety
     G.slack = m * (3.0f * 1.7320508f * 2.0f / 16777216.0f) * 1.00001f + 1e-30f;
     G.mu = BND ? job.mu : 0.f;
-  } else {
-    const double big = 1.7976931348623157e308;
-    G.lo[0] = wave_min(L.active ? L.qx : big); G.hi[0] = wave_max(L.active ? L.qx : -big);
-    G.lo[1] = wave_min(L.active ? L.qy : big); G.hi[1] = wave_max(L.active ? L.qy : -big);
-    G.lo[2] = wave_min(L.active ? L.qz : big); G.hi[2] = wave_max(L.active ? L.qz : -big);
-#pragma unroll
-    for (int a = 0; a < 3; ++a) G.c[a] = uniform_d(0.5 * (G.lo[a] + G.hi[a]), 0);
-    // largest coordinate magnitude either operand of a difference can have: the patch and the cloud's bounding box
-    double m = 0.0;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) m = fmax(m, fmax(fmax(fabs(G.lo[a]), fabs(G.hi[a])), g.maxabs));
-    // per axis: |fl32(q) - q| + |fl32(p) - p| + rounding of the fp32 subtraction <= 3 * 2^-24 * m; x sqrt(3) axes, x2 safety
-    G.slack = bcast((float)(m * (3.0 * 1.7320508 * 2.0 / 16777216.0)) + 1e-30f, 0);
-    G.mu = BND ? job.mu : 0.f;
   }
   { const float a = (float)L.qx, b = (float)L.qy, c2 = (float)L.qz; L.qx2 = f2v{a, a}; L.qy2 = f2v{b, b}; L.qz2 = f2v{c2, c2}; L.pad_ = 0.0; }
   L.thr = thr_of(L.best, G.slack + G.mu);
-  if ((OPT & 4) != 0 && job.seed) {
-    // Seeded launch: the lanes start from last round's neighbours.  If those bounds are already tight — the largest threshold of the wave
-    // is not beyond the patch's own diagonal — nearest-first visiting buys nothing and the children are taken in index order (no wave
-    // arg-min per child); after a large pose update (loose bounds) the order still matters.  order: 0 = this rule, 1 = always ordered,
-    // 2 = never ordered when seeded (A/B knob)
-    const bool f32 = (OPT & 1) != 0;
-    const float dx = f32 ? G.fhi[0] - G.flo[0] : (float)(G.hi[0] - G.lo[0]), dy = f32 ? G.fhi[1] - G.flo[1] : (float)(G.hi[1] - G.lo[1]),
-                dz = f32 ? G.fhi[2] - G.flo[2] : (float)(G.hi[2] - G.lo[2]);
-    const float diag2 = dx * dx + dy * dy + dz * dz;
-    const float g0 = wave_max_f(L.active ? L.thr : 0.f);
-    G.ordered = job.order == 1 ? true : job.order == 2 ? false : g0 > diag2;
-  }
   unsigned int n_cand = 0, n_box = 0;
   const int top = g.levels - 1;
   TileLds* T = &s_tile[wave];
   float2* sbox = s_box[wave];
-  if (TOP >= 0) visit<(TOP >= 0 ? TOP : 0), BND, OPT>(g, 0, g.cnt[TOP >= 0 ? TOP : 0], L, G, T, sbox, &n_cand, &n_box);
+  if (TOP >= 0) visit<(TOP >= 0 ? TOP : 0), BND>(g, 0, g.cnt[TOP >= 0 ? TOP : 0], L, G, T, sbox, &n_cand, &n_box);
   else switch (top) {
-    case 0: visit<0, BND, OPT>(g, 0, g.cnt[0], L, G, T, sbox, &n_cand, &n_box); break;
-    case 1: visit<1, BND, OPT>(g, 0, g.cnt[1], L, G, T, sbox, &n_cand, &n_box); break;
-    case 2: visit<2, BND, OPT>(g, 0, g.cnt[2], L, G, T, sbox, &n_cand, &n_box); break;
-    case 3: visit<3, BND, OPT>(g, 0, g.cnt[3], L, G, T, sbox, &n_cand, &n_box); break;
-    default: visit<4, BND, OPT>(g, 0, g.cnt[4], L, G, T, sbox, &n_cand, &n_box); break;
+    case 0: visit<0, BND>(g, 0, g.cnt[0], L, G, T, sbox, &n_cand, &n_box); break;
+    case 1: visit<1, BND>(g, 0, g.cnt[1], L, G, T, sbox, &n_cand, &n_box); break;
+    case 2: visit<2, BND>(g, 0, g.cnt[2], L, G, T, sbox, &n_cand, &n_box); break;
+    case 3: visit<3, BND>(g, 0, g.cnt[3], L, G, T, sbox, &n_cand, &n_box); break;
+    default: visit<4, BND>(g, 0, g.cnt[4], L, G, T, sbox, &n_cand, &n_box); break;
   }
   if (L.active) {
     const int out = i;   // sorted order of the source cloud
@@ -605,7 +526,6 @@ int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound, bool with_bounds) {
     j.inv = d.grid.inv;
     j.seed = (c->tile_seed && (int)c->nn_cache_edge.size() == c->E && c->nn_cache_edge[e]) ? 1 : 0;
     if (with_bounds) { j.out_lb = c->d_nn_lb + c->cap_off[e]; j.mu = (float)(c->tile_mu * d.grid.cell); }
-    j.order = c->tile_order;
     jobs.push_back(j);
     max_n = std::max(max_n, s.n);
     nq += s.n;
@@ -630,32 +550,18 @@ int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound, bool with_bounds) {
     const dim3 grid((max_n + NT - 1) / NT, (unsigned)jobs.size());
     int top = jobs[0].dst.levels - 1;   // same depth everywhere -> the traversal specialised for it
     for (const TileJob& j : jobs) if (j.dst.levels - 1 != top) top = -1;
-    // OPT bits (see visit / leaf_scan): 1 = fp32 patch box + cull, 2 = the running best's slot is not screened again, 4 = index-order children
-    // while the seeded bounds are tight, 8 = no per-lane box test above the leaf level.  kTileOpt = the measured best; the A/B builds
-    // exist for the common depth-3 case only (option "tile_opt")
-#define MVICP_TILE_K(W, T, B, O) hipLaunchKernelGGL((nn_tile_kernel<W, T, B, O>), grid, dim3(NT), 0, c->stream, d_jobs, d2_bound, d_stats)
+#define MVICP_TILE_K(W, T, B) hipLaunchKernelGGL((nn_tile_kernel<W, T, B>), grid, dim3(NT), 0, c->stream, d_jobs, d2_bound, d_stats)
     const int waves = c->tile_waves;   // 0 = pick: 7 waves per SIMD for the depth-3 build, 6 otherwise
-    const int opt = c->tile_opt < 0 ? kTileOpt : c->tile_opt;
-    // depth-3 build: 7 waves per SIMD measures the same as 8 (cfg4 rounds 1-4: 6.6 / 2.72 / 2.12 / 1.68 vs 6.5 / 2.73 / 2.13 / 1.67 ms) with 2
-    // spilled registers instead of 10; 6 waves (no spill at all) is 3-5 % slower
+    // depth-3 build: 7 waves per SIMD (no spills at 66 VGPRs); 6 and 8 measure 4-10 % slower (profiles/r03_tile_ab.txt)
     if (with_bounds) {   // hand-over round: one more fp64 register pair per lane, so one wave per SIMD fewer
-      if (top == 2) switch (opt) {
-        case 0: MVICP_TILE_K(6, 2, true, 0); break; case 1: MVICP_TILE_K(6, 2, true, 1); break; case 2: MVICP_TILE_K(6, 2, true, 2); break;
-        case 3: MVICP_TILE_K(6, 2, true, 3); break; case 7: MVICP_TILE_K(6, 2, true, 7); break; default: MVICP_TILE_K(6, 2, true, kTileOpt); break;
-      }
-      else MVICP_TILE_K(6, -1, true, kTileOpt);
+      if (top == 2) MVICP_TILE_K(6, 2, true); else MVICP_TILE_K(6, -1, true);
     }
-    else if (top == 2 && (waves == 0 || waves == 7)) switch (opt) {
-      case 0: MVICP_TILE_K(7, 2, false, 0); break; case 1: MVICP_TILE_K(7, 2, false, 1); break; case 2: MVICP_TILE_K(7, 2, false, 2); break;
-      case 3: MVICP_TILE_K(7, 2, false, 3); break; case 7: MVICP_TILE_K(7, 2, false, 7); break; case 15: MVICP_TILE_K(7, 2, false, 15); break;
-      case 19: MVICP_TILE_K(7, 2, false, 19); break; case 18: MVICP_TILE_K(7, 2, false, 18); break;
-      default: MVICP_TILE_K(7, 2, false, kTileOpt); break;
-    }
-    else if (top == 2 && waves == 8) MVICP_TILE_K(8, 2, false, kTileOpt);
-    else if (top == 2 && waves == 6) MVICP_TILE_K(6, 2, false, kTileOpt);
-    else if (top == 1 && (waves == 0 || waves == 6)) MVICP_TILE_K(6, 1, false, kTileOpt);
-    else if (waves == 8) MVICP_TILE_K(8, -1, false, kTileOpt);
-    else MVICP_TILE_K(6, -1, false, kTileOpt);
+    else if (top == 2 && (waves == 0 || waves == 7)) MVICP_TILE_K(7, 2, false);
+    else if (top == 2 && waves == 8) MVICP_TILE_K(8, 2, false);
+    else if (top == 2 && waves == 6) MVICP_TILE_K(6, 2, false);
+    else if (top == 1 && (waves == 0 || waves == 6)) MVICP_TILE_K(6, 1, false);
+    else if (waves == 8) MVICP_TILE_K(8, -1, false);
+    else MVICP_TILE_K(6, -1, false);
 #undef MVICP_TILE_K
   }
   MV_HIP(hipGetLastError());
