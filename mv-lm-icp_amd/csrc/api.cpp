@@ -230,7 +230,7 @@ void census_resolve(mvicp_ctx* c) {
     // cell-staging kernel: st[4] points staged into LDS (24 B each, once per wave), st[5] distinct cells looked up per wave (16-B brick
     // entry + 8-B cell-table entry), st[0] candidates scanned from LDS (no memory traffic), far part (st[1] boxes) from nn_far_kernel
     const double hits = (double)st[3];
-    pe.bytes += 52.0 * hits + 24.0 * (double)st[4] + 24.0 * (double)st[5] + 32.0 * (double)st[1];
+    pe.bytes += 36.0 * hits + 24.0 * (double)st[4] + 24.0 * (double)st[5] + 32.0 * (double)st[1];
     c->nn_candidates += (double)st[0]; c->nn_nodes += (double)st[1] + (double)st[5]; c->nn_far += (double)st[2]; c->nn_queries += nq; c->nn_hits += hits;
     c->nn_fetched += (double)st[4];
   } else if (c->census_kind == 2) {
@@ -240,10 +240,10 @@ void census_resolve(mvicp_ctx* c) {
     pe.bytes += 28.0 * (double)st[0] + 24.0 * (double)st[1];
     c->nn_candidates += (double)st[2]; c->nn_nodes += (double)st[1]; c->nn_queries += nq;
   } else {
-    // cache hit: previous index 4 B + bound 8 B + one 32-B record + bound write 8 B; searched query: 8 hash slots x 16 B + bound
-    // write 8 B; every candidate point examined: one 32-B record; every tree box tested: 32 B
+    // cache hit: previous index 4 B + fp32 bound 4 B + one 24-B point + bound write 4 B; searched query: 8 hash slots x 16 B + bound
+    // write 4 B; every candidate point examined: one 32-B record; every tree box tested: 32 B
     const double hits = (double)st[3], searched = nq - hits;
-    pe.bytes += 52.0 * hits + (c->census_kind == 1 ? 8.0 : 136.0) * searched + 32.0 * (double)st[0] + 32.0 * (double)st[1];
+    pe.bytes += 36.0 * hits + (c->census_kind == 1 ? 4.0 : 132.0) * searched + 32.0 * (double)st[0] + 32.0 * (double)st[1];
     c->nn_candidates += (double)st[0]; c->nn_nodes += (double)st[1]; c->nn_far += (double)st[2]; c->nn_queries += nq; c->nn_hits += hits;
     c->nn_fetched += (double)st[0];   // per-lane kernel: every candidate examined is a record fetched
   }

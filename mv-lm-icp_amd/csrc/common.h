@@ -122,7 +122,7 @@ struct mvicp_ctx {
   double* d_rel = nullptr;          // E x kEdgeRel
   // per-query (total_cap)
   int* d_nn_idx = nullptr; double* d_nn_d2 = nullptr;
-  double* d_nn_lb = nullptr;        // lower bound on the DISTANCE from the query to every target other than nn_idx (temporal cache)
+  float* d_nn_lb = nullptr;         // fp32, rounded down: lower bound on the DISTANCE from the query to every target other than nn_idx (temporal cache)
   bool nn_cache_valid = false; bool nn_cache_enable = true; float nn_cache_thresh = -1.f;
   std::vector<char> nn_cache_edge;  // edges searched (active) in the last grid search
   std::vector<double> prev_q;       // E x 12: query map M = Rd^-1 Rs (9, col-major) and v = Rd^-1 (ts - td) of the last search

@@ -68,7 +68,7 @@ struct GridJob {
   // "did anything change?" bookkeeping of the edge's compacted list (all null for the raw-query API)
   const int* qpos; int* second; double* cd2; const int* dirty; int* dirty_slots;  // dirty: host-forced flag; slots: one per NT queries
   double* stream; long long total_cap; const double* dst_nor;   // the edge's slice of the packed operand stream (linearize.hip) + sorted dst normals
-  double* out_lb;      // per query: lower bound on the distance to every target other than out_idx (null: no cache)
+  float* out_lb;       // per query: lower bound on the distance to every target other than out_idx, fp32 ROUNDED DOWN (null: no cache)
   int seed;            // out_idx still holds last round's neighbours (from any kernel): a starting candidate for far queries
 };
 
@@ -204,9 +204,9 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
   if (!TREE_ONLY && job.seed) {
     const int pi = job.out_idx[out];   // sorted position of last round's neighbour
     if (pi >= 0 && pi < g.n) {
-      const double2* tp = reinterpret_cast<const double2*>(g.srec + pi);
-      const double2 ta = tp[0], tb = tp[1];
-      const double d = dist2(qx, qy, qz, ta.x, ta.y, tb.x);
+      // (the 24-B point of the sorted cloud, not its 32-B record: a cache hit needs no index — round 3 byte diet, 68 -> 56 B per hit)
+      const double* tp = g.spts + 3 * (size_t)pi;
+      const double d = dist2(qx, qy, qz, tp[0], tp[1], tp[2]);
       if (slack >= 0.0 && job.out_lb != nullptr) {
         // how far THIS query moved since the last search: |dM p + dv| (exactly, up to the rounding allowance)
         const double p0 = job.q[3 * (size_t)i], p1 = job.q[3 * (size_t)i + 1], p2 = job.q[3 * (size_t)i + 2];
@@ -214,13 +214,13 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
         const double e1 = sxf[26] * p0 + sxf[29] * p1 + sxf[32] * p2 + sxf[35];
         const double e2 = sxf[27] * p0 + sxf[30] * p1 + sxf[33] * p2 + sxf[36];
         const double eps = sqrt(e0 * e0 + e1 * e1 + e2 * e2) * (1.0 + 1e-9) + slack;
-        const double nlb = job.out_lb[out] - eps;
+        const double nlb = (double)job.out_lb[out] - eps;
         if (sqrt(d) * (1.0 + 1e-12) < nlb) {
           // eps == 0 only when the host found the edge's query transform bit-identical to last round's (slack 0, dM = dv = 0): the
           // query, its distance, its bound and its list entry are then exactly what is stored already — nothing to write
           if (eps != 0.0) {
             job.out_d2[out] = d;
-            job.out_lb[out] = nlb;
+            job.out_lb[out] = __double2float_rd(nlb);
             if (job.dirty) update_list(job, i, pi, d, bound, true);
           }
           if (stats) {
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
   job.out_idx[out] = bi == 0x7fffffff ? -1 : (job.inv ? job.inv[bi] : bi);
   job.out_d2[out] = best;
   // every other target is either a scanned candidate (>= second) or outside the block (>= m)
-  if (job.out_lb != nullptr) job.out_lb[out] = resolved ? sqrt(fmin(fmin(second, m2), skipped)) * (1.0 - 1e-12) : 0.0;
+  if (job.out_lb != nullptr) job.out_lb[out] = resolved ? __double2float_rd(sqrt(fmin(fmin(second, m2), skipped)) * (1.0 - 1e-12)) : 0.f;
   if (job.dirty && (resolved || skip_far)) update_list(job, i, bi == 0x7fffffff ? -1 : job.inv[bi], best, bound);
   if (!resolved && !skip_far) {
     // wave-aggregated append: one atomic per wave
@@ -520,11 +520,11 @@ __global__ __launch_bounds__(NT, 5) void nn_cell_kernel(const GridJob* __restric
         const double e1 = sxf[26] * p0 + sxf[29] * p1 + sxf[32] * p2 + sxf[35];
         const double e2 = sxf[27] * p0 + sxf[30] * p1 + sxf[33] * p2 + sxf[36];
         const double eps = sqrt(e0 * e0 + e1 * e1 + e2 * e2) * (1.0 + 1e-9) + slack;
-        const double nlb = job.out_lb[i] - eps;
+        const double nlb = (double)job.out_lb[i] - eps;
         if (sqrt(d) * (1.0 + 1e-12) < nlb) {
           if (eps != 0.0) {   // (eps == 0: bit-identical query transform, everything stored is already exact — see nn_grid_kernel)
             job.out_d2[i] = d;
-            job.out_lb[i] = nlb;
+            job.out_lb[i] = __double2float_rd(nlb);
             if (job.dirty) update_list(job, i, pi, d, bound, true);
           }
           hit = true;
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(NT, 5) void nn_cell_kernel(const GridJob* __restric
     job.out_idx[i] = L.bpos;
     job.out_d2[i] = L.best;
     // every target that was not scanned is at least R1 away: outside the ball, or in a home cell beyond sqrt(TA2) >= R1
-    if (job.out_lb != nullptr) job.out_lb[i] = resolved ? sqrt(fmin(L.second, R1 * R1 * (1.0 - 1e-9))) * (1.0 - 1e-12) : 0.0;
+    if (job.out_lb != nullptr) job.out_lb[i] = resolved ? __double2float_rd(sqrt(fmin(L.second, R1 * R1 * (1.0 - 1e-9))) * (1.0 - 1e-12)) : 0.f;
     if (resolved) {
       if (job.dirty) update_list(job, i, L.bpos, L.best, bound);
     } else {
@@ -787,7 +787,7 @@ __global__ __launch_bounds__(NT) void nn_far_kernel(const GridJob* __restrict__ 
       job.out_idx[out] = bi == 0x7fffffff ? -1 : (job.inv ? job.inv[bi] : bi);
       job.out_d2[out] = best;
       // every other target was scanned (>= second) or sits in a skipped box (>= its lower bound)
-      if (job.out_lb != nullptr) job.out_lb[out] = bi == 0x7fffffff ? 0.0 : sqrt(fmin(second, pruned)) * (1.0 - 1e-12);
+      if (job.out_lb != nullptr) job.out_lb[out] = bi == 0x7fffffff ? 0.f : __double2float_rd(sqrt(fmin(second, pruned)) * (1.0 - 1e-12));
       if (job.dirty) update_list(job, i, bi == 0x7fffffff ? -1 : job.inv[bi], best, bound);
     }
   }

@@ -58,7 +58,7 @@ struct TileJob {
   int* out_idx; double* out_d2;
   const int* inv;   // target original index -> sorted position
   int seed;         // out_idx still holds last round's neighbours (sorted positions, -1 = none): use them as starting candidates
-  double* out_lb;   // BND builds: per query, a lower bound on the distance to every target other than out_idx (the grid kernel's temporal cache)
+  float* out_lb;    // BND builds (fp32, rounded down): per query, a lower bound on the distance to every target other than out_idx (the grid kernel's temporal cache)
   float mu;         // BND builds: width of the extra guard band (metres) that makes that bound useful
 };
 
@@ -233,13 +233,15 @@ __device__ __forceinline__ void leaf_scan(const TileView& g, int leaf, Lane& L, 
     const f2v ea = qx2 - xa, eb = qx2 - xb, fa = qy2 - ya, fb = qy2 - yb, ga = qz2 - za, gb = qz2 - zb;
     const f2v da = __builtin_elementwise_fma(ga, ga, __builtin_elementwise_fma(fa, fa, ea * ea));
     const f2v db = __builtin_elementwise_fma(gb, gb, __builtin_elementwise_fma(fb, fb, eb * eb));
-    const unsigned hit = (da.x <= thr ? 1u : 0u) | (da.y <= thr ? 2u : 0u) | (db.x <= thr ? 4u : 0u) | (db.y <= thr ? 8u : 0u);
-    if (hit) {
+    // the four screen results as lane predicates (one v_cmp each, the masks live in SGPR pairs); an integer hit mask per lane is 8 more
+    // VALU instructions per group in the listing but measures the same (SQ_INSTS_VALU identical, profiles/r03_tile_ab.txt)
+    const bool h[4] = {da.x <= thr, da.y <= thr, db.x <= thr, db.y <= thr};
+    if (h[0] || h[1] || h[2] || h[3]) {
       const float d32[4] = {da.x, da.y, db.x, db.y};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int k = 4 * k4 + j;
-        if (((hit >> j) & 1u) && k < cnt) {
+        if (h[j] && k < cnt) {
           const double d0 = __dsub_rn(L.qx, T->x[k]), d1 = __dsub_rn(L.qy, T->y[k]), d2 = __dsub_rn(L.qz, T->z[k]);
           const double d = __dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2));
           if (BND) {
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(NT, WPE) void nn_tile_kernel(const TileJob* __restr
     job.out_d2[out] = L.best;
     // every other target was evaluated exactly (>= second) or rejected by a screen (> sqrt(best) + mu away); 1e-9 relative covers the
     // fp64 roundings of this line.  No neighbour inside the cutoff: 0 forces a full search next round, like the grid kernel does.
-    if (BND) job.out_lb[out] = L.bi == 0x7fffffff ? 0.0 : fmin(sqrt(L.second), sqrt(L.best) + (double)G.mu) * (1.0 - 1e-9);
+    if (BND) job.out_lb[out] = L.bi == 0x7fffffff ? 0.f : __double2float_rd(fmin(sqrt(L.second), sqrt(L.best) + (double)G.mu) * (1.0 - 1e-9));
   }
   if (stats && (threadIdx.x & 63) == 0) {
     // wave-uniform counters: candidates examined PER LANE x active lanes, boxes tested per wave
