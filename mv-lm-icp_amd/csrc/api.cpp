@@ -730,6 +730,7 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
     upload_doubles = c->ctl_r2_off + (size_t)E * kEdgeRel;
   }
   MV_HIP(hipMemcpyAsync(c->d_ctl, hx, sizeof(double) * upload_doubles, hipMemcpyHostToDevice, c->stream));
+  c->far_narrow = nn_method == MVICP_NN_AUTO && method == MVICP_NN_GRID && c->nn_cache_valid && c->nn_cache_enable;   // AUTO's cached grid rounds: >= 96 % cache hits
   if (method == MVICP_NN_BRUTE) MV_CHECK(launch_nn_brute_edges(c));
   else if (method == MVICP_NN_GRID) MV_CHECK(launch_nn_grid_edges(c, bound));
   else if (method == MVICP_NN_TILE) MV_CHECK(launch_nn_tile_edges(c, bound, tile_lb));

@@ -198,6 +198,7 @@ struct mvicp_ctx {
   void* d_census = nullptr; size_t census_bytes = 0;
   void* d_far_list = nullptr; size_t far_cap = 0; unsigned int* d_far_count = nullptr;  // nn_grid far-query list
   int far_parity = 0;              // d_far_count holds TWO counters used alternately; a launch zeroes the one the next launch will use
+  bool far_narrow = false;         // this grid launch expects (almost) no far queries: narrow far-kernel launch (set by mvicp_correspond)
   bool skip_dirty_reduce = false;  // set by mvicp_correspond for a search in which no list can change (see api.cpp)
   bool nn_skip_far = false;        // PROFILING ONLY: leave unresolved queries unresolved (wrong results)
   bool tile_seed = true;           // tile kernel starts from last round's neighbours when there are any

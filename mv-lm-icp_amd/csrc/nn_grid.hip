@@ -1193,7 +1193,12 @@ int run(mvicp_ctx* c, const std::vector<GridJob>& jobs, double bound) {
       hipLaunchKernelGGL((nn_grid_kernel<false>), grid, dim3(NT), 0, c->stream, d_jobs, bound, d_stats, c->nn_skip_far ? 1 : 0, (int2*)c->d_far_list, far_cnt,
                          c->prune_rho);
     // phase 2: persistent grid-stride launch (the far count is only known on the device)
-    const unsigned int far_blocks = (unsigned int)std::min<size_t>(256 * 8, (total_q * 8 + NT - 1) / NT);
+    // With the temporal cache on, at most a fraction of a per cent of the queries ever reach the far list (0.1-0.2 % in the hand-over rounds,
+    // none at the fixed point): a 2048-workgroup launch then costs 19-22 us to find an empty list — 128 workgroups walk the same list
+    // (grid-stride) and cost ~4 us.  Only where MVICP_NN_AUTO has handed over to the cached grid rounds (api.cpp sets far_narrow); explicit
+    // grid searches, whose hit rate nobody vouches for, keep the wide launch.
+    const size_t far_wide = (edge_path && c->far_narrow) ? 128 : 256 * 8;
+    const unsigned int far_blocks = (unsigned int)std::min<size_t>(far_wide, (total_q * 8 + NT - 1) / NT);
     hipLaunchKernelGGL(nn_far_kernel, dim3(far_blocks), dim3(NT), 0, c->stream, d_jobs, (const int2*)c->d_far_list, bound, (const unsigned int*)far_cnt, far_next, d_stats, slots);
     // per-edge OR of the "list changed" slots — not needed when the host already knows that nothing can change (api.cpp: every
     // transform bit-identical, every list valid): no query marks a slot then
