@@ -180,7 +180,9 @@ int mvicp_closedform_point_to_plane(const double* src, const double* dst, const 
  * (0/1, default 1): the linearization reads the source points of an all-accepted edge from the shared sorted cloud; "nn_cell"
  * (0/1, default 0): wave-cooperative cell-staging variant of the grid kernel; "tile_bounds" (default 1): the MVICP_NN_AUTO round
  * that hands over from the tile kernel to the grid kernel runs a build of the tile kernel that also leaves the temporal-cache
- * bounds (2: every tile round does, 0: off), "tile_mu" (default 0.05): its guard band in hash-cell edges; "prune_rho", "auto_settle", "auto_switch",
+ * bounds (2: every tile round does, 0: off), "tile_mu" (default 0.02): its guard band in hash-cell edges; "tile_cache" (0/1, default 1):
+ * after that hand-over, rounds whose poses still move run the same build with the temporal-cache check as its prologue (lanes whose
+ * neighbour provably did not change sit out; the wave searches for its missed lanes only) and the grid kernel only re-verifies the fixed point; "prune_rho", "auto_settle", "auto_switch",
  * see DESIGN.md; "grid_curve" (default 2): device order of the clouds at the next mvicp_set_frame, 2 = balanced k-d order,
  * 1 / 0 = Hilbert / Morton index of the hash cell (nn_cell needs 0 or 1).  Tuning knobs: correspondences are
  * bit-identical for every setting. */

@@ -239,6 +239,7 @@ void census_resolve(mvicp_ctx* c) {
     // box once per wave (24 B); the per-lane distance evaluations (st[2]) are served from LDS.
     pe.bytes += 28.0 * (double)st[0] + 24.0 * (double)st[1];
     c->nn_candidates += (double)st[2]; c->nn_nodes += (double)st[1]; c->nn_queries += nq;
+    c->nn_hits += (double)st[3]; pe.bytes += 36.0 * (double)st[3];   // cache-aware rounds: lanes answered by the temporal cache (index, bound, neighbour point, bound write)
   } else {
     // cache hit: previous index 4 B + fp32 bound 4 B + one 24-B point + bound write 4 B; searched query: 8 hash slots x 16 B + bound
     // write 4 B; every candidate point examined: one 32-B record; every tree box tested: 32 B
@@ -678,11 +679,23 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   if (nn_method == MVICP_NN_AUTO && method == MVICP_NN_GRID && c->auto_last_method == MVICP_NN_TILE && c->tile_bounds >= 1 &&
       c->nn_cache_enable && !c->nn_cell) { method = MVICP_NN_TILE; tile_lb = true; handed_over = true; }
   if (method == MVICP_NN_TILE && c->tile_bounds >= 2 && c->nn_cache_enable) tile_lb = true;
+  // Cache-aware tile rounds (round 3).  After the hand-over the grid kernel answers cache hits at streaming speed but pays 1.5-2 ns for
+  // every isolated miss (per-lane hash probing), which dominates the rounds in which the poses still move a little (hit rates 74-99 %).
+  // Those rounds run the tile kernel's bounds-leaving build with the cache check as its prologue instead: a missed lane is searched by
+  // its wave, cooperatively.  Once every transform is bit-identical to last search's (the fixed point) the grid kernel's verify pass is
+  // the cheaper one and takes over.
+  bool tile_cached = false;
+  bool all_same = true;   // every active edge's query transform is bit-identical to last search's
+  {
+    for (int e = 0; e < E; ++e) if (c->active[e] && !same_edge[e]) all_same = false;
+    if (nn_method == MVICP_NN_AUTO && method == MVICP_NN_GRID && !handed_over && c->tile_cache && c->tile_bounds >= 1 && c->nn_cache_valid &&
+        c->nn_cache_enable && !c->nn_cell && !all_same) { method = MVICP_NN_TILE; tile_lb = true; tile_cached = true; handed_over = true; }
+  }
   {
     // an edge may keep last round's compacted list only if the grid kernel (which checks every query) runs and the list
     // on the device really is last round's result for this edge
     std::vector<int> dirty(E, 1);
-    if (method == MVICP_NN_GRID && !c->nn_tree_only && !c->nn_skip_far && c->list_reuse)
+    if ((tile_cached || (method == MVICP_NN_GRID && !c->nn_tree_only && !c->nn_skip_far)) && c->list_reuse)
       for (int e = 0; e < E; ++e) if (c->active[e] && c->list_valid[e]) dirty[e] = 0;
     std::memcpy(hd, dirty.data(), sizeof(int) * E);
   }
@@ -730,10 +743,10 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
     upload_doubles = c->ctl_r2_off + (size_t)E * kEdgeRel;
   }
   MV_HIP(hipMemcpyAsync(c->d_ctl, hx, sizeof(double) * upload_doubles, hipMemcpyHostToDevice, c->stream));
-  c->far_narrow = nn_method == MVICP_NN_AUTO && method == MVICP_NN_GRID && c->nn_cache_valid && c->nn_cache_enable;   // AUTO's cached grid rounds: >= 96 % cache hits
+  c->far_narrow = nn_method == MVICP_NN_AUTO && method == MVICP_NN_GRID && c->nn_cache_valid && c->nn_cache_enable && all_same;   // the fixed point: (almost) every query is a cache hit
   if (method == MVICP_NN_BRUTE) MV_CHECK(launch_nn_brute_edges(c));
   else if (method == MVICP_NN_GRID) MV_CHECK(launch_nn_grid_edges(c, bound));
-  else if (method == MVICP_NN_TILE) MV_CHECK(launch_nn_tile_edges(c, bound, tile_lb));
+  else if (method == MVICP_NN_TILE) MV_CHECK(launch_nn_tile_edges(c, bound, tile_lb, tile_cached));
   else { set_error("unknown nn_method %d", nn_method); return MVICP_ERR_ARG; }
   // only the grid kernel and the tile kernel's BND build leave the per-query lower bounds the temporal cache needs; the cutoff must
   // not change either
@@ -963,6 +976,7 @@ int mvicp_set_option(mvicp_ctx* c, const char* name, double value) try {
   if (std::strcmp(name, "tile_bounds") == 0) { c->tile_bounds = (int)value; return MVICP_OK; }
   if (std::strcmp(name, "tile_mu") == 0) { if (!(value > 0.0 && value <= 1.0)) { set_error("tile_mu outside (0, 1]"); return MVICP_ERR_ARG; } c->tile_mu = value; return MVICP_OK; }
   if (std::strcmp(name, "tile_waves") == 0) { c->tile_waves = (int)value; return MVICP_OK; }
+  if (std::strcmp(name, "tile_cache") == 0) { c->tile_cache = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "spin_wait") == 0) { c->spin_wait = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "spec_eval") == 0) { c->spec_enable = value != 0.0; c->spec_ready = false; return MVICP_OK; }
   if (std::strcmp(name, "grid_target") == 0) {

@@ -205,7 +205,10 @@ struct mvicp_ctx {
   int tile_bounds = 1;             // 1: the AUTO round that would hand over to the grid kernel runs the tile kernel's BND build instead (it leaves the
                                    // temporal-cache bounds, so the grid kernel starts with cache hits one round later and the uncached grid round — the
                                    // slowest of a registration — never runs); 2: every tile round leaves bounds (tests); 0: off
-  double tile_mu = 0.05;           // BND guard band as a fraction of the target's hash-cell edge (same role as prune_rho in the grid kernel)
+  bool tile_cache = true;          // AUTO, after the hand-over: rounds whose transforms still move run the tile kernel's bounds-leaving build WITH the
+                                   // temporal-cache check as its prologue (missed lanes are searched wave-cooperatively) instead of the grid kernel
+  double tile_mu = 0.02;           // BND guard band as a fraction of the target's hash-cell edge (same role as prune_rho in the grid kernel); round 3 sweep on cfg4
+                                   // (hand-over round + the two cache-aware rounds after it): 0.02 -> 2.06 ms, 0.05 -> 2.11, 0.1 -> 2.23, 0.2 -> 2.45
   int tile_waves = 0;              // nn_tile_kernel variant: waves per SIMD it is compiled for (0 = the measured best for the depth)
   double auto_prev_dist = 0.0; int auto_last_method = -1; double auto_settle = 0.5;   // MVICP_NN_AUTO policy state (api.cpp)
   double last_rms = -1.0;          // RMS residual at the end of the last mvicp_optimize since the last search (< 0: none): predicts the next NN distances
@@ -229,7 +232,7 @@ namespace mvicp {
 int launch_nn_brute_edges(mvicp_ctx* c);                                             // nn_brute.hip
 int launch_nn_brute_queries(mvicp_ctx* c, const FrameDev& f, const double* d_q, int n, int* d_idx, double* d_d2);
 int launch_nn_grid_edges(mvicp_ctx* c, double d2_bound);                              // nn_grid.hip
-int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound, bool with_bounds);
+int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound, bool with_bounds, bool with_cache);
 int warm_nn_tile(mvicp_ctx* c); int warm_nn_grid(mvicp_ctx* c);                                    // code-object load at set-up time (mvicp_set_graph)                              // nn_tile.hip
 int build_wide(FrameDev& f, const double* sorted_pts);                                 // nn_tile.hip (host, called by build_grid)
 int launch_nn_grid_queries(mvicp_ctx* c, const FrameDev& f, const double* d_q, int n, int* d_idx, double* d_d2);

@@ -36,6 +36,7 @@
 #include <unordered_set>
 
 #include "common.h"
+#include "nn_list.h"
 
 namespace mvicp {
 
@@ -112,41 +113,10 @@ __device__ __forceinline__ bool __lane0() {
   return (int)(threadIdx.x & 63) == __ffsll((long long)mask) - 1;
 }
 
-// The edge's compacted correspondence list survives a round when every query keeps its acceptance (cutoff test): squared
-// distances are refreshed in place, a changed neighbour is patched in place (list entry + its operands), and compaction +
-// operand gather are skipped for that edge.  Only a change of acceptance (the list's membership) marks the edge dirty.
-// No hot-address atomics: a query that invalidates the list stores 1 into its workgroup's slot (plain store, benign
-// same-value race); dirty_reduce_kernel ORs the slots per edge afterwards.
-// same_neighbour: the caller KNOWS idx_new is last round's neighbour (temporal-cache hit): a valid list then holds exactly that index
-// at the query's position (the list was built from out_idx and every round since kept every neighbour), so the load is skipped.
+// list maintenance shared with the tile kernel: nn_list.h
 __device__ __forceinline__ void update_list(const GridJob& job, int i, int idx_new, double d2_new, double bound, bool same_neighbour = false) {
-  if (*job.dirty != 0) return;   // forced dirty by the host (no valid list yet): nothing to check, qpos may be uninitialised
-  const int pos = job.qpos[i];
-  const bool acc = idx_new >= 0 && d2_new < bound;
-  bool clean;
-  if (pos < 0) clean = !acc;
-  else {
-    clean = acc;
-    if (clean) {
-      if (!same_neighbour && job.second[pos] != idx_new) {
-        // The query keeps its place in the list (still accepted) but has a NEW neighbour: patch the entry and its operands in place —
-        // n, c = n . q, q of the operand stream, exactly as gather_kernel writes them (corr.hip; same expression, no contraction) —
-        // instead of declaring the whole edge dirty (which re-compacts and re-gathers all of its ~N_src entries).
-        job.second[pos] = idx_new;
-        const double2* pb = reinterpret_cast<const double2*>(job.dst.srec + idx_new);
-        const double2 b0 = pb[0], b1 = pb[1];
-        double* st = job.stream + pos;
-        st[7 * job.total_cap] = b0.x; st[8 * job.total_cap] = b0.y; st[9 * job.total_cap] = b1.x;
-        if (job.dst_nor != nullptr) {
-          const double n0 = job.dst_nor[3 * (size_t)idx_new], n1 = job.dst_nor[3 * (size_t)idx_new + 1], n2 = job.dst_nor[3 * (size_t)idx_new + 2];
-          st[3 * job.total_cap] = n0; st[4 * job.total_cap] = n1; st[5 * job.total_cap] = n2;
-          st[6 * job.total_cap] = n0 * b0.x + n1 * b0.y + n2 * b1.x;
-        }
-      }
-      job.cd2[pos] = d2_new;
-    }
-  }
-  if (!clean) job.dirty_slots[i / NT] = 1;
+  const ListRef R{job.qpos, job.second, job.cd2, job.dirty, job.dirty_slots, job.stream, job.total_cap, job.dst_nor, job.dst.srec};
+  update_list_entry(R, i, idx_new, d2_new, bound, same_neighbour);
 }
 
 // Also leaves the slots zeroed for the next round (no memsets in the per-round launch sequence).
@@ -1195,8 +1165,8 @@ int run(mvicp_ctx* c, const std::vector<GridJob>& jobs, double bound) {
     // phase 2: persistent grid-stride launch (the far count is only known on the device)
     // With the temporal cache on, at most a fraction of a per cent of the queries ever reach the far list (0.1-0.2 % in the hand-over rounds,
     // none at the fixed point): a 2048-workgroup launch then costs 19-22 us to find an empty list — 128 workgroups walk the same list
-    // (grid-stride) and cost ~4 us.  Only where MVICP_NN_AUTO has handed over to the cached grid rounds (api.cpp sets far_narrow); explicit
-    // grid searches, whose hit rate nobody vouches for, keep the wide launch.
+    // (grid-stride) and cost ~4 us.  Only at the fixed point (api.cpp sets far_narrow: every transform bit-identical to last search's): with
+    // 0.2 % far queries (the 96 %-hit round of a hand-over) the narrow launch measured 0.1 ms SLOWER than the wide one.
     const size_t far_wide = (edge_path && c->far_narrow) ? 128 : 256 * 8;
     const unsigned int far_blocks = (unsigned int)std::min<size_t>(far_wide, (total_q * 8 + NT - 1) / NT);
     hipLaunchKernelGGL(nn_far_kernel, dim3(far_blocks), dim3(NT), 0, c->stream, d_jobs, (const int2*)c->d_far_list, bound, (const unsigned int*)far_cnt, far_next, d_stats, slots);
@@ -1216,6 +1186,12 @@ int run(mvicp_ctx* c, const std::vector<GridJob>& jobs, double bound) {
   return MVICP_OK;
 }
 }  // namespace
+
+int launch_dirty_reduce(mvicp_ctx* c) {
+  hipLaunchKernelGGL(dirty_reduce_kernel, dim3(c->E), dim3(256), 0, c->stream, c->E, c->d_dslot_off, c->d_dirty_slots, c->d_dirty);
+  MV_HIP(hipGetLastError());
+  return MVICP_OK;
+}
 
 namespace { __global__ void grid_warm_kernel() {} }
 

@@ -33,6 +33,7 @@
 #include <vector>
 
 #include "common.h"
+#include "nn_list.h"
 
 namespace mvicp {
 
@@ -60,6 +61,11 @@ struct TileJob {
   int seed;         // out_idx still holds last round's neighbours (sorted positions, -1 = none): use them as starting candidates
   float* out_lb;    // BND builds (fp32, rounded down): per query, a lower bound on the distance to every target other than out_idx (the grid kernel's temporal cache)
   float mu;         // BND builds: width of the extra guard band (metres) that makes that bound useful
+  // BND builds, cache-aware rounds (round 3): out_lb holds last search's bounds and the edge's query transform carries the temporal-cache
+  // allowance (xf[24] >= 0): a lane whose neighbour provably did not change sits the traversal out, like in nn_grid_kernel.  `list`
+  // (list.dirty != null) = the edge's compacted list is maintained in place by this launch (nn_list.h).
+  int cache;
+  ListRef list;
 };
 
 __device__ __forceinline__ void xf_point(const double* __restrict__ x, double p0, double p1, double p2, double& q0, double& q1, double& q2) {
@@ -366,21 +372,58 @@ __global__ __launch_bounds__(NT, WPE) void nn_tile_kernel(const TileJob* __restr
   L.best = bound; L.bi = 0x7fffffff;
   L.second = 1.7976931348623157e308;
   L.qx = L.qy = L.qz = 0.0;
+  double p0 = 0.0, p1 = 0.0, p2 = 0.0;
   if (L.active) {
-    const double p0 = job.q[3 * (size_t)i], p1 = job.q[3 * (size_t)i + 1], p2 = job.q[3 * (size_t)i + 2];
+    p0 = job.q[3 * (size_t)i]; p1 = job.q[3 * (size_t)i + 1]; p2 = job.q[3 * (size_t)i + 2];
     if (has_xf) xf_point(sxf, p0, p1, p2, L.qx, L.qy, L.qz);
     else { L.qx = p0; L.qy = p1; L.qz = p2; }
   }
   // Seed: last round's neighbour is an ordinary candidate (any target is), but starting from its distance instead of the
   // cutoff bound lets the traversal discard almost every tile that does not hold a true neighbour of some lane.
+  int seed_pi = -1;
+  double seed_d = 0.0;
   if (job.seed && L.active) {
     const int pi = job.out_idx[i];
     if (pi >= 0 && pi < g.n) {
       const double* p = g.spts + 3 * (size_t)pi;
       const double d0 = __dsub_rn(L.qx, p[0]), d1 = __dsub_rn(L.qy, p[1]), d2 = __dsub_rn(L.qz, p[2]);
       const double d = __dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2));
+      seed_pi = pi; seed_d = d;
       if (d <= L.best) { L.best = d; L.bi = g.sidx[pi]; }
     }
+  }
+  // Temporal cache (BND builds in cache-aware rounds; the same test as nn_grid_kernel's): last search left a lower bound on the distance
+  // to every target OTHER than the neighbour; the query has moved by exactly eps = |dM p + dv| since, so if the re-evaluated distance to
+  // the old neighbour is below (bound - eps) it is still the unique nearest neighbour and its exact d2 is the answer.  Such a lane is
+  // finished here and sits the traversal out: the wave walks the hierarchy for its MISSED lanes only — a patch of a few queries opens
+  // one or two tiles instead of six — and a wave without a miss leaves at once.
+  unsigned int n_hit = 0;
+  if (BND && job.cache && has_xf && seed_pi >= 0) {
+    const double cslack = sxf[24];
+    if (cslack >= 0.0) {
+      const double e0 = sxf[25] * p0 + sxf[28] * p1 + sxf[31] * p2 + sxf[34];
+      const double e1 = sxf[26] * p0 + sxf[29] * p1 + sxf[32] * p2 + sxf[35];
+      const double e2 = sxf[27] * p0 + sxf[30] * p1 + sxf[33] * p2 + sxf[36];
+      const double eps = sqrt(e0 * e0 + e1 * e1 + e2 * e2) * (1.0 + 1e-9) + cslack;
+      const double nlb = (double)job.out_lb[i] - eps;
+      if (sqrt(seed_d) * (1.0 + 1e-12) < nlb) {
+        if (eps != 0.0) {   // (eps == 0: bit-identical query transform, everything stored is already exact)
+          job.out_d2[i] = seed_d;
+          job.out_lb[i] = __double2float_rd(nlb);
+          if (job.list.dirty) update_list_entry(job.list, i, seed_pi, seed_d, bound, true);
+        }
+        L.active = false;
+        n_hit = 1;
+      }
+    }
+  }
+  if (BND && job.cache && __ballot(L.active) == 0ull) {
+    if (stats) {   // census (profiling only): all 64 lanes answered by the cache
+      const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + wave;
+      const unsigned long long hits = __popcll(__ballot(n_hit != 0u));
+      if ((threadIdx.x & 63) == 0) stats[8 * slot + 3] = hits;
+    }
+    return;
   }
   Group G;   // wave-uniform: lives in SGPRs
   {
@@ -402,7 +445,7 @@ __global__ __launch_bounds__(NT, WPE) void nn_tile_kernel(const TileJob* __restr
     G.mu = BND ? job.mu : 0.f;
   }
   { const float a = (float)L.qx, b = (float)L.qy, c2 = (float)L.qz; L.qx2 = f2v{a, a}; L.qy2 = f2v{b, b}; L.qz2 = f2v{c2, c2}; L.pad_ = 0.0; }
-  L.thr = thr_of(L.best, G.slack + G.mu);
+  L.thr = L.active ? thr_of(L.best, G.slack + G.mu) : -1.f;   // a finished / padding lane screens nothing (d32 >= 0 > -1)
   unsigned int n_cand = 0, n_box = 0;
   const int top = g.levels - 1;
   TileLds* T = &s_tile[wave];
@@ -422,12 +465,17 @@ __global__ __launch_bounds__(NT, WPE) void nn_tile_kernel(const TileJob* __restr
     // every other target was evaluated exactly (>= second) or rejected by a screen (> sqrt(best) + mu away); 1e-9 relative covers the
     // fp64 roundings of this line.  No neighbour inside the cutoff: 0 forces a full search next round, like the grid kernel does.
     if (BND) job.out_lb[out] = L.bi == 0x7fffffff ? 0.f : __double2float_rd(fmin(sqrt(L.second), sqrt(L.best) + (double)G.mu) * (1.0 - 1e-9));
+    if (BND && job.list.dirty) update_list_entry(job.list, i, L.bi == 0x7fffffff ? -1 : job.inv[L.bi], L.best, bound, false);
   }
   if (stats && (threadIdx.x & 63) == 0) {
     // wave-uniform counters: candidates examined PER LANE x active lanes, boxes tested per wave
     const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + wave;
     const unsigned long long act = (unsigned long long)min(64, job.n - (i & ~63));
     stats[8 * slot] = n_cand; stats[8 * slot + 1] = n_box; stats[8 * slot + 2] = (unsigned long long)n_cand * act;
+  }
+  if (stats && BND && job.cache) {
+    const unsigned long long hits = __popcll(__ballot(n_hit != 0u));
+    if ((threadIdx.x & 63) == 0) stats[8 * (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + wave) + 3] = hits;
   }
 }
 
@@ -511,7 +559,7 @@ int warm_nn_tile(mvicp_ctx* c) {   // see warm_nn_grid (nn_grid.hip): loads this
   return MVICP_OK;
 }
 
-int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound, bool with_bounds) {
+int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound, bool with_bounds, bool with_cache) {
   std::vector<TileJob> jobs;
   int max_n = 0;
   double nq = 0;
@@ -528,6 +576,11 @@ int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound, bool with_bounds) {
     j.inv = d.grid.inv;
     j.seed = (c->tile_seed && (int)c->nn_cache_edge.size() == c->E && c->nn_cache_edge[e]) ? 1 : 0;
     if (with_bounds) { j.out_lb = c->d_nn_lb + c->cap_off[e]; j.mu = (float)(c->tile_mu * d.grid.cell); }
+    if (with_bounds && with_cache) {
+      j.cache = 1;
+      j.list = ListRef{c->d_qpos + c->cap_off[e], c->d_second + c->cap_off[e], c->d_cd2 + c->cap_off[e], c->d_dirty + e, c->d_dirty_slots + c->dslot_off[e],
+                       c->d_stream + c->cap_off[e], c->total_cap, d.grid.snor, (const PointRec*)d.grid.srec};
+    }
     jobs.push_back(j);
     max_n = std::max(max_n, s.n);
     nq += s.n;
@@ -567,6 +620,7 @@ int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound, bool with_bounds) {
 #undef MVICP_TILE_K
   }
   MV_HIP(hipGetLastError());
+  if (with_bounds && with_cache) MV_CHECK(launch_dirty_reduce(c));   // per-edge OR of the "list membership changed" slots
   if (d_stats) {
     if (!c->h_census) MV_HIP(hipHostMalloc((void**)&c->h_census, 8 * sizeof(unsigned long long), hipHostMallocDefault));
     // counters -> pinned memory, asynchronously; census_resolve() folds them in after the caller's own wait (no extra sync)

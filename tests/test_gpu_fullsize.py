@@ -191,7 +191,7 @@ def test_cfg4_moving_rounds_cache_and_list_reuse_are_bit_identical(cfg4, curve):
     engs = []
     for on in (1, 0):
         e = mvicp.Engine(0)
-        e.set_option("nn_cache", on); e.set_option("list_reuse", on); e.set_option("sel_bracket", on)
+        e.set_option("nn_cache", on); e.set_option("list_reuse", on); e.set_option("sel_bracket", on)   # (nn_cache off also disables the cache-aware tile rounds)
         e.set_option("grid_curve", curve)   # 2: the default k-d order; 1: Hilbert order of the cells, which also has the brick map nn_cell needs
         e.set_option("nn_cell", on if curve == 1 else 0)
         e.set_frames(pb["pts"], pb["nor"]); e.set_graph(pb["src"], pb["dst"])

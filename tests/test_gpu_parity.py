@@ -667,6 +667,7 @@ def test_tile_kernel_lower_bounds_feed_the_temporal_cache(orc, mu):
     {"auto_settle": 0.05}, {"auto_settle": 5.0}, {"nn_cache": 0, "list_reuse": 0}, {"spin_wait": 1}, {"sel_bracket": 0},
     {"grid_curve": 0}, {"grid_curve": 1}, {"grid_target": 2.5}, {"nn_cell": 1}, {"nn_cell": 1, "auto_switch": 0.2}, {"nn_cell": 1, "auto_switch": 50.0}, {"nn_cell": 1, "prune_rho": 0.0},
     {"prune_rho": 3.0}, {"spec_eval": 0}, {"lin_share_p": 0}, {"tile_bounds": 0}, {"tile_bounds": 2}, {"tile_bounds": 2, "tile_mu": 0.5}, {"tile_mu": 0.005},
+    {"tile_cache": 0}, {"tile_cache": 0, "list_reuse": 0}, {"tile_cache": 1, "list_reuse": 0}, {"tile_cache": 1, "tile_mu": 0.5}, {"tile_cache": 1, "auto_settle": 5.0},
 ])
 def test_tuning_options_never_change_results(opts):
     """Every speed knob (kernel variants, seeding, cell pruning, AUTO hand-over policy, caches) must leave the whole ICP
