@@ -692,10 +692,11 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
         c->nn_cache_enable && !c->nn_cell && !all_same) { method = MVICP_NN_TILE; tile_lb = true; tile_cached = true; handed_over = true; }
   }
   {
-    // an edge may keep last round's compacted list only if the grid kernel (which checks every query) runs and the list
-    // on the device really is last round's result for this edge
+    // an edge may keep last round's compacted list only if a kernel that checks every query's acceptance and patches changed
+    // neighbours in place runs (the grid kernel, the tile kernel: nn_list.h) and the list on the device really is last round's result
+    // for this edge
     std::vector<int> dirty(E, 1);
-    if ((tile_cached || (method == MVICP_NN_GRID && !c->nn_tree_only && !c->nn_skip_far)) && c->list_reuse)
+    if ((method == MVICP_NN_TILE || (method == MVICP_NN_GRID && !c->nn_tree_only && !c->nn_skip_far)) && c->list_reuse)
       for (int e = 0; e < E; ++e) if (c->active[e] && c->list_valid[e]) dirty[e] = 0;
     std::memcpy(hd, dirty.data(), sizeof(int) * E);
   }
@@ -746,7 +747,7 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   c->far_narrow = nn_method == MVICP_NN_AUTO && method == MVICP_NN_GRID && c->nn_cache_valid && c->nn_cache_enable && all_same;   // the fixed point: (almost) every query is a cache hit
   if (method == MVICP_NN_BRUTE) MV_CHECK(launch_nn_brute_edges(c));
   else if (method == MVICP_NN_GRID) MV_CHECK(launch_nn_grid_edges(c, bound));
-  else if (method == MVICP_NN_TILE) MV_CHECK(launch_nn_tile_edges(c, bound, tile_lb, tile_cached));
+  else if (method == MVICP_NN_TILE) MV_CHECK(launch_nn_tile_edges(c, bound, tile_lb, tile_cached, c->list_reuse));
   else { set_error("unknown nn_method %d", nn_method); return MVICP_ERR_ARG; }
   // only the grid kernel and the tile kernel's BND build leave the per-query lower bounds the temporal cache needs; the cutoff must
   // not change either

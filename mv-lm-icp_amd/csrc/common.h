@@ -232,7 +232,7 @@ namespace mvicp {
 int launch_nn_brute_edges(mvicp_ctx* c);                                             // nn_brute.hip
 int launch_nn_brute_queries(mvicp_ctx* c, const FrameDev& f, const double* d_q, int n, int* d_idx, double* d_d2);
 int launch_nn_grid_edges(mvicp_ctx* c, double d2_bound);                              // nn_grid.hip
-int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound, bool with_bounds, bool with_cache);
+int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound, bool with_bounds, bool with_cache, bool with_list);
 int warm_nn_tile(mvicp_ctx* c); int warm_nn_grid(mvicp_ctx* c);                                    // code-object load at set-up time (mvicp_set_graph)                              // nn_tile.hip
 int build_wide(FrameDev& f, const double* sorted_pts);                                 // nn_tile.hip (host, called by build_grid)
 int launch_nn_grid_queries(mvicp_ctx* c, const FrameDev& f, const double* d_q, int n, int* d_idx, double* d_d2);

@@ -465,7 +465,10 @@ __global__ __launch_bounds__(NT, WPE) void nn_tile_kernel(const TileJob* __restr
     // every other target was evaluated exactly (>= second) or rejected by a screen (> sqrt(best) + mu away); 1e-9 relative covers the
     // fp64 roundings of this line.  No neighbour inside the cutoff: 0 forces a full search next round, like the grid kernel does.
     if (BND) job.out_lb[out] = L.bi == 0x7fffffff ? 0.f : __double2float_rd(fmin(sqrt(L.second), sqrt(L.best) + (double)G.mu) * (1.0 - 1e-9));
-    if (BND && job.list.dirty) update_list_entry(job.list, i, L.bi == 0x7fffffff ? -1 : job.inv[L.bi], L.best, bound, false);
+    // the edge's compacted list is maintained in place (nn_list.h) whenever the host handed it over (list.dirty != null): a query that
+    // keeps its acceptance patches its own entry and operands, so compaction + gather only run for edges whose MEMBERSHIP changed —
+    // also in the plain seeded rounds, where nearly every neighbour changes but hardly any acceptance does (round 3)
+    if (job.list.dirty) update_list_entry(job.list, i, L.bi == 0x7fffffff ? -1 : job.inv[L.bi], L.best, bound, false);
   }
   if (stats && (threadIdx.x & 63) == 0) {
     // wave-uniform counters: candidates examined PER LANE x active lanes, boxes tested per wave
@@ -559,7 +562,7 @@ int warm_nn_tile(mvicp_ctx* c) {   // see warm_nn_grid (nn_grid.hip): loads this
   return MVICP_OK;
 }
 
-int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound, bool with_bounds, bool with_cache) {
+int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound, bool with_bounds, bool with_cache, bool with_list) {
   std::vector<TileJob> jobs;
   int max_n = 0;
   double nq = 0;
@@ -576,8 +579,8 @@ int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound, bool with_bounds, bool w
     j.inv = d.grid.inv;
     j.seed = (c->tile_seed && (int)c->nn_cache_edge.size() == c->E && c->nn_cache_edge[e]) ? 1 : 0;
     if (with_bounds) { j.out_lb = c->d_nn_lb + c->cap_off[e]; j.mu = (float)(c->tile_mu * d.grid.cell); }
-    if (with_bounds && with_cache) {
-      j.cache = 1;
+    if (with_bounds && with_cache) j.cache = 1;
+    if (with_list) {
       j.list = ListRef{c->d_qpos + c->cap_off[e], c->d_second + c->cap_off[e], c->d_cd2 + c->cap_off[e], c->d_dirty + e, c->d_dirty_slots + c->dslot_off[e],
                        c->d_stream + c->cap_off[e], c->total_cap, d.grid.snor, (const PointRec*)d.grid.srec};
     }
@@ -620,7 +623,7 @@ int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound, bool with_bounds, bool w
 #undef MVICP_TILE_K
   }
   MV_HIP(hipGetLastError());
-  if (with_bounds && with_cache) MV_CHECK(launch_dirty_reduce(c));   // per-edge OR of the "list membership changed" slots
+  if (with_list) MV_CHECK(launch_dirty_reduce(c));   // per-edge OR of the "list membership changed" slots
   if (d_stats) {
     if (!c->h_census) MV_HIP(hipHostMalloc((void**)&c->h_census, 8 * sizeof(unsigned long long), hipHostMallocDefault));
     // counters -> pinned memory, asynchronously; census_resolve() folds them in after the caller's own wait (no extra sync)
