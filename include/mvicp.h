@@ -199,7 +199,8 @@ int mvicp_nn_census_ex(mvicp_ctx* ctx, double* out, int cap);
  * timed run). */
 int mvicp_profile_enable(mvicp_ctx* ctx, int on);
 int mvicp_profile_reset(mvicp_ctx* ctx);
-/* kernel in {"nn","compact","select","linearize","reduce"}: total ms, launches, algorithmic bytes. */
+/* kernel in {"nn","compact","gather","select","linearize","reduce","comm"} (HIP-event scopes) or a host timer ("host.correspond", "host.optimize",
+ * "host.evaluate", ...) or "spec.hit" (first evaluations served by the queued launch: launches only): total ms, launches, algorithmic bytes. */
 int mvicp_profile_get(mvicp_ctx* ctx, const char* kernel, double* total_ms, long long* launches, double* alg_bytes);
 /* Opaque hipStream_t the library launches on (so a harness can bracket it with its own events). */
 void* mvicp_stream(mvicp_ctx* ctx);

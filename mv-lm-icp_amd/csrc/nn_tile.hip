@@ -20,9 +20,14 @@
 //     keeping its running (d2, index) minimum.  Children are opened nearest-first (wave arg-min on the DPP network)
 //     so the running minima tighten before the siblings are tested;
 //   * from the second round on every lane starts from last round's neighbour (an ordinary candidate);
-//   * BND build (template flag; used for the one AUTO round that hands over to the grid kernel, api.cpp): the guard band is widened
-//     by mu and the exact second-best distance is tracked, which yields the per-query lower bound the grid kernel's temporal cache
-//     starts from (leaf_scan).  The plain build carries none of that state.
+//   * BND build (template flag; api.cpp): the guard band is widened by mu and the exact second-best distance is tracked, which yields
+//     the per-query lower bound the temporal cache needs (leaf_scan).  Used for the AUTO round that hands over from the plain build, and
+//     (round 3, "cache-aware" rounds) for every later round whose poses still move: there the kernel first runs the temporal-cache
+//     check of nn_grid_kernel as its prologue — a lane whose neighbour provably did not change is finished and sits the traversal
+//     out, the wave searches for its missed lanes only, a wave without a miss leaves at once.  The plain build carries none of that;
+//   * whenever the host hands the edge's compacted list over (TileJob::list), every answered lane maintains its own entry in place
+//     (nn_list.h: distance refresh, neighbour + operand patch, membership change -> edge dirty), so compaction + gather only run for
+//     edges whose membership changed — in the seeded plain rounds too.
 // The kernel is VALU-issue bound (not memory bound): its design minimises wave instructions per opened tile.
 // No per-lane pointer chasing, no divergence between "near" and "far" queries: the first-round regime
 // (centimetre misalignment) and the converged regime run the same code, the former just opens more leaves.
@@ -80,35 +85,9 @@ __device__ __forceinline__ void xf_point(const double* __restrict__ x, double p0
   q2 = __dadd_rn(__dadd_rn(__dmul_rn(x[12 + 2], u[0]), __dmul_rn(x[12 + 5], u[1])), __dmul_rn(x[12 + 8], u[2]));
 }
 
-// Wave-wide reductions on the DPP network (row quad-perm / mirror steps, then row_bcast15 / row_bcast31; lane 63 ends up
-// with the result, broadcast through readlane -> SGPRs).  __shfl_xor would go through ds_bpermute: ~12 LDS-crossbar round
-// trips per fp64 reduction, and this kernel reduces once per traversal step.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false); }
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_d(double v) {
-  return __hiloint2double(dpp_i<CTRL, ROW_MASK>(__double2hiint(v)), dpp_i<CTRL, ROW_MASK>(__double2loint(v)));
-}
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_f(float v) { return __int_as_float(dpp_i<CTRL, ROW_MASK>(__float_as_int(v))); }
-__device__ __forceinline__ double uniform_d(double v, int lane) {
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
-}
-#define MVICP_WAVE_REDUCE(T, DPP, OP, v)                              \
-  v = OP(v, DPP<0xB1, 0xf>(v));  /* quad_perm [1,0,3,2] */           \
-  v = OP(v, DPP<0x4E, 0xf>(v));  /* quad_perm [2,3,0,1] */           \
-  v = OP(v, DPP<0x141, 0xf>(v)); /* row_half_mirror */               \
-  v = OP(v, DPP<0x140, 0xf>(v)); /* row_mirror: every lane = row result */ \
-  v = OP(v, DPP<0x142, 0xa>(v)); /* row_bcast15 -> rows 1, 3 */       \
-  v = OP(v, DPP<0x143, 0xc>(v)); /* row_bcast31 -> rows 2, 3 */
-__device__ __forceinline__ double wave_max(double v) {
-  MVICP_WAVE_REDUCE(double, dpp_d, fmax, v)
-  return uniform_d(v, 63);
-}
-__device__ __forceinline__ double wave_min(double v) {
-  MVICP_WAVE_REDUCE(double, dpp_d, fmin, v)
-  return uniform_d(v, 63);
-}
+// Wave-wide reductions on the DPP network (row quad-perm / mirror steps, then row_bcast15 / row_bcast31; lane 63 ends up with the
+// result, broadcast through readlane -> SGPRs).  __shfl_xor would go through ds_bpermute: ~12 LDS-crossbar round trips per reduction,
+// and this kernel reduces once per traversal step.
 // fp32 reductions of NON-NEGATIVE values (incl. +inf): their bit patterns order like unsigned integers, so the whole
 // reduction is six v_min_u32 / v_max_u32 with the DPP permutation fused into the operand (the builtin form costs a
 // mov + mov_dpp + op per step).  "s_nop 1": a VALU result needs two wait states before a DPP read of it.
