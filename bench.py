@@ -233,34 +233,51 @@ def main():
             exchange = "host-staged gloo all-reduce (RCCL init failed; --allow-host-exchange)"
     method = {"auto": L.NN_AUTO, "brute": L.NN_BRUTE, "grid": L.NN_GRID, "tile": L.NN_TILE}[args.nn]
 
-    poses = pb["init"].copy()
-    log = []
+    # The timed loop keeps the poses in the engine's own K x 16 column-major buffer between the two calls of a round (what a C++ driver
+    # does) and only records raw numbers; everything derived (dicts, pose comparisons, the (K,4,4) views) is worked out after the clock stops.
+    rb = eng.round_state(K, pb["fixed"])
+    Pc = rb["P"]                                   # in/out of mvicp_optimize
+    init_c = L.poses_to_c(pb["init"])
+    np.copyto(Pc, init_c)
+    raw = []                                       # per global round: (g, t_nn, t_lm, iterations, evaluations, successful_steps, corr, poses after)
     state = {"g": 0}              # global round counter (warm-up + timed): round g % 20 + 1 of registration g // 20 + 1
+    thresh32 = np.float32(0.05)
+
+    def step():
+        g = state["g"]
+        t0 = time.perf_counter()
+        if g % ROUNDS_PER_REGISTRATION == 0 and g > 0:
+            # a new run of the reference program on the same clouds: same noisy initial poses (default-seeded noise), no memory of the last run
+            eng.reset_history()
+            np.copyto(Pc, init_c)
+        eng.correspond_raw(thresh32, method)
+        t1 = time.perf_counter()
+        sm = eng.optimize_raw(param, plane, True, 50)
+        t2 = time.perf_counter()
+        raw.append((g, t1 - t0, t2 - t1, sm.iterations, sm.evaluations, sm.successful_steps, int(rb["counts"].sum()), Pc.copy()))
+        state["g"] = g + 1
+
     poses_after = {}              # registration 1 only: poses after round r (1-based), for the CPU-path comparison
     iters_of = {}
 
-    def step():
-        nonlocal poses
-        g = state["g"]
-        reg, rnd = divmod(g, ROUNDS_PER_REGISTRATION)
-        t0 = time.perf_counter()
-        if rnd == 0 and g > 0:
-            # a new run of the reference program on the same clouds: same noisy initial poses (default-seeded noise), no memory of the last run
-            eng.reset_history()
-            poses = pb["init"].copy()
-        before = poses
-        counts, weights = eng.correspond(poses, pb["fixed"], 0.05, method)
-        t1 = time.perf_counter()
-        poses, sm = eng.optimize(poses, pb["fixed"], param, plane, True, 50)
-        t2 = time.perf_counter()
-        log.append({"registration": reg + 1, "round": rnd + 1, "nn_ms": (t1 - t0) * 1e3, "lm_ms": (t2 - t1) * 1e3, "lm_iters": sm["iterations"], "evals": sm["evaluations"],
-                    "corr": int(counts.sum()), "steps_taken": sm["successful_steps"], "moved": sm["successful_steps"] > 0,
-                    "poses_bit_identical": bool(np.array_equal(before, poses))})
-        if reg == 0:
-            poses_after[rnd + 1] = poses.copy(); iters_of[rnd + 1] = sm["iterations"]
-        elif rnd + 1 in poses_after and not np.array_equal(poses_after[rnd + 1], poses):
-            state["replay_mismatch"] = True      # a later registration must retrace registration 1 bit for bit
-        state["g"] = g + 1
+    def digest(rows):
+        """raw rows -> the per-round log (after the clock stopped); also fills poses_after / iters_of and checks that later registrations
+        retrace the first one bit for bit."""
+        out = []
+        for (g, t_nn, t_lm, its, evals, steps, corr, P16) in rows:
+            reg, rnd = divmod(g, ROUNDS_PER_REGISTRATION)
+            P = L.poses_from_c(P16)
+            before = pb["init"] if rnd == 0 else prev_of.get((reg, rnd))
+            out.append({"registration": reg + 1, "round": rnd + 1, "nn_ms": t_nn * 1e3, "lm_ms": t_lm * 1e3, "lm_iters": its, "evals": evals, "corr": corr,
+                        "steps_taken": steps, "moved": steps > 0, "poses_bit_identical": bool(before is not None and np.array_equal(before, P))})
+            prev_of[(reg, rnd + 1)] = P
+            if reg == 0:
+                poses_after[rnd + 1] = P; iters_of[rnd + 1] = its
+            elif rnd + 1 in poses_after and not np.array_equal(poses_after[rnd + 1], P):
+                state["replay_mismatch"] = True      # a later registration must retrace registration 1 bit for bit
+        return out
+
+    prev_of = {}
 
     def fence():
         if world > 1:
@@ -272,13 +289,15 @@ def main():
         step()
     eng.profile(2)   # live HIP-event scopes around the two roofline kernels only ("nn", "linearize") + the collective; everything else: replay pass below
     eng.profile_reset()
-    log.clear()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    digest(raw[:args.warmup])                       # warm-up rounds: only their poses matter (registration 1)
+    log = digest(raw[args.warmup:])
+    raw.clear()
     local_elapsed = elapsed
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -291,8 +310,7 @@ def main():
                                                             "host.corr.finish", "host.optimize", "host.evaluate")}
     eng.profile(False)
     timed_log = list(log)
-    final_poses = poses.copy()
-    g_end = state["g"]
+    final_poses = L.poses_from_c(Pc)
 
     # Replay pass (UNTIMED): the same global rounds again (same registrations, same resets), now with every profiling scope and the NN
     # census on (per-launch candidate / box / cache-hit counts = the algorithmic bytes of every NN launch).  The engine is
@@ -303,7 +321,7 @@ def main():
     replay_identical = None
     if not args.no_replay:
         eng.reset_history()
-        poses = pb["init"].copy()
+        np.copyto(Pc, init_c)
         state["g"] = 0
         for _ in range(args.warmup):
             step()
@@ -317,17 +335,19 @@ def main():
         census = eng.nn_census()
         eng.set_option("nn_census", 0)
         eng.profile(False)
-        replay_identical = bool(np.array_equal(poses, final_poses)) and not state.get("replay_mismatch", False)
+        prev_of.clear(); digest(raw); raw.clear()
+        replay_identical = bool(np.array_equal(L.poses_from_c(Pc), final_poses)) and not state.get("replay_mismatch", False)
     # registration 1 beyond the rounds the loop walked (untimed): the CPU-path comparison needs its first rounds
     cpu_rounds = args.cpu_rounds if args.cpu_rounds is not None else (8 if 2.0 * K * N <= 3e7 else 2)
     cpu_rounds = max(1, min(cpu_rounds, ROUNDS_PER_REGISTRATION))
     if world == 1 and not args.no_cpu_baseline and max(poses_after, default=0) < cpu_rounds:
         eng.reset_history()
-        poses = pb["init"].copy()
+        np.copyto(Pc, init_c)
         state["g"] = 0
         for _ in range(cpu_rounds):
             step()
-    log[:] = timed_log
+        prev_of.clear(); digest(raw); raw.clear()
+    log = timed_log
     window_rounds = [l["round"] for l in log]
 
     # ---- roofline.  Time and launch count: live HIP events in the timed region.  Algorithmic bytes:

@@ -137,7 +137,7 @@ void free_graph(mvicp_ctx* c) {
   dev_free(c->d_chunk_first); dev_free(c->d_partials); dev_free(c->d_out);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   c->h_pin = nullptr; c->h_pin_doubles = 0; c->d_res_host = nullptr; c->d_blocks_host = nullptr; c->lin_out = nullptr;
-  c->census_pending = false; c->spec_ready = false; c->spec_arm = false; c->d_spec_host = nullptr; c->d_adev_host = nullptr; c->d_res_target = nullptr;
+  c->census_pending = false; c->spec_ready = false; c->spec_arm = false; c->d_spec_host = nullptr; c->d_adev_host = nullptr; c->d_res_target = nullptr; c->d_a_check = nullptr;
   c->E = 0; c->total_cap = 0; c->n_cblocks = 0; c->n_chunks = 0; c->have_corr = false;
 }
 
@@ -730,7 +730,7 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
     for (int e = 0; e < E; ++e) if (!(fixed && fixed[c->esrc[e]]) && c->frames[c->edst[e]].n > 0 && c->frames[c->edst[e]].grid.snor == nullptr) c->spec_arm = false;
   const size_t nb = (size_t)E * MVICP_EDGE_BLOCK, ntail = 3 * (size_t)E + 1;   // tail = (count, median d2) x E | armed | a x E
   c->d_res_target = exchange ? c->d_out + nb : nullptr;
-  double* const a_chk_dev = exchange ? c->d_out + nb + 2 * (size_t)E + 1 : c->d_adev_host;
+  c->d_a_check = exchange ? c->d_out + nb + 2 * (size_t)E + 1 : c->d_adev_host;   // where the select kernels copy the scales they derive
   size_t upload_doubles = c->ctl_r1;
   if (c->spec_arm) {
     // the solve evaluates at x_to_pose(pose_to_x(P)) (host/lm.cpp): the same round trip here, so the poses match bit for bit.  The
@@ -763,10 +763,8 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
     MV_CHECK(launch_compact(c, bound));
     MV_CHECK(launch_gather_stream(c));
   }
-  double* const a_chk_saved = c->d_adev_host;
-  c->d_adev_host = a_chk_dev;   // (the select kernels copy the scales they derive to this address; restored below)
   int st_sel = use_bracket ? launch_select_bracket(c) : launch_select_median(c);
-  if (st_sel != MVICP_OK) { c->d_adev_host = a_chk_saved; c->spec_flags_valid = false; return st_sel; }
+  if (st_sel != MVICP_OK) { c->spec_flags_valid = false; return st_sel; }
   // the queued first evaluation (its relative transforms went up with the control block).  With N > 1 ranks: ONE collective per
   // search — [E x 91 blocks | (count, median d2) x E | armed | a x E], always the full buffer — and ONE wait.
   int st_q = MVICP_OK;
@@ -785,7 +783,7 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   // (count, median d2) per edge arrive in mapped host memory, written by select_final_kernel (single rank), or summed over ranks
   // behind the blocks; weight = (float)(1.5 * sqrt(median d2))  (frame.cpp:168-176)
   if (st_q == MVICP_OK) st_q = stream_wait(c);
-  if (st_q != MVICP_OK) { c->d_adev_host = a_chk_saved; c->spec_flags_valid = false; c->spec_arm = false; return st_q; }
+  if (st_q != MVICP_OK) { c->spec_flags_valid = false; c->spec_arm = false; return st_q; }
   census_resolve(c);
   mark("host.corr.wait");
   const double* hr = exchange ? c->h_pin + c->pin_spec_off + nb : c->h_pin + c->pin_res_off;
@@ -806,10 +804,9 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
         }
       }
       if (st_r == MVICP_OK) st_r = stream_wait(c);
-      if (st_r != MVICP_OK) { c->d_adev_host = a_chk_saved; c->spec_flags_valid = false; c->spec_arm = false; return st_r; }
+      if (st_r != MVICP_OK) { c->spec_flags_valid = false; c->spec_arm = false; return st_r; }
     }
   }
-  c->d_adev_host = a_chk_saved;
   for (int e = 0; e < E; ++e) {
     if (!(c->owned[e] && c->active[e])) { c->sel_med1[e] = c->sel_med2[e] = -1.0; continue; }
     c->sel_med2[e] = c->sel_med1[e];

@@ -33,7 +33,7 @@ void set_error(const char* fmt, ...);
 constexpr int kLinPartial = 32;      // doubles per linearize workgroup partial (28 plane / 29 point, padded)
 constexpr int kLinThreads = 256;
 constexpr int kCompactBlock = 1024;  // queries per compaction workgroup
-constexpr int kSelBlock = 4096;      // keys per radix-select workgroup
+constexpr int kSelBlock = 8192;      // keys per radix-select workgroup
 constexpr int kEdgeXf = 40;          // Rs(9) ts(3) Rdinv(9) td(3), column-major; [24] = temporal-cache switch (>= 0: on, value =
                                      // rounding allowance in metres), [25..36] = dM (9, col-major) dv (3): change of the query map
                                      // q = M p + v since the last search, so a query moved by exactly |dM p + dv|
@@ -172,6 +172,7 @@ struct mvicp_ctx {
   bool spec_ready = false;          // blocks of spec_poses are in the pinned spec region
   std::vector<double> spec_poses;   // n_frames x 16: poses the speculative evaluation was made at (after the parameterization round trip)
   size_t pin_spec_off = 0, pin_adev_off = 0; double* d_spec_host = nullptr; double* d_adev_host = nullptr;
+  double* d_a_check = nullptr;      // where this search's select kernels copy the SoftLOne scales they derive: mapped host memory (single rank) or d_out's tail
   bool spin_wait = false;           // poll the stream instead of a blocking wait (measured: no gain, HIP's own wait already spins)
   unsigned long long* h_census = nullptr;   // pinned: 8 counters of the last NN launch, resolved after the round's own sync
   bool census_pending = false; double census_nq = 0; int census_kind = 0;   // kind: 0 grid (per-lane), 1 tree-only grid, 2 tile, 3 grid (cell staging)

@@ -567,7 +567,7 @@ int launch_select_bracket(mvicp_ctx* c) {
   }
   hipLaunchKernelGGL(bracket_final_kernel, dim3(c->E), dim3(NT), 0, c->stream, c->E, c->d_count, c->d_cap_off, c->d_sel_keys1, cnt_lt,
                      cnt_mid, c->d_median, c->d_res_target ? c->d_res_target : c->d_res_host, c->spec_arm ? c->d_a : (double*)nullptr,
-                     c->spec_arm ? c->d_adev_host : (double*)nullptr, c->spec_arm ? 1.0 : 0.0);
+                     c->spec_arm ? c->d_a_check : (double*)nullptr, c->spec_arm ? 1.0 : 0.0);
   MV_HIP(hipGetLastError());
   return MVICP_OK;
 }
@@ -597,7 +597,7 @@ int launch_select_median(mvicp_ctx* c) {
   }
   hipLaunchKernelGGL(select_final_kernel, dim3(c->E), dim3(NT), 0, c->stream, c->E, c->d_count, c->d_cap_off, c->d_sel_keys2, (const unsigned int*)cnt2,
                      (const unsigned int*)hist, (const SelState*)st, c->d_median, c->d_res_target ? c->d_res_target : c->d_res_host,
-                     c->spec_arm ? c->d_a : (double*)nullptr, c->spec_arm ? c->d_adev_host : (double*)nullptr, c->spec_arm ? 1.0 : 0.0);
+                     c->spec_arm ? c->d_a : (double*)nullptr, c->spec_arm ? c->d_a_check : (double*)nullptr, c->spec_arm ? 1.0 : 0.0);
   MV_HIP(hipGetLastError());
   return MVICP_OK;
 }

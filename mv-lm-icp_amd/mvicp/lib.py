@@ -264,6 +264,23 @@ class Engine:
         self.counts = b["counts"].copy()
         return self.counts, b["weights"].copy()
 
+    # ---- the per-round calls without the (K,4,4) <-> column-major conversions: the caller keeps the poses in the engine's own K x 16
+    # buffer (Eigen's layout) between the calls, like a C++ driver does.  bench.py's timed loop uses these.
+    def round_state(self, K, fixed):
+        """-> dict with "P" (K x 16 column-major poses, in/out), "counts", "weights", "sm" (the Summary struct of the last optimize_raw)."""
+        b = self._round_buffers(K)
+        b["fx"][:] = fixed
+        return b
+
+    def correspond_raw(self, thresh, nn_method=NN_AUTO):
+        b = self._rb
+        _check(self.lib, self.lib.mvicp_correspond(self.h, b["pP"], b["pfx"], thresh, nn_method, b["pc"], b["pw"]))
+
+    def optimize_raw(self, param, point_to_plane, robust, max_iterations=50):
+        b = self._rb
+        _check(self.lib, self.lib.mvicp_optimize(self.h, b["pP"], b["pfx"], param, int(point_to_plane), int(robust), max_iterations, b["psm"]))
+        return b["sm"]
+
     def get_correspondences(self, edge):
         cap = self.npts[self.src[edge]]
         first = np.zeros(cap, dtype=np.int32)
