@@ -11,6 +11,8 @@ cat gpurun_out/fin3_tests.txt
 if grep -q "failed\|Error" gpurun_out/fin3_tests.txt || ! grep -q "passed" gpurun_out/fin3_tests.txt; then echo TESTS_NOT_GREEN; exit 0; fi
 ROUND=$R bash tools/profile.sh cfg4 5 20
 ROUND=$R bash tools/profile.sh cfg4 1 19
+# the bench lines below quote `traffic` from these summaries (same sources, same arguments): put them where bench.py looks
+for t in w5s20 w1s19; do cp gpurun_out/prof/${R}_cfg4_$t/${R}_cfg4_${t}_kernels.json gpurun_out/prof/${R}_cfg4_$t/${R}_cfg4_${t}_summary.txt profiles/ 2>/dev/null; done
 timeout 400 python bench.py --warmup 5 --steps 20 > gpurun_out/fin3_cfg4_w5s20.json 2> gpurun_out/fin3_cfg4_w5s20.err
 timeout 400 python bench.py > gpurun_out/fin3_cfg4.json 2> gpurun_out/fin3_cfg4.err
 for wl in cfg2 cfg3 shard8 shard8_cfg5 cfg5; do timeout 300 python bench.py --workload $wl --warmup 5 --steps 20 --no-cpu-baseline > gpurun_out/fin3_$wl.json 2> gpurun_out/fin3_$wl.err; done
