@@ -876,3 +876,65 @@ def test_changed_fixed_mask_at_identical_poses_is_not_mistaken_for_a_fixed_point
             assert np.array_equal(c, cf) and w.tobytes() == wf.tobytes() and np.array_equal(blk, bf), m
             assert all(c[e] == 0 for e in range(len(src)) if m[src[e]])
     eng.close()
+
+
+# ---------------------------------------------------------------- randomised shapes (round 3)
+def _random_cloud(rng, n, kind, scale):
+    if kind == "blob":
+        p = rng.normal(0.0, 0.05, (n, 3))
+    elif kind == "line":
+        p = np.outer(rng.uniform(-1, 1, n), [0.3, -0.2, 0.1]) + rng.normal(0.0, 1e-6, (n, 3))
+    elif kind == "plane":
+        p = np.column_stack([rng.uniform(-0.2, 0.2, n), rng.uniform(-0.2, 0.2, n), np.zeros(n)])
+    elif kind == "lattice":   # exact ties between targets everywhere (a range-image grid, like the Bunny scans)
+        side = int(np.ceil(n ** 0.5))
+        g = np.stack(np.meshgrid(np.arange(side), np.arange(side), indexing="ij"), -1).reshape(-1, 2)[:n].astype(np.float64)
+        p = np.column_stack([g * 0.0078125, np.full(n, 0.25)])
+    else:                      # two well-separated clusters (queries far from most of the cloud)
+        p = np.vstack([rng.normal(-0.5, 0.01, (n // 2, 3)), rng.normal(0.5, 0.01, (n - n // 2, 3))])
+    return np.ascontiguousarray(p * scale)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_shapes_every_kernel_and_the_cached_rounds(eng, orc, seed):
+    """Irregular inputs the synthetic surfaces never produce: 1..900 points per cloud, degenerate shapes, exact ties, coordinates scaled
+    over five decades.  (1) every NN kernel against the oracle's brute force; (2) three AUTO rounds with slightly moving poses, so that the
+    seeded tile rounds, the hand-over, the temporal cache and the in-place lists all run on them, each round against the oracle."""
+    rng = np.random.default_rng(100 + seed)
+    kinds = ["blob", "line", "plane", "lattice", "clusters"]
+    scale = float(10.0 ** rng.integers(-3, 3))
+    K = 3
+    top = 6000 if seed % 4 == 3 else 900
+    pts = [_random_cloud(rng, int(rng.integers(1, top)), kinds[int(rng.integers(0, 5))], scale) for _ in range(K)]
+    # (1) single queries
+    eng.set_frames(pts, None)
+    q = np.vstack([pts[1][: min(len(pts[1]), 64)], _random_cloud(rng, 97, "blob", scale)])
+    for m in METHODS:
+        idx, d2 = eng.nn_query(0, q, m)
+        oi, od = orc.nn_brute(pts[0], q)
+        assert np.array_equal(idx, oi) and np.array_equal(d2, od), (seed, m)
+    # (2) rounds
+    src = np.array([1, 2, 2], dtype=np.int32); dst = np.array([0, 0, 1], dtype=np.int32)
+    fixed = np.array([1, 0, 0], dtype=np.int32)
+    eng2 = mvicp.Engine(0)
+    try:
+        eng2.set_frames(pts, None); eng2.set_graph(src, dst)
+        thresh = np.float32(0.3 * scale)
+        poses = np.stack([np.eye(4)] * K)
+        for r in range(4):
+            for k in range(1, K):   # a small rigid motion per round, shrinking: the later rounds are cache hits
+                a = rng.normal(0.0, 0.02 / 4 ** r)
+                Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+                poses[k, :3, :3] = Rz @ poses[k, :3, :3]
+                poses[k, :3, 3] += rng.normal(0.0, 0.003 * scale / 4 ** r, 3)
+            counts, weights = eng2.correspond(poses, fixed, thresh, L.NN_AUTO)
+            for e, (s, d) in enumerate(zip(src, dst)):
+                f, sec, dist, w, _, _ = orc.correspond_edge(pts[s], poses[s], pts[d], poses[d], thresh)
+                gf, gs, gd = eng2.get_correspondences(e)
+                assert counts[e] == len(f), (seed, r, e)
+                assert np.array_equal(gf, f) and np.array_equal(gs, sec) and np.array_equal(gd, dist), (seed, r, e)
+                assert weights[e] == (w if len(f) else 0), (seed, r, e)
+        counts2, weights2 = eng2.correspond(poses, fixed, thresh, L.NN_AUTO)   # same poses again
+        assert np.array_equal(counts2, counts) and weights2.tobytes() == weights.tobytes()
+    finally:
+        eng2.close()
