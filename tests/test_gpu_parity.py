@@ -938,3 +938,43 @@ def test_random_shapes_every_kernel_and_the_cached_rounds(eng, orc, seed):
         assert np.array_equal(counts2, counts) and weights2.tobytes() == weights.tobytes()
     finally:
         eng2.close()
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_random_graphs_costs_and_parameterizations(eng, orc, seed):
+    """Random pose graphs (2..6 views, arbitrary directed edges incl. several into one target and edges out of fixed frames), random fixed
+    masks (view 0 always fixed, as in the reference), every parameterization / cost / loss combination: per-edge blocks and the whole solve against the oracle."""
+    rng = np.random.default_rng(500 + seed)
+    K = int(rng.integers(2, 7))
+    pb = synth.make_problem(K, int(rng.integers(600, 2500)), pose_seed=int(7000 + seed))
+    pairs = [(s, d) for s in range(K) for d in range(K) if s != d]
+    pick = rng.choice(len(pairs), size=int(rng.integers(1, min(len(pairs), 8) + 1)), replace=False)
+    src = np.array([pairs[i][0] for i in sorted(pick)], dtype=np.int32)
+    dst = np.array([pairs[i][1] for i in sorted(pick)], dtype=np.int32)
+    fixed = (rng.uniform(size=K) < 0.3).astype(np.int32)
+    fixed[0] = 1                                 # the reference always fixes view 0 (icp-ceres.cpp:244,341,417; mvicp_optimize forces it)
+    param = [L.PARAM_SOPHUS_SE3, L.PARAM_ANGLE_AXIS, L.PARAM_EIGEN_QUATERNION][seed % 3]
+    plane, robust = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+    eng.set_frames(pb["pts"], pb["nor"])
+    eng.set_graph(src, dst)
+    counts, weights = eng.correspond(pb["init"], fixed, 0.05)
+    corr = [eng.get_correspondences(e)[:2] for e in range(eng.E)]
+    got = eng.linearize(pb["init"], plane, robust)
+    want = orc.edge_blocks(pb["pts"], pb["nor"], src, dst, corr, weights, pb["init"], plane, robust)
+    for e in range(eng.E):
+        if counts[e] == 0:
+            assert np.all(got[e] == 0)
+            continue
+        scale = np.abs(want[e, :78]).max()
+        assert np.allclose(got[e, :78], want[e, :78], rtol=0, atol=1e-11 * scale), (seed, e)
+        assert np.allclose(got[e, 78:90], want[e, 78:90], rtol=0, atol=1e-10 * (np.abs(want[e, 78:90]).max() + 1e-300)), (seed, e)
+        assert abs(got[e, 90] - want[e, 90]) <= 1e-12 * abs(want[e, 90]) + 1e-300, (seed, e)
+    P, sm = eng.optimize(pb["init"], fixed, param, plane, bool(robust), 50)
+    prob = orc.make_problem(pb["pts"], pb["nor"], fixed, src, dst, corr, weights, param, plane, robust)
+    P_ref, sm_ref = orc.optimize(prob, pb["init"], 50)
+    assert sm["iterations"] == sm_ref["iterations"] and sm["termination"] == sm_ref["termination"], (seed, sm, sm_ref)
+    for k in range(K):
+        dt, dr = synth.pose_diff(P[k], P_ref[k])
+        assert dt < 1e-8 and dr < 1e-8, (seed, k, dt, dr)
+        if fixed[k]:
+            assert synth.pose_diff(P[k], pb["init"][k])[0] < 1e-12
