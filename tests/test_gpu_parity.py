@@ -978,3 +978,28 @@ def test_random_graphs_costs_and_parameterizations(eng, orc, seed):
         assert dt < 1e-8 and dr < 1e-8, (seed, k, dt, dr)
         if fixed[k]:
             assert synth.pose_diff(P[k], pb["init"][k])[0] < 1e-12
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_random_shapes_knn_lists_equal_nanoflann(eng, refnn, seed):
+    """Row f1 beyond the Bunny lattice: k-NN lists of random clouds — blobs, jittered and exact lattices (ties at every place), planes,
+    clusters, duplicated points; 12..3000 points, k = 3 / 10 / 16 — element for element against the real nanoflann's knnSearch
+    (tie order = the order its tree visits the leaves, csrc/kdvisit.h)."""
+    if refnn is None:
+        pytest.skip("oracle/_ref was not built")
+    rng = np.random.default_rng(900 + seed)
+    kind = ["blob", "lattice", "plane", "clusters", "lattice"][seed % 5]
+    n = int(rng.integers(12, 3000))
+    pts = _random_cloud(rng, n, kind, float(10.0 ** rng.integers(-2, 2)))
+    if seed % 4 == 1:
+        pts[n // 2:] = pts[: n - n // 2]      # exact duplicates
+    if seed % 5 == 1:
+        pts[:, 2] += np.round(rng.normal(0, 2, n)) * 0.0078125 * 0.5   # a quantised third coordinate, like a range image
+    k = [3, 10, 16][seed % 3]
+    eng.set_frames([pts], None)
+    nrm, knn = eng.recompute_normals(0, k, want_knn=True)
+    gi, gd = refnn.knn_self(pts, k)
+    e = pts[:, None, :] - pts[knn]
+    myd = (e[:, :, 0] * e[:, :, 0] + e[:, :, 1] * e[:, :, 1]) + e[:, :, 2] * e[:, :, 2]
+    assert np.array_equal(myd, gd), seed
+    assert np.array_equal(knn, gi), (seed, int((~np.all(knn == gi, axis=1)).sum()))
