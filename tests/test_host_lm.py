@@ -90,3 +90,37 @@ def test_edges_from_a_fixed_source_are_excluded(orc, param):
     for k in range(4):
         dt, dr = synth.pose_diff(P[k], P_kept[k])
         assert dt < 1e-9 and dr < 1e-9, (k, dt, dr)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_pose_graphs(orc, seed):
+    """Arbitrary directed pose graphs (not the ring the drivers build: several edges into one view, edges out of fixed views, views nobody
+    constrains), random fixed masks with view 0 fixed as in the reference, every parameterization / cost / loss: the host solve (general
+    sparsity path of the factorisation) against the oracle's."""
+    rng = np.random.default_rng(300 + seed)
+    K = int(rng.integers(2, 7))
+    pb = synth.make_problem(K, int(rng.integers(150, 500)), pose_seed=int(4000 + seed))
+    pairs = [(s, d) for s in range(K) for d in range(K) if s != d]
+    pick = sorted(rng.choice(len(pairs), size=int(rng.integers(1, min(len(pairs), 8) + 1)), replace=False))
+    src = np.array([pairs[i][0] for i in pick], dtype=np.int32); dst = np.array([pairs[i][1] for i in pick], dtype=np.int32)
+    fixed = (rng.uniform(size=K) < 0.3).astype(np.int32); fixed[0] = 1
+    param = PARAMS[seed % 3]
+    plane, robust = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+    corr, w = [], []
+    for s, d in zip(src, dst):
+        if fixed[s]:
+            corr.append((np.zeros(0, np.int32), np.zeros(0, np.int32))); w.append(0.0)
+            continue
+        f, sec, dist, wt, _, _ = orc.correspond_edge(pb["pts"][s], pb["init"][s], pb["pts"][d], pb["init"][d], 0.05)
+        corr.append((f, sec)); w.append(float(wt))
+    prob = orc.make_problem(pb["pts"], pb["nor"], fixed, src, dst, corr, w, param, plane, robust)
+    P_ref, sm_ref = orc.optimize(prob, pb["init"], 50)
+
+    def evaluator(poses):
+        return orc.edge_blocks(pb["pts"], pb["nor"], src, dst, corr, w, poses, plane, robust)
+
+    P, sm = L.lm_solve_host(K, src, dst, pb["init"], fixed, param, evaluator, 50)
+    assert sm["termination"] == sm_ref["termination"] and sm["iterations"] == sm_ref["iterations"], (seed, sm, sm_ref)
+    for k in range(K):
+        dt, dr = synth.pose_diff(P[k], P_ref[k])
+        assert dt < 1e-8 and dr < 1e-8, (seed, k, dt, dr)
