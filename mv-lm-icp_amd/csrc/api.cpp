@@ -239,6 +239,7 @@ void census_resolve(mvicp_ctx* c) {
     // box once per wave (24 B); the per-lane distance evaluations (st[2]) are served from LDS.
     pe.bytes += 28.0 * (double)st[0] + 24.0 * (double)st[1];
     c->nn_candidates += (double)st[2]; c->nn_nodes += (double)st[1]; c->nn_queries += nq;
+    for (int k = 0; k < 4; ++k) c->nn_dbg[k] += (double)st[4 + k];
     c->nn_hits += (double)st[3]; pe.bytes += 36.0 * (double)st[3];   // cache-aware rounds: lanes answered by the temporal cache (index, bound, neighbour point, bound write)
   } else {
     // cache hit: previous index 4 B + fp32 bound 4 B + one 24-B point + bound write 4 B; searched query: 8 hash slots x 16 B + bound
@@ -525,7 +526,7 @@ int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) t
     MV_HIP(hipMalloc(&c->d_far_list, sizeof(int) * 2 * cap));
     c->far_cap = cap;
   }
-  MV_CHECK(warm_nn_grid(c)); MV_CHECK(warm_nn_tile(c));
+  MV_CHECK(warm_nn_grid(c)); MV_CHECK(warm_nn_tile(c)); MV_CHECK(warm_nn_mfma(c));
   MV_CHECK(dev_alloc(&c->d_median, E));
   MV_CHECK(dev_alloc(&c->d_chunk_edge, (size_t)c->n_chunks)); MV_CHECK(dev_alloc(&c->d_chunk_start, (size_t)c->n_chunks));
   MV_CHECK(dev_alloc(&c->d_chunk_first, E + 1));
@@ -973,6 +974,9 @@ int mvicp_set_option(mvicp_ctx* c, const char* name, double value) try {
   if (std::strcmp(name, "tile_seed") == 0) { c->tile_seed = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "tile_bounds") == 0) { c->tile_bounds = (int)value; return MVICP_OK; }
   if (std::strcmp(name, "tile_mu") == 0) { if (!(value > 0.0 && value <= 1.0)) { set_error("tile_mu outside (0, 1]"); return MVICP_ERR_ARG; } c->tile_mu = value; return MVICP_OK; }
+  if (std::strcmp(name, "mfma_kacc") == 0) { if (!(value >= 1.0 && value <= 1024.0)) { set_error("mfma_kacc outside [1, 1024]"); return MVICP_ERR_ARG; } c->mfma_kacc = value; return MVICP_OK; }
+  if (std::strcmp(name, "mfma_trig") == 0) { c->mfma_trig = (int)value; return MVICP_OK; }
+  if (std::strcmp(name, "tile_mfma") == 0) { c->tile_mfma = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "tile_waves") == 0) { c->tile_waves = (int)value; return MVICP_OK; }
   if (std::strcmp(name, "tile_cache") == 0) { c->tile_cache = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "spin_wait") == 0) { c->spin_wait = value != 0.0; return MVICP_OK; }
@@ -988,8 +992,8 @@ int mvicp_set_option(mvicp_ctx* c, const char* name, double value) try {
 int mvicp_nn_census_ex(mvicp_ctx* c, double* out, int cap) try {
   MV_CHECK(bind(c));
   if (!out || cap < 0) { set_error("bad output buffer"); return MVICP_ERR_ARG; }
-  const double v[6] = {c->nn_queries, c->nn_candidates, c->nn_nodes, c->nn_far, c->nn_hits, c->nn_fetched};
-  const int n = std::min(cap, 6);
+  const double v[10] = {c->nn_queries, c->nn_candidates, c->nn_nodes, c->nn_far, c->nn_hits, c->nn_fetched, c->nn_dbg[0], c->nn_dbg[1], c->nn_dbg[2], c->nn_dbg[3]};
+  const int n = std::min(cap, 10);
   for (int i = 0; i < n; ++i) out[i] = v[i];
   return n;
 } MVICP_GUARD_ABI
@@ -1010,6 +1014,7 @@ int mvicp_profile_reset(mvicp_ctx* c) try {
   prof_collect(c);
   for (auto& kv : c->prof) { kv.second.ms = 0; kv.second.launches = 0; kv.second.bytes = 0; }
   c->nn_candidates = c->nn_nodes = c->nn_far = c->nn_queries = c->nn_hits = c->nn_fetched = 0;
+  for (int k = 0; k < 4; ++k) c->nn_dbg[k] = 0;
   return MVICP_OK;
 } MVICP_GUARD_ABI
 int mvicp_profile_get(mvicp_ctx* c, const char* kernel, double* total_ms, long long* launches, double* alg_bytes) try {

@@ -63,6 +63,9 @@ struct GridDev {
   int wide_levels = 0;
   int wide_cnt[6] = {0, 0, 0, 0, 0, 0};
   long long wide_off[6] = {0, 0, 0, 0, 0, 0};
+  // matrix-pipe operands (nn_mfma.hip, build_mfma): per 32-point tile 64 x 16 B of ready-made v_mfma_f32_32x32x16_f16 A fragments, per block of
+  // 64 tiles the origin / scale / error terms they refer to
+  void* mf_ops = nullptr; void* mf_blk = nullptr;
   double struct_bytes = 0.0;
   // dense brick map over the cells (nn_grid.hip, nn_cell_kernel): brick = 4x4x4 cells -> {occupancy mask, row of the cell table};
   // cell table row = 64 x {start, count} of the cell runs in the sorted array.  Null when the grid is too large for a dense map.
@@ -210,6 +213,9 @@ struct mvicp_ctx {
                                    // temporal-cache check as its prologue (missed lanes are searched wave-cooperatively) instead of the grid kernel
   double tile_mu = 0.02;           // BND guard band as a fraction of the target's hash-cell edge (same role as prune_rho in the grid kernel); round 3 sweep on cfg4
                                    // (hand-over round + the two cache-aware rounds after it): 0.02 -> 2.06 ms, 0.05 -> 2.11, 0.1 -> 2.23, 0.2 -> 2.45
+  bool tile_mfma = true;           // tile method: the screen of an opened tile runs on the matrix pipe (nn_mfma.hip) instead of the fp32 VALU screen (nn_tile.hip)
+  double mfma_kacc = 34.0;         // nn_mfma.hip: allowance for the fp32 accumulation inside one matrix instruction, in units of 2^-24 x sum |terms| (see tau_pieces)
+  int mfma_trig = 2;               // nn_mfma.hip: a lane with more than this many screen hits in a tile triggers the nearest-first second screen
   int tile_waves = 0;              // nn_tile_kernel variant: waves per SIMD it is compiled for (0 = the measured best for the depth)
   double auto_prev_dist = 0.0; int auto_last_method = -1; double auto_settle = 0.5;   // MVICP_NN_AUTO policy state (api.cpp)
   double last_rms = -1.0;          // RMS residual at the end of the last mvicp_optimize since the last search (< 0: none): predicts the next NN distances
@@ -221,6 +227,7 @@ struct mvicp_ctx {
   int grid_curve = 2;              // order of the sorted clouds: 0 Morton (Z-order) of the cells, 1 Hilbert of the cells, 2 balanced k-d order
   double grid_target = 5.0;        // points per occupied cell the cell-edge heuristic aims at (4-6 measure the same within 2 %)
   double nn_candidates = 0, nn_nodes = 0, nn_far = 0, nn_queries = 0, nn_hits = 0, nn_fetched = 0;
+  double nn_dbg[4] = {0, 0, 0, 0};   // nn_mfma_kernel census: second-screen passes, confirmation rounds, blocks scanned (all per wave), fp64 confirmations (per lane)
 
   // profiling
   bool profile = false; int profile_level = 0;   // 1: every scope, 2: only "nn" and "linearize"
@@ -234,6 +241,9 @@ int launch_nn_brute_edges(mvicp_ctx* c);                                        
 int launch_nn_brute_queries(mvicp_ctx* c, const FrameDev& f, const double* d_q, int n, int* d_idx, double* d_d2);
 int launch_nn_grid_edges(mvicp_ctx* c, double d2_bound);                              // nn_grid.hip
 int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound, bool with_bounds, bool with_cache, bool with_list);
+int launch_nn_mfma_edges(mvicp_ctx* c, double d2_bound, bool with_bounds, bool with_cache, bool with_list);   // nn_mfma.hip
+int build_mfma(FrameDev& f, const double* sorted_pts);                                 // nn_mfma.hip (host, called by build_grid)
+int warm_nn_mfma(mvicp_ctx* c);
 int warm_nn_tile(mvicp_ctx* c); int warm_nn_grid(mvicp_ctx* c);                                    // code-object load at set-up time (mvicp_set_graph)                              // nn_tile.hip
 int build_wide(FrameDev& f, const double* sorted_pts);                                 // nn_tile.hip (host, called by build_grid)
 int launch_nn_grid_queries(mvicp_ctx* c, const FrameDev& f, const double* d_q, int n, int* d_idx, double* d_d2);

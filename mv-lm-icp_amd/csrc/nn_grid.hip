@@ -1079,6 +1079,7 @@ int build_grid(mvicp_ctx* c, FrameDev& f, const double* xyz) {
   MV_HIP(hipMemcpy(G.table, table.data(), sizeof(HashEntry) * (size_t)tsize, hipMemcpyHostToDevice));
   G.struct_bytes = sizeof(HashEntry) * (double)tsize + sizeof(float) * 8.0 * nodes8;
   MV_CHECK(build_wide(f, spts.data()));
+  MV_CHECK(build_mfma(f, spts.data()));
   f.has_grid = true;
   return MVICP_OK;
 }
@@ -1092,6 +1093,8 @@ void free_grid(GridDev& g) {
   if (g.inv) (void)hipFree(g.inv);
   if (g.table) (void)hipFree(g.table);
   if (g.wide) (void)hipFree(g.wide);
+  if (g.mf_ops) (void)hipFree(g.mf_ops);
+  if (g.mf_blk) (void)hipFree(g.mf_blk);
   if (g.oct) (void)hipFree(g.oct);
   if (g.bricks) (void)hipFree(g.bricks);
   if (g.celltab) (void)hipFree(g.celltab);

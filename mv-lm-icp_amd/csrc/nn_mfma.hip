@@ -1,0 +1,632 @@
+// K2m — the wave-cooperative exact 1-NN of nn_tile.hip with the screen of an opened tile on the MATRIX pipe.
+//
+// Same contract as K1 / K2 / K2t (bit-exact indices and squared distances of the reference's Frame::getClosestPoint,
+// src/internal/frame.cpp:187-206, metric include/frame.h:70-76, query transform frame.cpp:117-118,131,136; lowest original index wins
+// exact ties), same job table, same outputs (neighbour, d2, BND lower bounds, in-place list maintenance: nn_tile_common.h, nn_list.h).
+//
+// nn_tile.hip is VALU-issue bound and a third of its instructions are the fp32 screen of the 32 points of every opened tile by all 64
+// lanes, of which ~15 need the tile (profiles/r03_tile_ab.txt runs D, F, G).  Here that screen is ONE v_mfma_f32_32x32x16_f16 per 32
+// queries: for a tile's points i and the wave's queries j, in coordinates local to the tile's BLOCK (64 tiles = one level-0 node of
+// the 64-wide hierarchy; origin c, power-of-two scale so that the block's points lie in [-128, 128]^3),
+//     V_ij = |b_i|^2 - 2 a_j . b_i - T_j          (norm expansion of |a_j - b_i|^2 minus the query's own threshold)
+// with every factor split into f16 pieces (b = bh + bl, a = ah + al, |b|^2 = n1 + n2 + n3, -T = 4096 t1 + t2 + t3): 15 of the 16 k-slots
+//     A (points, PRECOMPUTED per cloud, 16 B per lane per tile):  [-2bh.xyz | -2bl.xyz | n1 n2 || -2bh.xyz | n3 | 4096 1 1 | 0]
+//     B (queries, rebuilt per block):                             [  ah.xyz |   ah.xyz |  1  1 ||   al.xyz |  1 |  t1 t2 t3 | 0]
+// A candidate must be re-evaluated in the reference's fp64 arithmetic iff V_ij < 0: the sign bits of the 32 accumulators of a lane
+// (v_alignbit chain) exchanged between the half-waves (v_permlane32_swap) are the lane's 32-bit hit mask of the tile.  T_j carries a
+// rigorous allowance for everything the pieces drop (al . bl, the split residuals, the fp32 accumulation inside the instruction: kAcc
+// ulps of the sum of the |terms|, see tau_pieces), so a point is skipped only when it is provably farther than the lane's running best;
+// the slot of the running best itself (the seed: last round's neighbour) is masked, so in a converged round hardly any lane leaves the
+// screen.  No LDS staging, no per-lane box tests below the block level, confirmations read the 32-B sorted records straight from
+// memory.  Levels >= 1 of the hierarchy are walked exactly as in nn_tile.hip.
+#include "nn_tile_common.h"
+
+namespace mvicp {
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+static_assert(LEAF == 32 && FAN == 64, "the fragment maps below are those of 32-point tiles in blocks of 64");
+constexpr float kQueryRange = 4096.f;  // a query farther than this from the block's origin (scaled, per axis) confirms the block's opened tiles exhaustively
+// fp32 accumulation inside the instruction: 16 products (exact: 11 x 11 bits) + C summed by at most 17 additions, each at worst a truncating
+// fp32 addition (relative 2^-23 of a partial sum that never exceeds the sum of the |terms|): 34 x 2^-24 x sum |terms|.  Measured on MI355X
+// (tools/mfma_probe.hip, 4e5 sums of screen-like operands): worst 3.45 x 2^-24 x sum |terms|.
+// The factor is a job parameter (TileJob::kacc, default 34).
+
+struct LaneM {         // per-lane query state
+  double qx, qy, qz, best;
+  float rbest;           // fp32 upper bound of sqrt(best) (metres); box tests use box_thr(rbest, slack + mu) >= (sqrt(best) + slack + mu)^2
+  int bi;                // original index of the running best (0x7fffffff: none)
+  int bpos;              // its sorted position (-1: none)
+  bool active;
+  double second;         // BND builds only: smallest exact d2 among the fp64-evaluated targets other than the running best
+  // block-local (valid while the wave scans one block)
+  float a2, amax, dab;   // |a~|^2, max |alpha coordinate|, delta_a + delta_b (all in the block's scaled units)
+  bool inrange;
+};
+struct GroupM {        // wave-uniform patch description
+  float lo[3], hi[3], c[3];
+  float kacc; int trig;   // job tunables
+  float slack, mu, m;  // fp32 box-test guard band (metres), BND extra guard band, largest coordinate magnitude of cloud and patch
+};
+
+__device__ __forceinline__ float box_lb32(const LaneM& L, float b0, float b1, float b2, float b3, float b4, float b5) {
+  const float qxf = (float)L.qx, qyf = (float)L.qy, qzf = (float)L.qz;   // (converted here: three registers fewer across the traversal)
+  const float g0 = fmaxf(fmaxf(b0 - qxf, qxf - b3), 0.f);
+  const float g1 = fmaxf(fmaxf(b1 - qyf, qyf - b4), 0.f);
+  const float g2 = fmaxf(fmaxf(b2 - qzf, qzf - b5), 0.f);
+  return __builtin_fmaf(g2, g2, __builtin_fmaf(g1, g1, g0 * g0));
+}
+
+__device__ __forceinline__ unsigned int pack2(_Float16 lo, _Float16 hi) { const h2 v = {lo, hi}; return __builtin_bit_cast(unsigned int, v); }
+
+// fp32 upper bound of sqrt(d) (v_sqrt_f32 is accurate to 1 ulp)
+__device__ __forceinline__ float sqrt_up(double d) { return __builtin_amdgcn_sqrtf(__double2float_ru(d)) * 1.000001f; }
+__device__ __forceinline__ float box_thr(float rbest, float slack) { const float rb = rbest + slack; return rb * rb * 1.000002f; }
+
+// The query's threshold pieces (t1, t2, t3), -T = 4096 t1 + t2 + t3 (rounded DOWN: a lower -T only admits more candidates).
+// In the block's scaled units: a candidate with true distance^2 D <= best (BND: sqrt(D) <= sqrt(best) + mu) has
+//     |a~ - b~| <= sqrt(D) + delta_a + delta_b,  so  |a~ - b~|^2 <= U := (rb + dab)^2,  rb >= sqrt(best) (+ mu), and
+//     V_exact = |a~ - b~|^2 - |a~|^2 + (n - |b~|^2) + 2 al . bl - T  <=  U - a2 + en + ell - T;     V_computed <= V_exact + e_acc.
+// With T = U - a2 + E and E = 2 (en + ell + e_acc + fp32 slop of this function) + tiny, V_computed <= -E / 2 < 0: the sign bit is set.
+//     ell   <= 2 * 3 * (2^-11 * 128) * (2^-11 * amax) * 1.001
+//     e_acc <= kAcc * 2^-24 * sum |terms|,  sum |terms| <= 49160 (n) + 770 amax (2 b . a, all three piece products) + 1.002 (U + a2) (the T pieces)
+//     slop  <= 2^-21 (U + a2): a2 and T = U - a2 + E are evaluated in fp32
+__device__ __forceinline__ void tau_pieces(const LaneM& L, float scale_f, float mu_s, float en, float kAcc, _Float16& t1, _Float16& t2, _Float16& t3) {
+  if (!L.active) { t1 = (_Float16)60000.f; t2 = (_Float16)0.f; t3 = (_Float16)0.f; return; }    // V >= -3.2e6 + 2.4e8 > 0: never a hit
+  if (!L.inrange) { t1 = (_Float16)-60000.f; t2 = (_Float16)0.f; t3 = (_Float16)0.f; return; }  // operands zeroed: V = n - 2.4e8 < 0, every point is confirmed
+  const float rb = (L.rbest * scale_f + mu_s + L.dab) * 1.000001f;
+  const float U = rb * rb * 1.000001f;
+  const float s = U + L.a2;
+  const float E = (2.f * kAcc * 49160.f / 16777216.f + 1e-5f) + 2.f * en + L.amax * (3.7e-4f + 2.f * kAcc * 770.f / 16777216.f) +
+                  s * (2.f * kAcc * 1.002f / 16777216.f + 1.0e-6f);
+  float tau = -((U - L.a2) + E);
+  tau -= fabsf(tau) * 2.4e-7f;                                  // (the two fp32 roundings above, downwards)
+  t1 = (_Float16)(tau * (1.f / 4096.f));
+  const float r1 = __builtin_fmaf(-4096.f, (float)t1, tau);     // exact
+  t2 = (_Float16)r1;
+  const float r2 = r1 - (float)t2;                               // exact
+  t3 = (_Float16)(r2 - fabsf(r2) * 1.0e-3f - 6.0e-8f);          // rounded down (f16: 2^-11 relative, 2^-24 absolute)
+}
+
+struct Census { unsigned int cand, box, rescreen, rounds, blocks, conf; };   // per wave (conf: per lane); CEN builds (profiling with nn_census) only
+#define MV_CEN(stmt) do { if (CEN) { stmt; } } while (0)
+
+// The wave's B fragments for one block (bx: queries 0-31, by: queries 32-63) and what is needed to refresh their T pieces.
+struct BlockM { float scale_f, mu_s, en, kacc; int trig; unsigned int xo2; unsigned int bx[4], by[4]; };
+
+__device__ __forceinline__ void retau(const LaneM& L, BlockM& K) {   // new thresholds: only the T pieces of the B fragments change
+  _Float16 t1, t2, t3;
+  tau_pieces(L, K.scale_f, K.mu_s, K.en, K.kacc, t1, t2, t3);
+  const auto s2 = __builtin_amdgcn_permlane32_swap(K.xo2, pack2(t1, t2), false, false); K.bx[2] = s2[0]; K.by[2] = s2[1];
+  const auto s3 = __builtin_amdgcn_permlane32_swap(pack2((_Float16)1.f, (_Float16)1.f), pack2(t3, (_Float16)0.f), false, false); K.bx[3] = s3[0]; K.by[3] = s3[1];
+}
+
+// bit of a tile row in a lane's hit mask: accumulator r = (row & 3) | (row >> 3) << 2 of half-wave (row >> 2) & 1
+__device__ __forceinline__ unsigned int row_bit(int row) { return 1u << (((row & 3) | ((row >> 3) << 2)) + 16 * ((row >> 2) & 1)); }
+
+// V = A . B for the wave's 64 queries against the tile's 32 points -> the lane's 32-bit mask of the points with V < 0 (bit p: accumulator
+// p & 15 of half-wave p >> 4 = row (r & 3) + 8 (r >> 2) + 4 (p >> 4)), the running best's own slot masked.  NEAREST: instead, the (at most
+// two) bits of the most negative V of each row half — the candidates nearest to the query.
+template <bool NEAREST>
+__device__ __forceinline__ unsigned int half_screen(const h8 a, const unsigned int (&bq)[4]) {
+  const uint4 q4 = make_uint4(bq[0], bq[1], bq[2], bq[3]);
+  f16v z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r] = 0.f;
+  const f16v acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(h8, q4), z, 0, 0, 0);
+  if (!NEAREST) {
+    unsigned int m = 0u;
+#pragma unroll
+    for (int r = 15; r >= 0; --r) m = __builtin_amdgcn_alignbit(m, __float_as_uint(acc[r]), 31);
+    return m;
+  }
+  // the accumulator index rides in the low four mantissa bits (a perturbation of 2^-19: WHICH candidates are confirmed first does not
+  // affect the result, only how fast the thresholds tighten)
+  float e[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) e[r] = __uint_as_float((__float_as_uint(acc[r]) & 0xfffffff0u) | (unsigned)r);
+#pragma unroll
+  for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+    for (int r = 0; r < w; ++r) e[r] = fminf(e[r], e[r + w]);
+  return __float_as_uint(e[0]);
+}
+template <bool NEAREST>
+__device__ __forceinline__ unsigned int screen(const h8 a, const BlockM& K, const LaneM& L, int tile) {
+  // one instruction after the other, so that the 16 accumulators of the first are dead before the second's are born
+  const unsigned int m1 = half_screen<NEAREST>(a, K.bx);
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned int m2 = half_screen<NEAREST>(a, K.by);
+  // lanes l and l + 32 hold query (l & 31)'s rows of the first instruction and query 32 + (l & 31)'s of the second: one half exchange
+  // hands every lane both row halves of ITS query
+  const auto sw = __builtin_amdgcn_permlane32_swap(m1, m2, false, false);
+  unsigned int m;
+  if (!NEAREST) m = sw[0] | (sw[1] << 16);
+  else { const unsigned int c0 = sw[0], c1 = sw[1]; m = ((c0 >> 31) << (c0 & 15u)) | ((c1 >> 31) << (16u + (c1 & 15u))); }
+  if ((L.bpos >> 5) == tile) m &= ~row_bit(L.bpos & 31);   // the running best itself (the seed when its tile comes by) is not a candidate
+  return m;
+}
+
+// fp64 re-evaluation (the reference's arithmetic) of the candidates in the lane's mask; true when the lane's best changed
+template <bool BND, bool CEN>
+__device__ __forceinline__ bool confirm(const TileView& g, int tile, LaneM& L, unsigned int m, Census& C) {
+  bool changed = false;
+  while (__ballot(m != 0u) != 0ull) {
+    MV_CEN(++C.rounds);
+    if (m != 0u) {
+      MV_CEN(++C.conf);
+      const int p = __ffs((int)m) - 1;
+      m &= m - 1u;
+      const int r = p & 15;
+      const int k = tile * LEAF + (r & 3) + 8 * (r >> 2) + 4 * (p >> 4);
+      if (k < g.n) {
+        const double2* pr = reinterpret_cast<const double2*>(g.srec + k);
+        const double2 u = pr[0], v = pr[1];
+        const double d0 = __dsub_rn(L.qx, u.x), d1 = __dsub_rn(L.qy, u.y), d2 = __dsub_rn(L.qz, v.x);
+        const double d = __dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2));
+        const int oi = (int)__double_as_longlong(v.y);
+        if (BND) {
+          if (d < L.best || (d == L.best && oi < L.bi)) {
+            L.second = fmin(L.second, L.best);   // the old best (or the cutoff bound: only lowers the bound) is now "another target"
+            L.best = d; L.bi = oi; L.bpos = k; changed = true;
+          } else if (oi != L.bi) {
+            L.second = fmin(L.second, d);
+          }
+        } else if (d <= L.best) {
+          if (d < L.best || oi < L.bi) { L.best = d; L.bi = oi; L.bpos = k; changed = true; }
+        }
+      }
+    }
+  }
+  return changed;
+}
+
+// Screen + confirm one tile for the whole wave; true when some lane's best (hence the wave's largest threshold) changed.
+// A lane with few candidates confirms them all.  When some lane has many (loose seed, or none: the first rounds of a registration) the
+// CROWDED lanes confirm only their nearest one or two first and the tile is screened again with the tightened thresholds — instead of
+// re-evaluating every point inside a loose threshold in fp64.
+template <bool BND, bool CEN>
+__device__ __forceinline__ bool tile_scan(const TileView& g, int tile, const h8 a, LaneM& L, BlockM& K, float sm, Census& C) {
+  unsigned int done = 0u;
+  bool any = false;
+  for (;;) {
+    unsigned int m = screen<false>(a, K, L, tile) & ~done;
+    if (__ballot(m != 0u) == 0ull) break;
+    const bool crowded = __popc(m) > K.trig;
+    const bool again = __ballot(crowded) != 0ull;
+    if (again) {
+      MV_CEN(++C.rescreen);
+      const unsigned int mn = screen<true>(a, K, L, tile);
+      if (crowded) { const unsigned int mm = m & mn; m = mm != 0u ? mm : (m & (0u - m)); }   // (always at least one: every pass retires a candidate of every lane that has one)
+    }
+    done |= m;
+    const bool ch = confirm<BND, CEN>(g, tile, L, m, C);
+    if (ch) L.rbest = fminf(L.rbest, sqrt_up(L.best));
+    if (__ballot(ch) != 0ull) { any = true; retau(L, K); }
+    if (!again) break;   // every candidate of every lane was confirmed; what the screen rejected stays rejected under tighter thresholds
+  }
+  return any;
+}
+
+// One block (level-0 node): its `nchild` tiles [first, first + nchild), one per lane.
+template <bool BND, bool CEN>
+__device__ void scan_block(const TileView& g, int first, int nchild, LaneM& L, const GroupM& G, Census& C, float kacc, int trig) {
+  const int lane = threadIdx.x & 63;
+  const float inf = __int_as_float(0x7f800000);
+  float ddf = inf, key = inf;
+  if (lane < nchild) {
+    const float* base = g.wide + g.off[0] + first + lane;
+    const long long st = g.cnt[0];
+    const float b0 = base[0], b1 = base[st], b2 = base[2 * st], b3 = base[3 * st], b4 = base[4 * st], b5 = base[5 * st];
+    const float e0 = fmaxf(fmaxf(b0 - G.hi[0], G.lo[0] - b3), 0.f);
+    const float e1 = fmaxf(fmaxf(b1 - G.hi[1], G.lo[1] - b4), 0.f);
+    const float e2 = fmaxf(fmaxf(b2 - G.hi[2], G.lo[2] - b5), 0.f);
+    ddf = (e0 * e0 + e1 * e1 + e2 * e2) * 0.999999f;   // lower bound of the box-to-patch distance^2 (see nn_tile.hip visit)
+    const float k0 = fmaxf(fmaxf(b0 - G.c[0], G.c[0] - b3), 0.f);
+    const float k1 = fmaxf(fmaxf(b1 - G.c[1], G.c[1] - b4), 0.f);
+    const float k2 = fmaxf(fmaxf(b2 - G.c[2], G.c[2] - b5), 0.f);
+    key = k0 * k0 + k1 * k1 + k2 * k2;                 // visiting order only
+  }
+  MV_CEN(C.box += (unsigned)nchild);
+  const float sm = G.slack + G.mu;
+  float gmax = box_thr(wave_max_f(L.active ? L.rbest : 0.f), sm);
+  bool pend = ddf <= gmax;
+  if (__ballot(pend) == 0ull) return;
+  MV_CEN(++C.blocks);
+  // first tile: picked (nearest to the patch centre) and its fragment requested before the query fragments are built
+  int c_cur;
+  {
+    const float kmin = wave_min_f(pend ? key : inf);
+    c_cur = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(pend && key == kmin)) - 1);
+    if (lane == c_cur) pend = false;
+  }
+  uint4 a_cur = g.mf_ops[(size_t)(first + c_cur) * 64 + lane];
+
+  // the queries in the block's frame: alpha = (q - c) * scale, split into f16 pieces
+  const MfBlock* Bp = g.mf_blk + (first >> 6);
+  const double cx = Bp->cx, cy = Bp->cy, cz = Bp->cz, scale = Bp->scale;
+  BlockM K;
+  K.scale_f = (float)scale; K.en = Bp->en; K.kacc = kacc; K.trig = trig;
+  K.mu_s = G.mu * K.scale_f * 1.000001f;
+  {
+    const float ax = (float)((L.qx - cx) * scale), ay = (float)((L.qy - cy) * scale), az = (float)((L.qz - cz) * scale);
+    L.amax = fmaxf(fmaxf(fabsf(ax), fabsf(ay)), fabsf(az));
+    L.inrange = L.amax <= kQueryRange;   // (NaN: false)
+    _Float16 hx = (_Float16)0.f, hy = hx, hz = hx, lx = hx, ly = hx, lz = hx;
+    L.a2 = 0.f;
+    if (L.inrange) {
+      hx = (_Float16)ax; hy = (_Float16)ay; hz = (_Float16)az;
+      lx = (_Float16)(ax - (float)hx); ly = (_Float16)(ay - (float)hy); lz = (_Float16)(az - (float)hz);
+      const float tx = (float)hx + (float)lx, ty = (float)hy + (float)ly, tz = (float)hz + (float)lz;
+      L.a2 = __builtin_fmaf(tz, tz, __builtin_fmaf(ty, ty, tx * tx));
+    }
+    // delta_a: fp32 conversion of alpha (2^-24) + split residual (2^-22, f16 subnormal floor 2^-25 per axis) + the fp64 rounding of
+    // (q - c) * scale (2^-52 of the operands' magnitude); delta_b (host, exact) in the block record
+    L.dab = 1.7320508f * (L.amax * 4.8e-7f + 1.2e-7f) + G.m * K.scale_f * 1.8e-15f + Bp->db;
+    _Float16 t1, t2, t3;
+    tau_pieces(L, K.scale_f, K.mu_s, K.en, K.kacc, t1, t2, t3);
+    const _Float16 one = (_Float16)1.f, zero = (_Float16)0.f;
+    const unsigned int X0 = pack2(hx, hy), X1 = pack2(hz, hx), X2 = pack2(hy, hz), X3 = pack2(one, one);
+    const unsigned int Y0 = pack2(lx, ly), Y1 = pack2(lz, one), Y2 = pack2(t1, t2), Y3 = pack2(t3, zero);
+    K.xo2 = X2;
+    const auto s0 = __builtin_amdgcn_permlane32_swap(X0, Y0, false, false); K.bx[0] = s0[0]; K.by[0] = s0[1];
+    const auto s1 = __builtin_amdgcn_permlane32_swap(X1, Y1, false, false); K.bx[1] = s1[0]; K.by[1] = s1[1];
+    const auto s2 = __builtin_amdgcn_permlane32_swap(X2, Y2, false, false); K.bx[2] = s2[0]; K.by[2] = s2[1];
+    const auto s3 = __builtin_amdgcn_permlane32_swap(X3, Y3, false, false); K.bx[3] = s3[0]; K.by[3] = s3[1];
+  }
+  while (true) {
+    // the tile after this one (nearest pending under the current thresholds): its fragment is requested now and arrives while this one
+    // is screened; should the thresholds shrink past its box meanwhile it is simply dropped
+    int c_nxt = -1;
+    float ddf_nxt = inf;
+    uint4 a_nxt = make_uint4(0u, 0u, 0u, 0u);
+    if (__ballot(pend) != 0ull) {
+      const float kmin = wave_min_f(pend ? key : inf);
+      c_nxt = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(pend && key == kmin)) - 1);
+      if (lane == c_nxt) pend = false;
+      ddf_nxt = bcast(ddf, c_nxt);
+      a_nxt = g.mf_ops[(size_t)(first + c_nxt) * 64 + lane];
+    }
+    const int tile = first + c_cur;
+    const bool any = tile_scan<BND, CEN>(g, tile, __builtin_bit_cast(h8, a_cur), L, K, sm, C);
+    MV_CEN(C.cand += (unsigned)min(LEAF, g.n - tile * LEAF));
+    if (any) {
+      gmax = box_thr(wave_max_f(L.active ? L.rbest : 0.f), sm);
+      pend = pend && ddf <= gmax;
+      while (c_nxt >= 0 && !(ddf_nxt <= gmax)) {   // the requested tile fell outside: next pending one (no prefetch for it)
+        c_nxt = -1;
+        if (__ballot(pend) != 0ull) {
+          const float kmin = wave_min_f(pend ? key : inf);
+          c_nxt = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(pend && key == kmin)) - 1);
+          if (lane == c_nxt) pend = false;
+          ddf_nxt = bcast(ddf, c_nxt);
+          a_nxt = g.mf_ops[(size_t)(first + c_nxt) * 64 + lane];
+        }
+      }
+    }
+    if (c_nxt < 0) break;
+    c_cur = c_nxt; a_cur = a_nxt;
+  }
+}
+
+// Levels >= 1: as nn_tile.hip's visit (coarse cull against the patch box, per-lane box test, children nearest-first).
+template <int LEVEL, bool BND, bool CEN>
+__device__ void visit(const TileView& g, int first, int nchild, LaneM& L, const GroupM& G, float2* __restrict__ sbox, Census& C) {
+  if constexpr (LEVEL == 0) { scan_block<BND, CEN>(g, first, nchild, L, G, C, G.kacc, G.trig); return; } else {
+  const int lane = threadIdx.x & 63;
+  const float inf = __int_as_float(0x7f800000);
+  float b0 = inf, b1 = inf, b2 = inf, b3 = -inf, b4 = -inf, b5 = -inf;
+  if (lane < nchild) {
+    const float* base = g.wide + g.off[LEVEL] + first + lane;
+    const long long st = g.cnt[LEVEL];
+    b0 = base[0]; b1 = base[st]; b2 = base[2 * st]; b3 = base[3 * st]; b4 = base[4 * st]; b5 = base[5 * st];
+  }
+  float ddf, key;
+  {
+    const float e0 = fmaxf(fmaxf(b0 - G.hi[0], G.lo[0] - b3), 0.f);
+    const float e1 = fmaxf(fmaxf(b1 - G.hi[1], G.lo[1] - b4), 0.f);
+    const float e2 = fmaxf(fmaxf(b2 - G.hi[2], G.lo[2] - b5), 0.f);
+    ddf = (e0 * e0 + e1 * e1 + e2 * e2) * 0.999999f;
+    const float k0 = fmaxf(fmaxf(b0 - G.c[0], G.c[0] - b3), 0.f);
+    const float k1 = fmaxf(fmaxf(b1 - G.c[1], G.c[1] - b4), 0.f);
+    const float k2 = fmaxf(fmaxf(b2 - G.c[2], G.c[2] - b5), 0.f);
+    key = k0 * k0 + k1 * k1 + k2 * k2;
+  }
+  float2* mybox = sbox + (LEVEL > 0 ? (LEVEL - 1) * 3 * FAN : 0);   // levels 1 and 2 park their boxes in wave-private LDS
+  constexpr bool IN_LDS = LEVEL == 1 || LEVEL == 2;
+  if (IN_LDS) {
+    __builtin_amdgcn_wave_barrier();
+    mybox[lane] = make_float2(b0, b3);
+    mybox[FAN + lane] = make_float2(b1, b4);
+    mybox[2 * FAN + lane] = make_float2(b2, b5);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  MV_CEN(C.box += (unsigned)nchild);
+  bool pend = lane < nchild;
+  const float sm = G.slack + G.mu;
+  float gmax = box_thr(wave_max_f(L.active ? L.rbest : 0.f), sm);
+  while (true) {
+    pend = pend && ddf <= gmax;
+    if (__ballot(pend) == 0ull) break;
+    const float kmin = wave_min_f(pend ? key : inf);
+    const unsigned long long pick = __ballot(pend && key == kmin);
+    const int c = __builtin_amdgcn_readfirstlane(__ffsll((long long)pick) - 1);
+    if (lane == c) pend = false;
+    float c0, c1, c2, c3, c4, c5;
+    if (IN_LDS) {
+      const float2 u = mybox[c], v = mybox[FAN + c], w = mybox[2 * FAN + c];
+      c0 = u.x; c3 = u.y; c1 = v.x; c4 = v.y; c2 = w.x; c5 = w.y;
+    } else {
+      c0 = bcast(b0, c); c1 = bcast(b1, c); c2 = bcast(b2, c); c3 = bcast(b3, c); c4 = bcast(b4, c); c5 = bcast(b5, c);
+    }
+    const float lb = box_lb32(L, c0, c1, c2, c3, c4, c5);
+    if (__ballot(L.active && lb <= box_thr(L.rbest, sm)) == 0ull) continue;
+    const int cf = (first + c) * FAN;
+    visit<(LEVEL > 0 ? LEVEL - 1 : 0), BND, CEN>(g, cf, min(FAN, g.cnt[LEVEL > 0 ? LEVEL - 1 : 0] - cf), L, G, sbox, C);
+    gmax = box_thr(wave_max_f(L.active ? L.rbest : 0.f), sm);
+  }
+  }
+}
+
+template <int WPE, int TOP, bool BND, bool CEN>
+__global__ __launch_bounds__(NT, WPE) void nn_mfma_kernel(const TileJob* __restrict__ jobs, double bound, unsigned long long* __restrict__ stats) {
+  __shared__ float2 s_box[NT / 64][2 * 3 * FAN];   // levels 1 and 2: 64 child boxes x 24 B each, per wave
+  __shared__ double sxf[kEdgeXf];
+  const TileJob& job = jobs[blockIdx.y];
+  if (blockIdx.x * NT >= job.n) return;
+  const bool has_xf = job.xf != nullptr;
+  if (has_xf && threadIdx.x < kEdgeXf) sxf[threadIdx.x] = job.xf[threadIdx.x];
+  __syncthreads();
+  const int wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * NT + threadIdx.x;
+  if ((i & ~63) >= job.n) return;  // whole wave beyond the end
+  const TileView& g = job.dst;
+
+  LaneM L;
+  L.active = i < job.n;
+  L.best = bound; L.bi = 0x7fffffff; L.bpos = -1;
+  L.second = 1.7976931348623157e308;
+  L.qx = L.qy = L.qz = 0.0;
+  L.a2 = 0.f; L.amax = 0.f; L.dab = 0.f; L.inrange = false;
+  double p0 = 0.0, p1 = 0.0, p2 = 0.0;
+  if (L.active) {
+    p0 = job.q[3 * (size_t)i]; p1 = job.q[3 * (size_t)i + 1]; p2 = job.q[3 * (size_t)i + 2];
+    if (has_xf) xf_point(sxf, p0, p1, p2, L.qx, L.qy, L.qz);
+    else { L.qx = p0; L.qy = p1; L.qz = p2; }
+  }
+  // Seed: last round's neighbour is an ordinary candidate; starting from its distance lets the traversal discard almost every tile
+  // that does not hold a true neighbour of some lane.  Its slot is masked when its tile is screened (tile_scan).
+  int seed_pi = -1;
+  double seed_d = 0.0;
+  if (job.seed && L.active) {
+    const int pi = job.out_idx[i];
+    if (pi >= 0 && pi < g.n) {
+      const double2* pr = reinterpret_cast<const double2*>(g.srec + pi);
+      const double2 u = pr[0], v = pr[1];
+      const double d0 = __dsub_rn(L.qx, u.x), d1 = __dsub_rn(L.qy, u.y), d2 = __dsub_rn(L.qz, v.x);
+      const double d = __dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2));
+      seed_pi = pi; seed_d = d;
+      if (d <= L.best) { L.best = d; L.bi = (int)__double_as_longlong(v.y); L.bpos = pi; }
+    }
+  }
+  // Temporal cache (BND builds in cache-aware rounds): see nn_tile.hip — a lane whose neighbour provably did not change is finished here.
+  unsigned int n_hit = 0;
+  if (BND && job.cache && has_xf && seed_pi >= 0) {
+    const double cslack = sxf[24];
+    if (cslack >= 0.0) {
+      const double e0 = sxf[25] * p0 + sxf[28] * p1 + sxf[31] * p2 + sxf[34];
+      const double e1 = sxf[26] * p0 + sxf[29] * p1 + sxf[32] * p2 + sxf[35];
+      const double e2 = sxf[27] * p0 + sxf[30] * p1 + sxf[33] * p2 + sxf[36];
+      const double eps = sqrt(e0 * e0 + e1 * e1 + e2 * e2) * (1.0 + 1e-9) + cslack;
+      const double nlb = (double)job.out_lb[i] - eps;
+      if (sqrt(seed_d) * (1.0 + 1e-12) < nlb) {
+        if (eps != 0.0) {   // (eps == 0: bit-identical query transform, everything stored is already exact)
+          job.out_d2[i] = seed_d;
+          job.out_lb[i] = __double2float_rd(nlb);
+          if (job.list.dirty) update_list_entry(job.list, i, seed_pi, seed_d, bound, true);
+        }
+        L.active = false;
+        n_hit = 1;
+      }
+    }
+  }
+  if (BND && job.cache && __ballot(L.active) == 0ull) {
+    if (stats) {   // census (profiling only): all 64 lanes answered by the cache
+      const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + wave;
+      const unsigned long long hits = __popcll(__ballot(n_hit != 0u));
+      if ((threadIdx.x & 63) == 0) stats[8 * slot + 3] = hits;
+    }
+    return;
+  }
+  GroupM G;   // wave-uniform: lives in SGPRs
+  {
+    const float qxf = (float)L.qx, qyf = (float)L.qy, qzf = (float)L.qz;
+    // patch box in fp32, rounded outward (nn_tile.hip)
+    const float inf = __int_as_float(0x7f800000);
+    float lo[3] = {wave_min_any(L.active ? qxf : inf), wave_min_any(L.active ? qyf : inf), wave_min_any(L.active ? qzf : inf)};
+    float hi[3] = {wave_max_any(L.active ? qxf : -inf), wave_max_any(L.active ? qyf : -inf), wave_max_any(L.active ? qzf : -inf)};
+    float m = (float)g.maxabs * 1.000001f;
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+      lo[ax] -= fabsf(lo[ax]) * 1.2e-7f + 1e-37f; hi[ax] += fabsf(hi[ax]) * 1.2e-7f + 1e-37f;
+      G.lo[ax] = lo[ax]; G.hi[ax] = hi[ax]; G.c[ax] = 0.5f * (lo[ax] + hi[ax]);
+      m = fmaxf(m, fmaxf(fabsf(lo[ax]), fabsf(hi[ax])));
+    }
+    // per axis: |fl32(q) - q| + |fl32(p) - p| + rounding of the fp32 subtraction <= 3 * 2^-24 * m; x sqrt(3) axes, x2 safety
+    G.slack = m * (3.0f * 1.7320508f * 2.0f / 16777216.0f) * 1.00001f + 1e-30f;
+    G.mu = BND ? job.mu : 0.f;
+    G.m = m;
+    G.kacc = job.kacc; G.trig = job.trig;
+  }
+  L.rbest = L.active ? (float)sqrt(L.best) * 1.000001f : 0.f;
+  Census C = {0u, 0u, 0u, 0u, 0u, 0u};
+  const int top = g.levels - 1;
+  float2* sbox = s_box[wave];
+  if (TOP >= 0) visit<(TOP >= 0 ? TOP : 0), BND, CEN>(g, 0, g.cnt[TOP >= 0 ? TOP : 0], L, G, sbox, C);
+  else switch (top) {
+    case 0: visit<0, BND, CEN>(g, 0, g.cnt[0], L, G, sbox, C); break;
+    case 1: visit<1, BND, CEN>(g, 0, g.cnt[1], L, G, sbox, C); break;
+    case 2: visit<2, BND, CEN>(g, 0, g.cnt[2], L, G, sbox, C); break;
+    case 3: visit<3, BND, CEN>(g, 0, g.cnt[3], L, G, sbox, C); break;
+    default: visit<4, BND, CEN>(g, 0, g.cnt[4], L, G, sbox, C); break;
+  }
+  if (L.active) {
+    const int out = i;   // sorted order of the source cloud
+    job.out_idx[out] = L.bpos;   // sorted position of the neighbour (-1: none inside the cutoff)
+    job.out_d2[out] = L.best;
+    // every other target was evaluated exactly (>= second) or rejected by a screen (> sqrt(best) + mu away); 1e-9 relative covers the
+    // fp64 roundings of this line.  No neighbour inside the cutoff: 0 forces a full search next round, like the grid kernel does.
+    if (BND) job.out_lb[out] = L.bpos < 0 ? 0.f : __double2float_rd(fmin(sqrt(L.second), sqrt(L.best) + (double)G.mu) * (1.0 - 1e-9));
+    if (job.list.dirty) update_list_entry(job.list, i, L.bpos, L.best, bound, false);
+  }
+  if (CEN && stats && (threadIdx.x & 63) == 0) {
+    const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + wave;
+    const unsigned long long act = (unsigned long long)min(64, job.n - (i & ~63));
+    stats[8 * slot] = C.cand; stats[8 * slot + 1] = C.box; stats[8 * slot + 2] = (unsigned long long)C.cand * act;
+    stats[8 * slot + 4] = C.rescreen; stats[8 * slot + 5] = C.rounds; stats[8 * slot + 6] = C.blocks;
+  }
+  if (CEN && stats) {   // fp64 confirmations: per lane
+    unsigned int v = C.conf;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) stats[8 * (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + wave) + 7] = v;
+  }
+  if (stats && BND && job.cache) {
+    const unsigned long long hits = __popcll(__ballot(n_hit != 0u));
+    if ((threadIdx.x & 63) == 0) stats[8 * (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + wave) + 3] = hits;
+  }
+}
+
+// ---- host: f16 pieces of the targets (exact arithmetic, so the error terms in the block records are maxima, not estimates) ----
+unsigned short f16_bits(double x) {   // round to nearest even; |x| < 65520
+  if (x == 0.0) return 0;
+  const unsigned short sign = x < 0 ? 0x8000 : 0;
+  const double a = std::fabs(x);
+  int e;
+  (void)std::frexp(a, &e);
+  int E = e - 1;
+  if (E < -14) return sign | (unsigned short)std::nearbyint(std::ldexp(a, 24));   // subnormal: multiples of 2^-24 (1024 -> the smallest normal)
+  double k = std::nearbyint(std::ldexp(a, 10 - E));
+  if (k == 2048.0) { k = 1024.0; ++E; }
+  if (E > 15) return sign | 0x7bff;
+  return sign | (unsigned short)(((E + 15) << 10) | ((int)k - 1024));
+}
+double f16_value(unsigned short h) {
+  const int e = (h >> 10) & 31, f = h & 1023;
+  const double v = e == 0 ? std::ldexp((double)f, -24) : std::ldexp((double)(1024 + f), e - 25);
+  return (h & 0x8000) ? -v : v;
+}
+
+__global__ void mfma_warm_kernel() {}
+
+}  // namespace
+
+int build_mfma(FrameDev& f, const double* spts) {
+  GridDev& G = f.grid;
+  const int n = f.n;
+  const int tiles = (n + LEAF - 1) / LEAF, blocks = (tiles + FAN - 1) / FAN;
+  std::vector<unsigned short> ops((size_t)std::max(tiles, 1) * 64 * 8, 0);
+  std::vector<MfBlock> blk((size_t)std::max(blocks, 1));
+  double cloud_max = 0.0;
+  for (size_t k = 0; k < 3 * (size_t)n; ++k) cloud_max = std::max(cloud_max, std::fabs(spts[k]));
+  for (int b = 0; b < blocks; ++b) {
+    const int p0 = b * FAN * LEAF, p1 = std::min(n, (b + 1) * FAN * LEAF);
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int k = p0; k < p1; ++k)
+      for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], spts[3 * (size_t)k + a]); hi[a] = std::max(hi[a], spts[3 * (size_t)k + a]); }
+    double c[3], ext = 0.0;
+    for (int a = 0; a < 3; ++a) { c[a] = 0.5 * (lo[a] + hi[a]); ext = std::max(ext, std::max(hi[a] - c[a], c[a] - lo[a])); }
+    // power-of-two scale: the block's points land in [-127, 127] (rounded to f16: <= 128)
+    int s = 0;
+    if (ext > 0.0 && std::isfinite(ext)) { s = (int)std::floor(std::log2(127.0 / ext)); while (std::ldexp(ext, s) > 127.0) --s; }
+    s = std::max(-900, std::min(900, s));
+    const double scale = std::ldexp(1.0, s);
+    double db = 0.0, en = 0.0;
+    for (int t = b * FAN; t < std::min(tiles, (b + 1) * FAN); ++t)
+      for (int i = 0; i < LEAF; ++i) {
+        const int k = t * LEAF + i;
+        unsigned short lo8[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hi8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        hi8[4] = f16_bits(4096.0); hi8[5] = hi8[6] = f16_bits(1.0);
+        if (k < n) {
+          double bt[3], res2 = 0.0, nn = 0.0;
+          for (int a = 0; a < 3; ++a) {
+            const double beta = (spts[3 * (size_t)k + a] - c[a]) * scale;
+            const unsigned short h = f16_bits(beta);
+            const unsigned short l = f16_bits(beta - f16_value(h));
+            bt[a] = f16_value(h) + f16_value(l);
+            res2 += (beta - bt[a]) * (beta - bt[a]);
+            nn += bt[a] * bt[a];
+            lo8[a] = hi8[a] = f16_bits(-2.0 * f16_value(h));
+            lo8[3 + a] = f16_bits(-2.0 * f16_value(l));
+          }
+          const unsigned short n1 = f16_bits(nn), n2 = f16_bits(nn - f16_value(n1)), n3 = f16_bits(nn - f16_value(n1) - f16_value(n2));
+          lo8[6] = n1; lo8[7] = n2; hi8[3] = n3;
+          en = std::max(en, std::fabs(nn - f16_value(n1) - f16_value(n2) - f16_value(n3)) + nn * 1e-15);
+          db = std::max(db, std::sqrt(res2));
+        } else {
+          lo8[6] = 0x7bff;   // padding: |b|^2 = 65504, never below a finite threshold (and k < n is re-checked before a confirmation)
+        }
+        std::memcpy(&ops[((size_t)t * 64 + i) * 8], lo8, 16);
+        std::memcpy(&ops[((size_t)t * 64 + 32 + i) * 8], hi8, 16);
+      }
+    MfBlock& B = blk[b];
+    B.cx = c[0]; B.cy = c[1]; B.cz = c[2]; B.scale = scale;
+    // + the fp64 rounding of (p - c) * scale on the host
+    B.db = (float)((db + (cloud_max + std::fabs(c[0]) + std::fabs(c[1]) + std::fabs(c[2])) * scale * 4.5e-16) * 1.000001 + 1e-30);
+    B.en = (float)(en * 1.000001 + 1e-30);
+    B.pad0 = B.pad1 = 0.f;
+  }
+  MV_HIP(hipMalloc((void**)&G.mf_ops, ops.size() * sizeof(unsigned short)));
+  MV_HIP(hipMemcpy(G.mf_ops, ops.data(), ops.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+  MV_HIP(hipMalloc((void**)&G.mf_blk, blk.size() * sizeof(MfBlock)));
+  MV_HIP(hipMemcpy(G.mf_blk, blk.data(), blk.size() * sizeof(MfBlock), hipMemcpyHostToDevice));
+  return MVICP_OK;
+}
+
+int warm_nn_mfma(mvicp_ctx* c) {
+  hipLaunchKernelGGL(mfma_warm_kernel, dim3(1), dim3(64), 0, c->stream);
+  MV_HIP(hipGetLastError());
+  return MVICP_OK;
+}
+
+int launch_nn_mfma_edges(mvicp_ctx* c, double d2_bound, bool with_bounds, bool with_cache, bool with_list) {
+  std::vector<TileJob> jobs;
+  int max_n = 0;
+  double nq = 0;
+  MV_CHECK(build_tile_jobs(c, with_bounds, with_cache, with_list, jobs, max_n, nq));
+  if (jobs.empty() || max_n == 0) return MVICP_OK;
+  TileJob* d_jobs = nullptr;
+  MV_CHECK(cached_upload(c, jobs[0].xf ? "tile_jobs" : "tile_jobs_raw", jobs.data(), sizeof(TileJob) * jobs.size(), (void**)&d_jobs));
+  unsigned long long* d_stats = nullptr;
+  const size_t slots = (size_t)((max_n + NT - 1) / NT) * jobs.size() * (NT / 64);
+  MV_CHECK(census_scratch(c, slots, &d_stats));
+  {
+    ProfScope ps(c, "nn", 36.0 * nq);  // query read 24 B + result write 12 B; tile-operand / box bytes come from the census
+    const dim3 grid((max_n + NT - 1) / NT, (unsigned)jobs.size());
+    int top = jobs[0].dst.levels - 1;   // same depth everywhere -> the traversal specialised for it
+    for (const TileJob& j : jobs) if (j.dst.levels - 1 != top) top = -1;
+#define MVICP_MFMA_K(W, T, B) do { if (d_stats) hipLaunchKernelGGL((nn_mfma_kernel<W, T, B, true>), grid, dim3(NT), 0, c->stream, d_jobs, d2_bound, d_stats); \
+                                 else hipLaunchKernelGGL((nn_mfma_kernel<W, T, B, false>), grid, dim3(NT), 0, c->stream, d_jobs, d2_bound, d_stats); } while (0)
+    const int waves = c->tile_waves;
+    if (with_bounds) {
+      if (top == 2) MVICP_MFMA_K(5, 2, true); else MVICP_MFMA_K(5, -1, true);
+    }
+    else if (top == 2 && waves == 6) MVICP_MFMA_K(6, 2, false);
+    else if (top == 2 && waves == 4) MVICP_MFMA_K(4, 2, false);
+    else if (top == 2) MVICP_MFMA_K(5, 2, false);
+    else if (top == 1) MVICP_MFMA_K(5, 1, false);
+    else MVICP_MFMA_K(5, -1, false);
+#undef MVICP_MFMA_K
+  }
+  MV_HIP(hipGetLastError());
+  if (with_list) MV_CHECK(launch_dirty_reduce(c));   // per-edge OR of the "list membership changed" slots
+  if (d_stats) MV_CHECK(census_collect(c, d_stats, slots, nq));
+  return MVICP_OK;
+}
+
+}  // namespace mvicp

@@ -31,100 +31,11 @@
 // The kernel is VALU-issue bound (not memory bound): its design minimises wave instructions per opened tile.
 // No per-lane pointer chasing, no divergence between "near" and "far" queries: the first-round regime
 // (centimetre misalignment) and the converged regime run the same code, the former just opens more leaves.
-#include <algorithm>
-#include <cmath>
-#include <cstring>
-#include <limits>
-#include <vector>
-
-#include "common.h"
-#include "nn_list.h"
+#include "nn_tile_common.h"
 
 namespace mvicp {
 
 namespace {
-
-constexpr int NT = 256;
-#ifndef MVICP_TILE_LEAF
-#define MVICP_TILE_LEAF 32
-#endif
-constexpr int LEAF = MVICP_TILE_LEAF;   // points per leaf tile (tuning builds may override; 32 measured best)
-constexpr int FAN = 64;    // children per node = one box per lane
-
-struct TileView {
-  const double* spts; const int* sidx; int n;
-  const float* wide; int levels;  // number of box levels (>= 1)
-  int cnt[6]; long long off[6];
-  double maxabs;                  // largest |coordinate| in the cloud
-};
-
-struct TileJob {
-  TileView dst;
-  const double* q; const int* qidx; const double* xf; int n;
-  int* out_idx; double* out_d2;
-  const int* inv;   // target original index -> sorted position
-  int seed;         // out_idx still holds last round's neighbours (sorted positions, -1 = none): use them as starting candidates
-  float* out_lb;    // BND builds (fp32, rounded down): per query, a lower bound on the distance to every target other than out_idx (the grid kernel's temporal cache)
-  float mu;         // BND builds: width of the extra guard band (metres) that makes that bound useful
-  // BND builds, cache-aware rounds (round 3): out_lb holds last search's bounds and the edge's query transform carries the temporal-cache
-  // allowance (xf[24] >= 0): a lane whose neighbour provably did not change sits the traversal out, like in nn_grid_kernel.  `list`
-  // (list.dirty != null) = the edge's compacted list is maintained in place by this launch (nn_list.h).
-  int cache;
-  ListRef list;
-};
-
-__device__ __forceinline__ void xf_point(const double* __restrict__ x, double p0, double p1, double p2, double& q0, double& q1, double& q2) {
-  double g[3], u[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-    g[i] = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(x[i], p0), __dmul_rn(x[i + 3], p1)), __dmul_rn(x[i + 6], p2)), x[9 + i]);
-#pragma unroll
-  for (int i = 0; i < 3; ++i) u[i] = __dsub_rn(g[i], x[21 + i]);
-  q0 = __dadd_rn(__dadd_rn(__dmul_rn(x[12 + 0], u[0]), __dmul_rn(x[12 + 3], u[1])), __dmul_rn(x[12 + 6], u[2]));
-  q1 = __dadd_rn(__dadd_rn(__dmul_rn(x[12 + 1], u[0]), __dmul_rn(x[12 + 4], u[1])), __dmul_rn(x[12 + 7], u[2]));
-  q2 = __dadd_rn(__dadd_rn(__dmul_rn(x[12 + 2], u[0]), __dmul_rn(x[12 + 5], u[1])), __dmul_rn(x[12 + 8], u[2]));
-}
-
-// Wave-wide reductions on the DPP network (row quad-perm / mirror steps, then row_bcast15 / row_bcast31; lane 63 ends up with the
-// result, broadcast through readlane -> SGPRs).  __shfl_xor would go through ds_bpermute: ~12 LDS-crossbar round trips per reduction,
-// and this kernel reduces once per traversal step.
-// fp32 reductions of NON-NEGATIVE values (incl. +inf): their bit patterns order like unsigned integers, so the whole
-// reduction is six v_min_u32 / v_max_u32 with the DPP permutation fused into the operand (the builtin form costs a
-// mov + mov_dpp + op per step).  "s_nop 1": a VALU result needs two wait states before a DPP read of it.
-#define MVICP_DPP_CHAIN(OP)                                                         \
-  "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
-  "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" \
-  "s_nop 1\n\t" OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"     \
-  "s_nop 1\n\t" OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"          \
-  "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"        \
-  "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"        \
-  "s_nop 1"
-__device__ __forceinline__ float wave_max_f(float nonneg) {
-  unsigned int v = (unsigned int)__float_as_int(nonneg);
-  asm volatile(MVICP_DPP_CHAIN("v_max_u32_dpp") : "+v"(v));
-  return __int_as_float(__builtin_amdgcn_readlane((int)v, 63));
-}
-__device__ __forceinline__ float wave_min_f(float nonneg) {
-  unsigned int v = (unsigned int)__float_as_int(nonneg);
-  asm volatile(MVICP_DPP_CHAIN("v_min_u32_dpp") : "+v"(v));
-  return __int_as_float(__builtin_amdgcn_readlane((int)v, 63));
-}
-// fp32 reductions of ARBITRARY floats (negative coordinates, +-inf): the key  b ^ ((b >> 31) & 0x7fffffff)  orders like the float as a
-// signed integer and is its own inverse, so the wave minimum / maximum is again six DPP-fused v_min_i32 / v_max_i32.
-__device__ __forceinline__ int fkey(float f) { const int b = __float_as_int(f); return b ^ ((b >> 31) & 0x7fffffff); }
-__device__ __forceinline__ float wave_min_any(float f) {
-  int v = fkey(f);
-  asm volatile(MVICP_DPP_CHAIN("v_min_i32_dpp") : "+v"(v));
-  return __int_as_float(fkey(__int_as_float(__builtin_amdgcn_readlane(v, 63))));
-}
-__device__ __forceinline__ float wave_max_any(float f) {
-  int v = fkey(f);
-  asm volatile(MVICP_DPP_CHAIN("v_max_i32_dpp") : "+v"(v));
-  return __int_as_float(fkey(__int_as_float(__builtin_amdgcn_readlane(v, 63))));
-}
-__device__ __forceinline__ float bcast(float v, int lane) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
 
 typedef float f2v __attribute__((ext_vector_type(2)));
 
@@ -157,11 +68,6 @@ __device__ __forceinline__ float box_lb32(const Lane& L, float b0, float b1, flo
   return __builtin_fmaf(g2, g2, __builtin_fmaf(g1, g1, g0 * g0));
 }
 
-// screen threshold for a running best: (sqrt(best) + slack)^2 with 2^-20 relative head-room
-__device__ __forceinline__ float thr_of(double best, float slack) {
-  const float rb = (float)sqrt(best) * 1.000001f + slack;
-  return rb * rb * 1.000002f;
-}
 
 // Scan one leaf tile for the whole wave.  The tile is staged once in LDS as fp64 (exact evaluation) AND fp32
 // (screening): a candidate is evaluated in the reference's fp64 arithmetic only if its fp32 distance is within
@@ -461,30 +367,6 @@ __global__ __launch_bounds__(NT, WPE) void nn_tile_kernel(const TileJob* __restr
   }
 }
 
-// sums the per-wave census slots (8 counters each) into out8 (zeroed by the caller); 64 workgroups, 8 atomics each
-__global__ __launch_bounds__(256) void census_sum_kernel(const unsigned long long* __restrict__ stats, size_t slots, unsigned long long* __restrict__ out8) {
-  __shared__ unsigned long long sh[8][256];
-  unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < slots; i += (size_t)gridDim.x * 256)
-    for (int k = 0; k < 8; ++k) v[k] += stats[8 * i + k];
-  for (int k = 0; k < 8; ++k) sh[k][threadIdx.x] = v[k];
-  __syncthreads();
-  if (threadIdx.x < 8) {
-    unsigned long long s = 0;
-    for (int i = 0; i < 256; ++i) s += sh[threadIdx.x][i];
-    atomicAdd(&out8[threadIdx.x], s);
-  }
-}
-
-TileView view_of(const FrameDev& f) {
-  TileView v;
-  v.spts = f.grid.spts; v.sidx = f.grid.sidx; v.n = f.n;
-  v.wide = f.grid.wide; v.levels = f.grid.wide_levels;
-  for (int l = 0; l < 6; ++l) { v.cnt[l] = f.grid.wide_cnt[l]; v.off[l] = f.grid.wide_off[l]; }
-  v.maxabs = f.grid.maxabs;
-  return v;
-}
-
 }  // namespace
 
 int build_wide(FrameDev& f, const double* spts) {
@@ -542,46 +424,17 @@ int warm_nn_tile(mvicp_ctx* c) {   // see warm_nn_grid (nn_grid.hip): loads this
 }
 
 int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound, bool with_bounds, bool with_cache, bool with_list) {
+  if (c->tile_mfma) return launch_nn_mfma_edges(c, d2_bound, with_bounds, with_cache, with_list);   // the matrix-pipe build of the same search (nn_mfma.hip)
   std::vector<TileJob> jobs;
   int max_n = 0;
   double nq = 0;
-  for (int e = 0; e < c->E; ++e) {
-    if (!c->active[e]) continue;
-    const FrameDev& s = c->frames[c->esrc[e]];
-    const FrameDev& d = c->frames[c->edst[e]];
-    if (!s.has_grid || !d.has_grid) { set_error("tile NN needs the per-cloud structure on frames %d and %d", c->esrc[e], c->edst[e]); return MVICP_ERR_STATE; }
-    TileJob j;
-    std::memset(&j, 0, sizeof(j));  // padding too: the table is cached by content
-    j.dst = view_of(d);
-    j.q = s.grid.spts; j.qidx = nullptr; j.xf = c->d_xf + (size_t)e * kEdgeXf; j.n = s.n;
-    j.out_idx = c->d_nn_idx + c->cap_off[e]; j.out_d2 = c->d_nn_d2 + c->cap_off[e];
-    j.inv = d.grid.inv;
-    j.seed = (c->tile_seed && (int)c->nn_cache_edge.size() == c->E && c->nn_cache_edge[e]) ? 1 : 0;
-    if (with_bounds) { j.out_lb = c->d_nn_lb + c->cap_off[e]; j.mu = (float)(c->tile_mu * d.grid.cell); }
-    if (with_bounds && with_cache) j.cache = 1;
-    if (with_list) {
-      j.list = ListRef{c->d_qpos + c->cap_off[e], c->d_second + c->cap_off[e], c->d_cd2 + c->cap_off[e], c->d_dirty + e, c->d_dirty_slots + c->dslot_off[e],
-                       c->d_stream + c->cap_off[e], c->total_cap, d.grid.snor, (const PointRec*)d.grid.srec};
-    }
-    jobs.push_back(j);
-    max_n = std::max(max_n, s.n);
-    nq += s.n;
-  }
+  MV_CHECK(build_tile_jobs(c, with_bounds, with_cache, with_list, jobs, max_n, nq));
   if (jobs.empty() || max_n == 0) return MVICP_OK;
   TileJob* d_jobs = nullptr;
   MV_CHECK(cached_upload(c, jobs[0].xf ? "tile_jobs" : "tile_jobs_raw", jobs.data(), sizeof(TileJob) * jobs.size(), (void**)&d_jobs));
   unsigned long long* d_stats = nullptr;
   const size_t slots = (size_t)((max_n + NT - 1) / NT) * jobs.size() * (NT / 64);
-  if (c->profile && c->nn_census) {
-    const size_t need = sizeof(unsigned long long) * 8 * (slots + 1);
-    if (need > c->census_bytes) {
-      if (c->d_census) MV_HIP(hipFree(c->d_census));
-      MV_HIP(hipMalloc((void**)&c->d_census, need));
-      c->census_bytes = need;
-    }
-    d_stats = (unsigned long long*)c->d_census;
-    MV_HIP(hipMemsetAsync(d_stats, 0, need, c->stream));
-  }
+  MV_CHECK(census_scratch(c, slots, &d_stats));
   {
     ProfScope ps(c, "nn", 36.0 * nq);  // query read 24 B + result write 12 B; candidate / box bytes come from the census
     const dim3 grid((max_n + NT - 1) / NT, (unsigned)jobs.size());
@@ -603,13 +456,7 @@ int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound, bool with_bounds, bool w
   }
   MV_HIP(hipGetLastError());
   if (with_list) MV_CHECK(launch_dirty_reduce(c));   // per-edge OR of the "list membership changed" slots
-  if (d_stats) {
-    if (!c->h_census) MV_HIP(hipHostMalloc((void**)&c->h_census, 8 * sizeof(unsigned long long), hipHostMallocDefault));
-    // counters -> pinned memory, asynchronously; census_resolve() folds them in after the caller's own wait (no extra sync)
-    hipLaunchKernelGGL(census_sum_kernel, dim3(64), dim3(256), 0, c->stream, d_stats, slots, d_stats + 8 * slots);
-    MV_HIP(hipMemcpyAsync(c->h_census, d_stats + 8 * slots, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-    c->census_pending = true; c->census_nq = nq; c->census_kind = 2;
-  }
+  if (d_stats) MV_CHECK(census_collect(c, d_stats, slots, nq));
   return MVICP_OK;
 }
 

@@ -319,9 +319,10 @@ class Engine:
         _check(self.lib, self.lib.mvicp_set_option(self.h, name.encode(), float(value)))
 
     def nn_census(self):
-        out = np.zeros(6)
-        _check(self.lib, self.lib.mvicp_nn_census_ex(self.h, _dp(out), 6))
-        return {"queries": out[0], "candidates": out[1], "nodes": out[2], "far": out[3], "hits": out[4], "fetched": out[5]}
+        out = np.zeros(10)
+        _check(self.lib, self.lib.mvicp_nn_census_ex(self.h, _dp(out), 10))
+        return {"queries": out[0], "candidates": out[1], "nodes": out[2], "far": out[3], "hits": out[4], "fetched": out[5],
+                "rescreens": out[6], "confirm_rounds": out[7], "blocks": out[8], "confirmations": out[9]}
 
     # ---- profiling
     def profile(self, on=True):

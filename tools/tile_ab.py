@@ -27,7 +27,12 @@ for v in variants:
         ms = eng.profile_get("nn")[0]
         cs = eng.nn_census() if os.environ.get("AB_CENSUS") == "1" else None
         poses, sm = eng.optimize(poses, pb["fixed"], 2, 1, 1, 50)
-        rows.append(round(ms, 3) if cs is None else (round(ms, 3), round(cs["candidates"] / max(cs["queries"], 1), 1)))
+        if cs is None:
+            rows.append(round(ms, 3))
+        else:   # ms, candidates per query, [per wave: second screens, confirmation rounds, blocks], fp64 confirmations per query
+            w = max(cs["queries"], 1) / 64.0
+            rows.append((round(ms, 3), round(float(cs["candidates"] / max(cs["queries"], 1)), 1), round(float(cs["rescreens"] / w), 2), round(float(cs["confirm_rounds"] / w), 2),
+                         round(float(cs["blocks"] / w), 2), round(float(cs["confirmations"] / max(cs["queries"], 1)), 2)))
         trace.append((c.copy(), w.copy(), poses.copy()))
     same = None
     if ref is None:
