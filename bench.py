@@ -42,7 +42,7 @@ WORKLOADS = {
 }
 ROUNDS_PER_REGISTRATION = 20   # main_multiview.cpp:150
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 
 def source_sha16():
@@ -149,6 +149,20 @@ def cpu_reference_legs(pb, plane, param, gpu_poses_after, gpu_iters, window_roun
     return out
 
 
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch_argv(n, argv, port=None):
+    """The command `python bench.py --gpus N ...` turns itself into when it was not started by a launcher (RANK unset): the driver's own
+    multi-GPU form, one rank per GPU on this node, rendezvous on 127.0.0.1."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port if port is not None else free_port()), os.path.abspath(__file__)] + list(argv)
+
+
 def synth_pose_diff(A, B):
     from mvicp import synth
     return synth.pose_diff(A, B)
@@ -167,9 +181,24 @@ def main():
     ap.add_argument("--allow-host-exchange", action="store_true", help="N > 1 only: if the RCCL communicator cannot be created, fall back to a host-staged gloo all-reduce instead of failing")
     ap.add_argument("--grid-target", type=float, default=None)
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (mvicp_set_option), repeatable; tuning / A-B runs")
+    ap.add_argument("--windows", type=int, default=5, help="the timed window of --steps rounds is repeated this many times; value = the MEDIAN window (all in window_values)")
     args = ap.parse_args()
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or args.windows < 1:
+        print("[bench] --gpus, --steps and --windows must be >= 1 and --warmup >= 0", file=sys.stderr)
+        sys.exit(2)
 
     import torch
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # Started as plain `python bench.py --gpus N`: become N ranks (one per GPU) through torch.distributed.run instead of silently
+        # measuring one.  The parent only launches and relays the exit code; rank 0 of the children prints the JSON line.
+        n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n_dev < args.gpus:
+            print(f"[bench] --gpus {args.gpus} needs {args.gpus} visible GPUs, this node has {n_dev}: not measuring a smaller job under that label", file=sys.stderr)
+            sys.exit(2)
+        import subprocess
+        sys.exit(subprocess.call(self_launch_argv(args.gpus, sys.argv[1:])))
+
     import mvicp
     from mvicp import lib as L
     from mvicp import synth
@@ -179,9 +208,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("MVICP_FORCE_DEVICE") is not None:   # debugging aid: several ranks on one GPU
         local = int(os.environ["MVICP_FORCE_DEVICE"])
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    if world != args.gpus:
+        # a launcher that started a different number of ranks than --gpus says is a mislabelled measurement: refuse
+        if rank == 0:
+            print(f"[bench] launched with WORLD_SIZE={world} but --gpus {args.gpus}: refusing to print a line labelled with either", file=sys.stderr)
+        sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a GPU: the product path has no CPU fallback"
+    if os.environ.get("MVICP_FORCE_DEVICE") is None and torch.cuda.device_count() < world:
+        if rank == 0:
+            print(f"[bench] {world} ranks but only {torch.cuda.device_count()} visible GPUs (one rank per GPU)", file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
@@ -287,30 +323,43 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    eng.profile(2)   # live HIP-event scopes around the two roofline kernels only ("nn", "linearize") + the collective; everything else: replay pass below
+    eng.profile(2)   # live HIP-event scopes around the roofline kernels only (one scope per NN kernel, "linearize") + the collective; everything else: replay pass below
     eng.profile_reset()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    # R back-to-back windows of exactly --steps rounds, each bracketed by barrier + synchronize on both sides and reduced with MAX over
+    # ranks; `value` is the MEDIAN window (a 20-round window is ~20 ms: one window alone is at the mercy of a single slow launch)
+    R = args.windows
+    NSTEPS = args.steps * R          # rounds under the live scopes (per-step averages below)
+    window_s, window_local_s = [], []
+    for w in range(R):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        window_local_s.append(dt)
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        window_s.append(dt)
+    med = int(np.argsort(window_s)[(R - 1) // 2])   # (lower median for an even count)
+    elapsed = window_s[med]
+    local_elapsed = window_local_s[med]
     digest(raw[:args.warmup])                       # warm-up rounds: only their poses matter (registration 1)
-    log = digest(raw[args.warmup:])
+    log_all = digest(raw[args.warmup:])
+    log = log_all[med * args.steps:(med + 1) * args.steps]   # the per-round log of the median window
     raw.clear()
-    local_elapsed = elapsed
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
 
-    timed = {k: eng.profile_get(k) for k in ("nn", "linearize", "comm")}
-    spec_hits = eng.profile_get("spec.hit")[1]
-    host = {k: eng.profile_get(k)[0] / args.steps for k in ("host.correspond", "host.corr.setup", "host.corr.nn_launch", "host.corr.post_launch", "host.corr.wait",
-                                                            "host.corr.finish", "host.optimize", "host.evaluate")}
+    NN_SCOPES = ("nn_mfma", "nn_tile", "nn_grid", "nn_brute")   # one HIP-event scope per NN kernel; "nn_far" = the grid stage's second phase; "nn" = all together
+    timed = {k: eng.profile_get(k) for k in ("nn", "linearize", "comm", "nn_far") + NN_SCOPES}
+    spec_hits = eng.profile_get("spec.hit")[1] / R
+    host = {k: eng.profile_get(k)[0] / NSTEPS for k in ("host.correspond", "host.corr.setup", "host.corr.nn_launch", "host.corr.post_launch", "host.corr.wait",
+                                                          "host.corr.finish", "host.optimize", "host.evaluate")}
     eng.profile(False)
     timed_log = list(log)
     final_poses = L.poses_from_c(Pc)
+    g_end = state["g"]
 
     # Replay pass (UNTIMED): the same global rounds again (same registrations, same resets), now with every profiling scope and the NN
     # census on (per-launch candidate / box / cache-hit counts = the algorithmic bytes of every NN launch).  The engine is
@@ -328,10 +377,11 @@ def main():
         eng.profile(1)
         eng.set_option("nn_census", 1)
         eng.profile_reset()
-        for _ in range(args.steps):
+        for _ in range(NSTEPS):
             step()
         fence()
         replay = {k: eng.profile_get(k) for k in ("nn", "compact", "gather", "select", "linearize", "reduce")}
+        replay_ex = {k: eng.profile_get_ex(k) for k in ("nn",) + NN_SCOPES}
         census = eng.nn_census()
         eng.set_option("nn_census", 0)
         eng.profile(False)
@@ -355,14 +405,19 @@ def main():
     #   nn         per launch 24 N_src (queries) + 12 N_src (index + distance) + 24 x candidate points FETCHED FROM MEMORY + 8 x cells / boxes
     #              looked up, from the replay's exact census (hash-slot reads of the per-lane kernel are not counted: conservative).
     #              `compulsory` = the structure-independent bound 60 B per query the survey quotes next to it.
-    prof = {"linearize": timed["linearize"]}
-    nn_ms, nn_n, _ = timed["nn"]
-    nn_alg = nn_comp = nn_model = float("nan")
-    if census is not None and replay["nn"][1] == nn_n and nn_n > 0:
-        nn_alg = (36.0 * census["queries"] + 24.0 * census["fetched"] + 8.0 * census["nodes"]) / nn_n
-        nn_comp = 60.0 * census["queries"] / nn_n
-        nn_model = replay["nn"][2] / nn_n
-    prof["nn"] = (nn_ms, nn_n, nn_alg * nn_n if nn_n else 0.0)
+    # one entry per kernel: (timed ms, timed launches, SURVEY bytes over those launches, compulsory bytes, library-model bytes)
+    prof = {"linearize": (timed["linearize"][0], timed["linearize"][1], timed["linearize"][2], None, None)}
+    for k in ("nn",) + NN_SCOPES:
+        ms_k, n_k, _ = timed[k]
+        if n_k == 0:
+            continue
+        alg = comp = model = float("nan")
+        # the replay pass repeats exactly the rounds under the live scopes (all R windows): same launches, now with the census on
+        if replay is not None and replay_ex[k]["launches"] == n_k:
+            alg = replay_ex[k]["survey_bytes"]
+            comp = 60.0 * replay_ex[k]["queries"]
+            model = replay_ex[k]["model_bytes"]
+        prof[k] = (ms_k, n_k, alg, comp, model)
 
     sha = source_sha16()
 
@@ -370,34 +425,40 @@ def main():
         """HBM bytes per launch of THIS command from a committed rocprofv3 PMC summary (tools/profile.sh -> profiles/), used only if
         that summary was taken with the same workload / warm-up / steps / NN method AND the same device sources (hash) — otherwise null.
         FETCH_SIZE is doubled for the 16-B/lane coalesced linearize stream as MI355X_MICROARCH.md §HBM prescribes for gfx950; the NN
-        stage mixes access widths (uncalibrated there), so its raw counters are used as they are."""
+        kernels mix access widths (uncalibrated there), so their raw counters are used as they are."""
         path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{args.workload}_w{args.warmup}s{args.steps}_kernels.json")
         if world != 1 or args.nn != "auto" or args.opt or not os.path.exists(path):
             return None
         try:
             j = json.load(open(path))
-            if j.get("source_sha16") != sha or j.get("warmup_skipped") != args.warmup or j.get("timed_rounds") != args.steps:
+            if j.get("source_sha16") != sha or j.get("warmup_skipped") != args.warmup or j.get("timed_rounds") != args.steps or j.get("windows", 1) != args.windows:
                 return None
             sc = j["scopes"][name]
             return (sc["FETCH_SIZE_KiB"] * (2.0 if name == "linearize" else 1.0) + sc["WRITE_SIZE_KiB"]) * 1024.0
         except Exception:
             return None
 
+    KERNEL_OF = {"nn_mfma": "nn_mfma_kernel", "nn_tile": "nn_tile_kernel", "nn_grid": "nn_grid_kernel", "nn_brute": "nn_brute_kernel", "linearize": "linearize_kernel",
+                 "nn": "(all NN kernels together: a scope, not a kernel)"}
+
     def roof(name):
-        ms, n, b = prof[name]
-        if n == 0 or ms <= 0 or not np.isfinite(b):
+        if name not in prof:
+            return None
+        ms, n, b, comp, model = prof[name]
+        if n == 0 or ms <= 0 or b is None or not np.isfinite(b):
             return None
         ach = (b / n) / (ms / n * 1e-3) / 1e9
-        r = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-             "traffic": pmc_traffic(name), "launches": n, "avg_us": ms / n * 1e3, "alg_bytes_per_launch": b / n}
-        if name == "nn":
-            r["compulsory_bytes_per_launch"] = nn_comp
-            r["compulsory_frac"] = nn_comp / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS
-            r["overhead_bytes"] = max(0.0, nn_model - b / n)   # temporal-cache / list state and record padding in the library's own finer byte model
+        r = {"kernel": name, "device_function": KERNEL_OF.get(name), "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+             "traffic": pmc_traffic(name), "launches": n, "avg_us": ms / n * 1e3, "total_ms": ms, "alg_bytes_per_launch": b / n}
+        if name.startswith("nn"):
+            r["compulsory_bytes_per_launch"] = comp / n
+            r["compulsory_frac"] = comp / n / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS
+            r["overhead_bytes"] = max(0.0, (model - b) / n)   # temporal-cache / list state and record padding in the library's own finer byte model
             r["bytes_formula"] = "36 B/query + 24 B/candidate point fetched + 8 B/cell or box looked up (SURVEY.md §8d), census of the untimed replay pass"
         return r
 
-    dominant = max(("nn", "linearize"), key=lambda k: prof[k][0])
+    # the dominant KERNEL: largest total time under the live scopes among the individual kernels ("nn" is a scope over several kernels, never the headline)
+    dominant = max([k for k in prof if k != "nn"], key=lambda k: prof[k][0])
     err_t = max(synth.pose_diff(final_poses[k], pb["gt"][k])[0] for k in range(K))
     err_r = max(synth.pose_diff(final_poses[k], pb["gt"][k])[1] for k in range(K))
 
@@ -414,7 +475,7 @@ def main():
     if world > 1:
         # per-rank phase times (ms per step) so that a first real multi-GPU run is diagnosable: who waits for whom
         mine = torch.tensor([local_elapsed / args.steps * 1e3, float(np.mean([l["nn_ms"] for l in log])), float(np.mean([l["lm_ms"] for l in log])),
-                             timed["nn"][0] / args.steps, timed["linearize"][0] / args.steps, timed["comm"][0] / args.steps, host["host.corr.wait"], host["host.evaluate"]],
+                             timed["nn"][0] / NSTEPS, timed["linearize"][0] / NSTEPS, timed["comm"][0] / NSTEPS, host["host.corr.wait"], host["host.evaluate"]],
                             dtype=torch.float64, device="cuda")
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
@@ -442,27 +503,31 @@ def main():
                         "rounds_with_bit_identical_poses": int(sum(l["poses_bit_identical"] for l in log))},
             "round_ms": [round(l["nn_ms"] + l["lm_ms"], 4) for l in log], "round_index": window_rounds,
             "roofline": roof(dominant), "roofline_nn": roof("nn"), "roofline_linearize": roof("linearize"),
+            **{"roofline_" + k: roof(k) for k in NN_SCOPES if k in prof},
+            "window_values": [args.steps / t for t in window_s], "window_ms_per_step": [t / args.steps * 1e3 for t in window_s], "windows": R,
+            "window_note": f"{R} back-to-back windows of {args.steps} rounds, each fenced; value / ms_per_step / round_ms / regimes = the median window; kernel_ms_per_step, host_ms_per_step and the rooflines = all windows",
             "phase_ms_per_step": {"correspond": float(np.mean([l["nn_ms"] for l in log])), "optimize": float(np.mean([l["lm_ms"] for l in log])),
                                   "lm_iterations": float(np.mean([l["lm_iters"] for l in log])), "device_evaluations": float(np.mean([l["evals"] for l in log])),
                                   "correspondences": float(np.mean([l["corr"] for l in log]))},
             "lm_step_economy": {"lm_iterations": int(sum(l["lm_iters"] for l in log)), "rejected_or_terminal_steps": int(rejected),
                                 "evaluations": int(sum(l["evals"] for l in log)), "first_evaluations_served_by_the_queued_launch": int(spec_hits)},
-            "kernel_ms_per_step": {"nn": timed["nn"][0] / args.steps, "linearize": timed["linearize"][0] / args.steps},
+            "kernel_ms_per_step": {**{k: timed[k][0] / NSTEPS for k in ("nn", "linearize", "nn_far") + NN_SCOPES if timed[k][1] > 0}},
             "host_ms_per_step": host,
             "pose_error_vs_gt": {"max_translation_m": err_t, "max_rotation_rad": err_r},
             "source_sha16": sha,
         }
         if replay is not None:
-            out["kernel_ms_per_step"].update({k: replay[k][0] / args.steps for k in ("compact", "gather", "select", "reduce")})   # secondary scopes: replay pass
-            out["replay_pass"] = {"identical_poses": replay_identical, "nn_ms_per_step": replay["nn"][0] / args.steps,
+            out["kernel_ms_per_step"].update({k: replay[k][0] / NSTEPS for k in ("compact", "gather", "select", "reduce")})   # secondary scopes: replay pass
+            out["replay_pass"] = {"identical_poses": replay_identical, "nn_ms_per_step": replay["nn"][0] / NSTEPS,
                                   "note": "untimed re-run of the same rounds with all scopes + NN census on (algorithmic bytes per launch)"}
             q = max(1.0, census["queries"])
             out["nn_census_per_query"] = {"candidates_examined": census["candidates"] / q, "candidate_points_fetched": census["fetched"] / q,
                                           "cells_or_boxes": census["nodes"] / q, "tree_fallback_fraction": census["far"] / q,
                                           "temporal_cache_hit_fraction": census["hits"] / q}
         if world > 1:
-            out["comm_ms_per_step"] = timed["comm"][0] / args.steps
-            out["comm_launches_per_step"] = timed["comm"][1] / args.steps
+            out["comm_ms_per_step"] = timed["comm"][0] / NSTEPS
+            out["comm_launches_per_step"] = timed["comm"][1] / NSTEPS
+            out["rccl_nranks"] = eng.comm_nranks() if "rccl" in exchange else None
             out["per_rank"] = per_rank
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -89,6 +89,8 @@ int mvicp_edge_owner(int n_edges, const int* n_src, int world, int* owner);
  * produced by mvicp_comm_unique_id on rank 0 and broadcast by the launcher. */
 int mvicp_comm_unique_id(const char* librccl_path, void* unique_id_128);
 int mvicp_comm_init(mvicp_ctx* ctx, const char* librccl_path, const void* unique_id_128, int rank, int world);
+/* Ranks of the communicator as RCCL itself reports them (ncclCommCount): 0 = no communicator, -1 = this librccl does not say. */
+int mvicp_comm_nranks(mvicp_ctx* ctx);
 
 /* Alternative exchange without RCCL: the launcher supplies an in-place sum all-reduce over HOST doubles (e.g. MPI or
  * torch.distributed/gloo); the library stages the per-edge blocks through host memory.  Same sharding, same exactness;
@@ -174,7 +176,11 @@ int mvicp_closedform_point_to_plane(const double* src, const double* dst, const 
  * "nn_census" (0/1): count candidates / boxes / cache hits per launch while profiling (feeds the algorithmic-byte model).
  * "spin_wait" (0/1, default 0): poll the stream for up to 2 ms before blocking on the per-evaluation / per-round waits.
  * "tile_seed" (0/1, default 1): the tile kernel starts from last round's neighbours; "tile_waves" (0 = auto, 4..8):
- * occupancy variant of the tile kernel; "sel_bracket" (0/1, default 1): one-pass median select around last round's median
+ * occupancy variant of the tile kernel; "tile_mfma" (0/1/2, default 1): the tile method screens an opened tile on the matrix pipe
+ * (nn_mfma_kernel) — 1: except in cache-aware rounds, 2: always, 0: never (the fp32 VALU screen of nn_tile_kernel); "mfma_kacc" (default
+ * 34): allowance for the fp32 accumulation inside one matrix instruction, in units of 2^-24 x sum |terms| (34 = seventeen truncating
+ * additions; lower values are a measured, not a proven, bound); "mfma_trig" (default 2): a lane with more screen hits than this in one
+ * tile makes the wave confirm nearest-first and screen the tile again; "sel_bracket" (0/1, default 1): one-pass median select around last round's median
  * once it has settled; "spec_eval" (0/1, default 1): mvicp_correspond queues the first linearization of the following
  * mvicp_optimize (same poses, previous solve's flags) behind its own kernels so the round waits once, not twice; "lin_share_p"
  * (0/1, default 1): the linearization reads the source points of an all-accepted edge from the shared sorted cloud; "nn_cell"
@@ -195,13 +201,17 @@ int mvicp_nn_census(mvicp_ctx* ctx, double* out5);              /* the first fiv
 int mvicp_nn_census_ex(mvicp_ctx* ctx, double* out, int cap);
 
 /* ---- profiling (HIP events on the library's own stream) ------------------------------------------ */
-/* on = 0: off; 1: every scope below; 2: only "nn" and "linearize" (fewer event packets between the kernels of a
- * timed run). */
+/* on = 0: off; 1: every scope below; 2: only the NN kernels, "linearize" and "comm" (fewer event packets between the kernels of
+ * a timed run). */
 int mvicp_profile_enable(mvicp_ctx* ctx, int on);
 int mvicp_profile_reset(mvicp_ctx* ctx);
-/* kernel in {"nn","compact","gather","select","linearize","reduce","comm"} (HIP-event scopes) or a host timer ("host.correspond", "host.optimize",
- * "host.evaluate", ...) or "spec.hit" (first evaluations served by the queued launch: launches only): total ms, launches, algorithmic bytes. */
+/* kernel in {"nn_brute","nn_grid","nn_tile","nn_mfma" (one scope per NN kernel; "nn" = all of them together),"compact","gather","select","linearize",
+ * "reduce","comm"} (HIP-event scopes) or a host timer ("host.correspond", "host.optimize", "host.evaluate", ...) or "spec.hit" (first evaluations
+ * served by the queued launch: launches only): total ms, launches, bytes of the library's own model. */
 int mvicp_profile_get(mvicp_ctx* ctx, const char* kernel, double* total_ms, long long* launches, double* alg_bytes);
+/* The same entry as numbers: out[0..4] = total ms, launches, model bytes, SURVEY 8(d) algorithmic bytes (NN scopes: 36 B per query + 24 B per
+ * candidate point fetched + 8 B per box or cell looked up; the last two need the "nn_census" option), queries answered.  Returns how many were written. */
+int mvicp_profile_get_ex(mvicp_ctx* ctx, const char* kernel, double* out, int cap);
 /* Opaque hipStream_t the library launches on (so a harness can bracket it with its own events). */
 void* mvicp_stream(mvicp_ctx* ctx);
 int mvicp_sync(mvicp_ctx* ctx);

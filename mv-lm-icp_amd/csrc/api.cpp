@@ -70,7 +70,7 @@ int scratch_upload(mvicp_ctx* c, const void* src, size_t bytes, void** dptr) {
 
 ProfScope::ProfScope(mvicp_ctx* ctx, const char* nm, double bytes) : c(ctx), name(nm), on(ctx->profile) {
   // level 2: only the two roofline scopes (every event pair is two extra queue packets between kernels)
-  if (on && ctx->profile_level >= 2 && std::strcmp(nm, "nn") != 0 && std::strcmp(nm, "linearize") != 0 && std::strcmp(nm, "comm") != 0) on = false;
+  if (on && ctx->profile_level >= 2 && std::strncmp(nm, "nn_", 3) != 0 && std::strcmp(nm, "linearize") != 0 && std::strcmp(nm, "comm") != 0) on = false;
   if (!on) return;
   ProfEntry& pe = c->prof[name];
   auto get = [&]() {
@@ -81,6 +81,7 @@ ProfScope::ProfScope(mvicp_ctx* ctx, const char* nm, double bytes) : c(ctx), nam
   };
   a = get(); b = get();
   pe.bytes += bytes;
+  if (std::strncmp(nm, "nn_", 3) == 0) { pe.survey_bytes += bytes; pe.queries += bytes / 36.0; }   // NN scopes open with 36 B per query (24 B read + 12 B result)
   pe.launches += 1;
   if (a) (void)hipEventRecord(a, c->stream);
 }
@@ -223,7 +224,7 @@ void census_resolve(mvicp_ctx* c) {
   c->census_pending = false;
   const unsigned long long* st = c->h_census;
   const double nq = c->census_nq;
-  ProfEntry& pe = c->prof["nn"];
+  ProfEntry& pe = c->prof[c->census_scope];
   // SURVEY.md §8(d) algorithmic bytes of an NN launch = 36 B per query (already in the scope) + 24 B per candidate point FETCHED FROM
   // MEMORY + 8 B per cell / box looked up; the library's own finer model (record widths, cache state) goes to pe.bytes as before
   if (c->census_kind == 3) {
@@ -233,8 +234,10 @@ void census_resolve(mvicp_ctx* c) {
     pe.bytes += 36.0 * hits + 24.0 * (double)st[4] + 24.0 * (double)st[5] + 32.0 * (double)st[1];
     c->nn_candidates += (double)st[0]; c->nn_nodes += (double)st[1] + (double)st[5]; c->nn_far += (double)st[2]; c->nn_queries += nq; c->nn_hits += hits;
     c->nn_fetched += (double)st[4];
+    pe.survey_bytes += 24.0 * (double)st[4] + 8.0 * ((double)st[1] + (double)st[5]);
   } else if (c->census_kind == 2) {
     c->nn_fetched += (double)st[0];
+    pe.survey_bytes += 24.0 * (double)st[0] + 8.0 * (double)st[1];
     // tile kernel, memory side: every opened tile is loaded ONCE per wave (24 B xyz + 4 B index per point) and every tested
     // box once per wave (24 B); the per-lane distance evaluations (st[2]) are served from LDS.
     pe.bytes += 28.0 * (double)st[0] + 24.0 * (double)st[1];
@@ -248,6 +251,7 @@ void census_resolve(mvicp_ctx* c) {
     pe.bytes += 36.0 * hits + (c->census_kind == 1 ? 4.0 : 132.0) * searched + 32.0 * (double)st[0] + 32.0 * (double)st[1];
     c->nn_candidates += (double)st[0]; c->nn_nodes += (double)st[1]; c->nn_far += (double)st[2]; c->nn_queries += nq; c->nn_hits += hits;
     c->nn_fetched += (double)st[0];   // per-lane kernel: every candidate examined is a record fetched
+    pe.survey_bytes += 24.0 * (double)st[0] + 8.0 * (double)st[1];
   }
 }
 
@@ -976,7 +980,7 @@ int mvicp_set_option(mvicp_ctx* c, const char* name, double value) try {
   if (std::strcmp(name, "tile_mu") == 0) { if (!(value > 0.0 && value <= 1.0)) { set_error("tile_mu outside (0, 1]"); return MVICP_ERR_ARG; } c->tile_mu = value; return MVICP_OK; }
   if (std::strcmp(name, "mfma_kacc") == 0) { if (!(value >= 1.0 && value <= 1024.0)) { set_error("mfma_kacc outside [1, 1024]"); return MVICP_ERR_ARG; } c->mfma_kacc = value; return MVICP_OK; }
   if (std::strcmp(name, "mfma_trig") == 0) { c->mfma_trig = (int)value; return MVICP_OK; }
-  if (std::strcmp(name, "tile_mfma") == 0) { c->tile_mfma = value != 0.0; return MVICP_OK; }
+  if (std::strcmp(name, "tile_mfma") == 0) { c->tile_mfma = (int)value; return MVICP_OK; }
   if (std::strcmp(name, "tile_waves") == 0) { c->tile_waves = (int)value; return MVICP_OK; }
   if (std::strcmp(name, "tile_cache") == 0) { c->tile_cache = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "spin_wait") == 0) { c->spin_wait = value != 0.0; return MVICP_OK; }
@@ -1012,26 +1016,41 @@ int mvicp_profile_reset(mvicp_ctx* c) try {
   MV_CHECK(bind(c));
   MV_HIP(hipStreamSynchronize(c->stream));
   prof_collect(c);
-  for (auto& kv : c->prof) { kv.second.ms = 0; kv.second.launches = 0; kv.second.bytes = 0; }
+  for (auto& kv : c->prof) { kv.second.ms = 0; kv.second.launches = 0; kv.second.bytes = 0; kv.second.survey_bytes = 0; kv.second.queries = 0; }
   c->nn_candidates = c->nn_nodes = c->nn_far = c->nn_queries = c->nn_hits = c->nn_fetched = 0;
   for (int k = 0; k < 4; ++k) c->nn_dbg[k] = 0;
   return MVICP_OK;
 } MVICP_GUARD_ABI
+// "nn" = every NN kernel scope together (nn_brute, nn_grid, nn_tile, nn_mfma)
+static void prof_sum(mvicp_ctx* c, const char* kernel, double out[5]) {
+  for (int k = 0; k < 5; ++k) out[k] = 0.0;
+  const std::string key = kernel ? kernel : "";
+  for (const auto& kv : c->prof) {
+    if (!(kv.first == key || (key == "nn" && kv.first.compare(0, 3, "nn_") == 0))) continue;
+    out[0] += kv.second.ms; out[1] += (double)kv.second.launches; out[2] += kv.second.bytes; out[3] += kv.second.survey_bytes; out[4] += kv.second.queries;
+  }
+}
 int mvicp_profile_get(mvicp_ctx* c, const char* kernel, double* total_ms, long long* launches, double* alg_bytes) try {
   MV_CHECK(bind(c));
   MV_HIP(hipStreamSynchronize(c->stream));
   prof_collect(c);
-  auto it = c->prof.find(kernel ? kernel : "");
-  if (it == c->prof.end()) {
-    if (total_ms) *total_ms = 0;
-    if (launches) *launches = 0;
-    if (alg_bytes) *alg_bytes = 0;
-    return MVICP_OK;
-  }
-  if (total_ms) *total_ms = it->second.ms;
-  if (launches) *launches = it->second.launches;
-  if (alg_bytes) *alg_bytes = it->second.bytes;
+  double v[5];
+  prof_sum(c, kernel, v);
+  if (total_ms) *total_ms = v[0];
+  if (launches) *launches = (long long)v[1];
+  if (alg_bytes) *alg_bytes = v[2];
   return MVICP_OK;
+} MVICP_GUARD_ABI
+int mvicp_profile_get_ex(mvicp_ctx* c, const char* kernel, double* out, int cap) try {
+  MV_CHECK(bind(c));
+  if (!out || cap < 0) { set_error("bad output buffer"); return MVICP_ERR_ARG; }
+  MV_HIP(hipStreamSynchronize(c->stream));
+  prof_collect(c);
+  double v[5];
+  prof_sum(c, kernel, v);
+  const int n = std::min(cap, 5);
+  for (int k = 0; k < n; ++k) out[k] = v[k];
+  return n;
 } MVICP_GUARD_ABI
 void* mvicp_stream(mvicp_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int mvicp_sync(mvicp_ctx* c) try {

@@ -20,6 +20,7 @@ struct RcclApi {
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
+  int (*CommCount)(void*, int*) = nullptr;   // optional
 };
 
 namespace {
@@ -38,6 +39,7 @@ RcclApi* load(const char* path) {
   a->AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclAllReduce");
   a->CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
   a->GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+  a->CommCount = (int (*)(void*, int*))dlsym(h, "ncclCommCount");
   if (!a->GetUniqueId || !a->CommInitRank || !a->AllReduce || !a->CommDestroy) {
     set_error("%s lacks the nccl* entry points", p);
     delete a;
@@ -93,6 +95,14 @@ int comm_allreduce_sum(mvicp_ctx* c, double* d_buf, size_t n) {
   return MVICP_OK;
 }
 
+// ranks of the communicator as RCCL itself reports them (ncclCommCount); 0 without a communicator
+int comm_nranks(mvicp_ctx* c) {
+  if (!c->comm || !c->rccl) return 0;
+  int n = 0;
+  if (!c->rccl->CommCount || c->rccl->CommCount(c->comm, &n) != 0) return -1;
+  return n;
+}
+
 }  // namespace mvicp
 
 using namespace mvicp;
@@ -100,6 +110,10 @@ extern "C" {
 int mvicp_comm_unique_id(const char* librccl_path, void* unique_id_128) try {
   if (!unique_id_128) { set_error("null id"); return MVICP_ERR_ARG; }
   return comm_unique_id(librccl_path, unique_id_128);
+} MVICP_GUARD_ABI
+int mvicp_comm_nranks(mvicp_ctx* c) try {
+  if (!c) { set_error("null context"); return MVICP_ERR_ARG; }
+  return comm_nranks(c);
 } MVICP_GUARD_ABI
 int mvicp_comm_set_callback(mvicp_ctx* c, mvicp_allreduce_fn fn, void* user) try {
   if (!c) { set_error("null context"); return MVICP_ERR_ARG; }

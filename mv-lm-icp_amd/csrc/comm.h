@@ -9,4 +9,5 @@ int comm_init(mvicp_ctx* c, const char* path, const void* id128, int rank, int w
 void comm_destroy(mvicp_ctx* c);
 // in-place sum over ranks of a device fp64 buffer, on the context's stream
 int comm_allreduce_sum(mvicp_ctx* c, double* d_buf, size_t n);
+int comm_nranks(mvicp_ctx* c);   // ncclCommCount of the communicator (0: none, -1: not reported)
 }  // namespace mvicp

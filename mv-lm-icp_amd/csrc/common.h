@@ -86,7 +86,9 @@ struct FrameDev {
 struct ProfEntry {
   double ms = 0.0;
   long long launches = 0;
-  double bytes = 0.0;
+  double bytes = 0.0;          // the library's own byte model of the scope's launches
+  double survey_bytes = 0.0;   // NN scopes: SURVEY.md 8(d) algorithmic bytes (36 B/query + 24 B/candidate point fetched + 8 B/box or cell looked up)
+  double queries = 0.0;        // NN scopes: queries answered
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
   std::vector<hipEvent_t> pool;
 };
@@ -178,7 +180,7 @@ struct mvicp_ctx {
   double* d_a_check = nullptr;      // where this search's select kernels copy the SoftLOne scales they derive: mapped host memory (single rank) or d_out's tail
   bool spin_wait = false;           // poll the stream instead of a blocking wait (measured: no gain, HIP's own wait already spins)
   unsigned long long* h_census = nullptr;   // pinned: 8 counters of the last NN launch, resolved after the round's own sync
-  bool census_pending = false; double census_nq = 0; int census_kind = 0;   // kind: 0 grid (per-lane), 1 tree-only grid, 2 tile, 3 grid (cell staging)
+  bool census_pending = false; double census_nq = 0; int census_kind = 0; const char* census_scope = "nn_grid";   // kind: 0 grid (per-lane), 1 tree-only grid, 2 tile, 3 grid (cell staging)
   // brute-force split scratch
   int* d_split_idx = nullptr; double* d_split_d2 = nullptr; size_t split_cap = 0;
 
@@ -213,7 +215,8 @@ struct mvicp_ctx {
                                    // temporal-cache check as its prologue (missed lanes are searched wave-cooperatively) instead of the grid kernel
   double tile_mu = 0.02;           // BND guard band as a fraction of the target's hash-cell edge (same role as prune_rho in the grid kernel); round 3 sweep on cfg4
                                    // (hand-over round + the two cache-aware rounds after it): 0.02 -> 2.06 ms, 0.05 -> 2.11, 0.1 -> 2.23, 0.2 -> 2.45
-  bool tile_mfma = true;           // tile method: the screen of an opened tile runs on the matrix pipe (nn_mfma.hip) instead of the fp32 VALU screen (nn_tile.hip)
+  int tile_mfma = 1;               // tile method: 1 = the screen of an opened tile runs on the matrix pipe (nn_mfma.hip) except in cache-aware rounds, 2 = always,
+                                   // 0 = never (the fp32 VALU screen of nn_tile.hip)
   double mfma_kacc = 34.0;         // nn_mfma.hip: allowance for the fp32 accumulation inside one matrix instruction, in units of 2^-24 x sum |terms| (see tau_pieces)
   int mfma_trig = 2;               // nn_mfma.hip: a lane with more than this many screen hits in a tile triggers the nearest-first second screen
   int tile_waves = 0;              // nn_tile_kernel variant: waves per SIMD it is compiled for (0 = the measured best for the depth)

@@ -159,7 +159,7 @@ int run_jobs(mvicp_ctx* c, const std::vector<BruteJob>& jobs, double* pairs_out)
     MV_CHECK(scratch_upload(c, off.data(), sizeof(long long) * off.size(), (void**)&d_off));
   }
   {
-    ProfScope ps(c, "nn", pairs * 24.0);
+    ProfScope ps(c, "nn_brute", pairs * 24.0);
     hipLaunchKernelGGL(nn_brute_kernel, dim3(qblocks, splits, (unsigned)jobs.size()), dim3(NT), 0, c->stream, d_jobs, splits,
                        c->d_split_idx, c->d_split_d2, d_off);
     if (splits > 1)

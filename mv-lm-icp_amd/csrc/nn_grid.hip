@@ -1151,9 +1151,9 @@ int run(mvicp_ctx* c, const std::vector<GridJob>& jobs, double bound) {
   unsigned int* far_next = c->d_far_count + (c->far_parity ^ 1);
   c->far_parity ^= 1;
   bool use_cell = false;
+  const dim3 grid((max_n + NT - 1) / NT, (unsigned)jobs.size());
   {
-    ProfScope ps(c, "nn", 36.0 * nq);  // query 24 B + result 12 B; the rest comes from the census below (0 if the census is off)
-    const dim3 grid((max_n + NT - 1) / NT, (unsigned)jobs.size());
+    ProfScope ps(c, "nn_grid", 36.0 * nq);  // the phase-1 kernel alone: query 24 B + result 12 B; the rest comes from the census below (0 if the census is off)
     // edge searches on clouds with a brick map: the wave-cooperative cell-staging kernel; otherwise (raw queries, profiling
     // switches, grids too large for a dense brick map) the per-lane hash kernel
     use_cell = c->nn_cell && !c->nn_tree_only && !c->nn_skip_far && edge_path;
@@ -1165,6 +1165,9 @@ int run(mvicp_ctx* c, const std::vector<GridJob>& jobs, double bound) {
     else
       hipLaunchKernelGGL((nn_grid_kernel<false>), grid, dim3(NT), 0, c->stream, d_jobs, bound, d_stats, c->nn_skip_far ? 1 : 0, (int2*)c->d_far_list, far_cnt,
                          c->prune_rho);
+  }
+  {
+    ProfScope ps(c, "nn_far", 0.0);   // phase 2 + the list flags: their own scope, so that "nn_grid" times one kernel ("nn" = every nn_* scope together)
     // phase 2: persistent grid-stride launch (the far count is only known on the device)
     // With the temporal cache on, at most a fraction of a per cent of the queries ever reach the far list (0.1-0.2 % in the hand-over rounds,
     // none at the fixed point): a 2048-workgroup launch then costs 19-22 us to find an empty list — 128 workgroups walk the same list
@@ -1184,7 +1187,7 @@ int run(mvicp_ctx* c, const std::vector<GridJob>& jobs, double bound) {
     // counters -> pinned memory, asynchronously; census_resolve() folds them in after the caller's own wait (no extra sync)
     hipLaunchKernelGGL(census_sum_kernel, dim3(64), dim3(256), 0, c->stream, d_stats, slots, d_stats + 8 * slots);
     MV_HIP(hipMemcpyAsync(c->h_census, d_stats + 8 * slots, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-    c->census_pending = true; c->census_nq = nq; c->census_kind = c->nn_tree_only ? 1 : (use_cell ? 3 : 0);
+    c->census_pending = true; c->census_nq = nq; c->census_kind = c->nn_tree_only ? 1 : (use_cell ? 3 : 0); c->census_scope = "nn_grid";
   }
   return MVICP_OK;
 }

@@ -129,11 +129,10 @@ __device__ __forceinline__ unsigned int half_screen(const h8 a, const unsigned i
   float e[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) e[r] = __uint_as_float((__float_as_uint(acc[r]) & 0xfffffff0u) | (unsigned)r);
-#pragma unroll
-  for (int w = 8; w >= 1; w >>= 1)
-#pragma unroll
-    for (int r = 0; r < w; ++r) e[r] = fminf(e[r], e[r + w]);
-  return __float_as_uint(e[0]);
+  // 16 -> 1 in eight v_min3_f32 / v_min_f32
+  const float f0 = fminf(fminf(e[0], e[1]), e[2]), f1 = fminf(fminf(e[3], e[4]), e[5]), f2 = fminf(fminf(e[6], e[7]), e[8]);
+  const float f3 = fminf(fminf(e[9], e[10]), e[11]), f4 = fminf(fminf(e[12], e[13]), e[14]);
+  return __float_as_uint(fminf(fminf(fminf(f0, f1), f2), fminf(fminf(f3, f4), e[15])));
 }
 template <bool NEAREST>
 __device__ __forceinline__ unsigned int screen(const h8 a, const BlockM& K, const LaneM& L, int tile) {
@@ -190,7 +189,7 @@ __device__ __forceinline__ bool confirm(const TileView& g, int tile, LaneM& L, u
 // CROWDED lanes confirm only their nearest one or two first and the tile is screened again with the tightened thresholds — instead of
 // re-evaluating every point inside a loose threshold in fp64.
 template <bool BND, bool CEN>
-__device__ __forceinline__ bool tile_scan(const TileView& g, int tile, const h8 a, LaneM& L, BlockM& K, float sm, Census& C) {
+__device__ __forceinline__ bool tile_scan(const TileView& g, int tile, const h8 a, LaneM& L, BlockM& K, bool last, Census& C) {
   unsigned int done = 0u;
   bool any = false;
   for (;;) {
@@ -206,10 +205,18 @@ __device__ __forceinline__ bool tile_scan(const TileView& g, int tile, const h8 
     done |= m;
     const bool ch = confirm<BND, CEN>(g, tile, L, m, C);
     if (ch) L.rbest = fminf(L.rbest, sqrt_up(L.best));
-    if (__ballot(ch) != 0ull) { any = true; retau(L, K); }
+    if (__ballot(ch) != 0ull) { any = true; if (again || !last) retau(L, K); }   // (the block's last tile, fully confirmed: nobody reads the fragments again)
     if (!again) break;   // every candidate of every lane was confirmed; what the screen rejected stays rejected under tighter thresholds
   }
   return any;
+}
+
+// Next tile of a block: the pending one nearest to the patch centre — or simply the first when at most two are left (no order can save a tile
+// then, and the arg-min is ~20 instructions).  pm = ballot of the pending lanes, != 0.
+__device__ __forceinline__ int pick_tile(unsigned long long pm, bool pend, float key) {
+  if (__popcll(pm) <= 2) return __ffsll((long long)pm) - 1;
+  const float kmin = wave_min_f(pend ? key : __int_as_float(0x7f800000));
+  return __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(pend && key == kmin)) - 1);
 }
 
 // One block (level-0 node): its `nchild` tiles [first, first + nchild), one per lane.
@@ -235,15 +242,12 @@ __device__ void scan_block(const TileView& g, int first, int nchild, LaneM& L, c
   const float sm = G.slack + G.mu;
   float gmax = box_thr(wave_max_f(L.active ? L.rbest : 0.f), sm);
   bool pend = ddf <= gmax;
-  if (__ballot(pend) == 0ull) return;
+  unsigned long long pm = __ballot(pend);
+  if (pm == 0ull) return;
   MV_CEN(++C.blocks);
   // first tile: picked (nearest to the patch centre) and its fragment requested before the query fragments are built
-  int c_cur;
-  {
-    const float kmin = wave_min_f(pend ? key : inf);
-    c_cur = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(pend && key == kmin)) - 1);
-    if (lane == c_cur) pend = false;
-  }
+  int c_cur = pick_tile(pm, pend, key);
+  if (lane == c_cur) pend = false;
   uint4 a_cur = g.mf_ops[(size_t)(first + c_cur) * 64 + lane];
 
   // the queries in the block's frame: alpha = (q - c) * scale, split into f16 pieces
@@ -284,24 +288,24 @@ __device__ void scan_block(const TileView& g, int first, int nchild, LaneM& L, c
     int c_nxt = -1;
     float ddf_nxt = inf;
     uint4 a_nxt = make_uint4(0u, 0u, 0u, 0u);
-    if (__ballot(pend) != 0ull) {
-      const float kmin = wave_min_f(pend ? key : inf);
-      c_nxt = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(pend && key == kmin)) - 1);
+    pm = __ballot(pend);
+    if (pm != 0ull) {
+      c_nxt = pick_tile(pm, pend, key);
       if (lane == c_nxt) pend = false;
       ddf_nxt = bcast(ddf, c_nxt);
       a_nxt = g.mf_ops[(size_t)(first + c_nxt) * 64 + lane];
     }
     const int tile = first + c_cur;
-    const bool any = tile_scan<BND, CEN>(g, tile, __builtin_bit_cast(h8, a_cur), L, K, sm, C);
+    const bool any = tile_scan<BND, CEN>(g, tile, __builtin_bit_cast(h8, a_cur), L, K, c_nxt < 0, C);
     MV_CEN(C.cand += (unsigned)min(LEAF, g.n - tile * LEAF));
     if (any) {
       gmax = box_thr(wave_max_f(L.active ? L.rbest : 0.f), sm);
       pend = pend && ddf <= gmax;
       while (c_nxt >= 0 && !(ddf_nxt <= gmax)) {   // the requested tile fell outside: next pending one (no prefetch for it)
         c_nxt = -1;
-        if (__ballot(pend) != 0ull) {
-          const float kmin = wave_min_f(pend ? key : inf);
-          c_nxt = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(pend && key == kmin)) - 1);
+        pm = __ballot(pend);
+        if (pm != 0ull) {
+          c_nxt = pick_tile(pm, pend, key);
           if (lane == c_nxt) pend = false;
           ddf_nxt = bcast(ddf, c_nxt);
           a_nxt = g.mf_ops[(size_t)(first + c_nxt) * 64 + lane];
@@ -606,7 +610,7 @@ int launch_nn_mfma_edges(mvicp_ctx* c, double d2_bound, bool with_bounds, bool w
   const size_t slots = (size_t)((max_n + NT - 1) / NT) * jobs.size() * (NT / 64);
   MV_CHECK(census_scratch(c, slots, &d_stats));
   {
-    ProfScope ps(c, "nn", 36.0 * nq);  // query read 24 B + result write 12 B; tile-operand / box bytes come from the census
+    ProfScope ps(c, "nn_mfma", 36.0 * nq);  // query read 24 B + result write 12 B; tile-operand / box bytes come from the census
     const dim3 grid((max_n + NT - 1) / NT, (unsigned)jobs.size());
     int top = jobs[0].dst.levels - 1;   // same depth everywhere -> the traversal specialised for it
     for (const TileJob& j : jobs) if (j.dst.levels - 1 != top) top = -1;
@@ -625,7 +629,7 @@ int launch_nn_mfma_edges(mvicp_ctx* c, double d2_bound, bool with_bounds, bool w
   }
   MV_HIP(hipGetLastError());
   if (with_list) MV_CHECK(launch_dirty_reduce(c));   // per-edge OR of the "list membership changed" slots
-  if (d_stats) MV_CHECK(census_collect(c, d_stats, slots, nq));
+  if (d_stats) MV_CHECK(census_collect(c, d_stats, slots, nq, "nn_mfma"));
   return MVICP_OK;
 }
 

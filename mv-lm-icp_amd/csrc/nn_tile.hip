@@ -424,7 +424,10 @@ int warm_nn_tile(mvicp_ctx* c) {   // see warm_nn_grid (nn_grid.hip): loads this
 }
 
 int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound, bool with_bounds, bool with_cache, bool with_list) {
-  if (c->tile_mfma) return launch_nn_mfma_edges(c, d2_bound, with_bounds, with_cache, with_list);   // the matrix-pipe build of the same search (nn_mfma.hip)
+  // the matrix-pipe build of the same search (nn_mfma.hip).  Cache-aware rounds (a few missed lanes per wave) stay here by default: with
+  // most lanes finished by the cache the per-lane box tests prune nearly every tile, and the 7-wave occupancy of this build hides the
+  // latency of the few that remain (cfg4 rounds 6 / 7: 0.57 / 0.38 ms here against 0.65 / 0.57 ms there)
+  if (c->tile_mfma >= 2 || (c->tile_mfma == 1 && !with_cache)) return launch_nn_mfma_edges(c, d2_bound, with_bounds, with_cache, with_list);
   std::vector<TileJob> jobs;
   int max_n = 0;
   double nq = 0;
@@ -436,7 +439,7 @@ int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound, bool with_bounds, bool w
   const size_t slots = (size_t)((max_n + NT - 1) / NT) * jobs.size() * (NT / 64);
   MV_CHECK(census_scratch(c, slots, &d_stats));
   {
-    ProfScope ps(c, "nn", 36.0 * nq);  // query read 24 B + result write 12 B; candidate / box bytes come from the census
+    ProfScope ps(c, "nn_tile", 36.0 * nq);  // query read 24 B + result write 12 B; candidate / box bytes come from the census
     const dim3 grid((max_n + NT - 1) / NT, (unsigned)jobs.size());
     int top = jobs[0].dst.levels - 1;   // same depth everywhere -> the traversal specialised for it
     for (const TileJob& j : jobs) if (j.dst.levels - 1 != top) top = -1;
@@ -456,7 +459,7 @@ int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound, bool with_bounds, bool w
   }
   MV_HIP(hipGetLastError());
   if (with_list) MV_CHECK(launch_dirty_reduce(c));   // per-edge OR of the "list membership changed" slots
-  if (d_stats) MV_CHECK(census_collect(c, d_stats, slots, nq));
+  if (d_stats) MV_CHECK(census_collect(c, d_stats, slots, nq, "nn_tile"));
   return MVICP_OK;
 }
 

@@ -169,11 +169,11 @@ inline int build_tile_jobs(mvicp_ctx* c, bool with_bounds, bool with_cache, bool
 }
 
 // census counters -> pinned memory, asynchronously; census_resolve() (api.cpp) folds them in after the caller's own wait (no extra sync)
-inline int census_collect(mvicp_ctx* c, unsigned long long* d_stats, size_t slots, double nq) {
+inline int census_collect(mvicp_ctx* c, unsigned long long* d_stats, size_t slots, double nq, const char* scope) {
   if (!c->h_census) MV_HIP(hipHostMalloc((void**)&c->h_census, 8 * sizeof(unsigned long long), hipHostMallocDefault));
   hipLaunchKernelGGL(census_sum_kernel, dim3(64), dim3(256), 0, c->stream, d_stats, slots, d_stats + 8 * slots);
   MV_HIP(hipMemcpyAsync(c->h_census, d_stats + 8 * slots, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-  c->census_pending = true; c->census_nq = nq; c->census_kind = 2;
+  c->census_pending = true; c->census_nq = nq; c->census_kind = 2; c->census_scope = scope;
   return MVICP_OK;
 }
 

@@ -13,9 +13,9 @@ EDGE_BLOCK = 91
 
 SYMBOLS = [
     "mvicp_last_error", "mvicp_version", "mvicp_create", "mvicp_destroy", "mvicp_set_num_frames", "mvicp_set_frame",
-    "mvicp_recompute_normals", "mvicp_set_graph", "mvicp_set_shard", "mvicp_edge_owner", "mvicp_comm_unique_id", "mvicp_comm_init", "mvicp_comm_set_callback", "mvicp_correspond",
+    "mvicp_recompute_normals", "mvicp_set_graph", "mvicp_set_shard", "mvicp_edge_owner", "mvicp_comm_unique_id", "mvicp_comm_init", "mvicp_comm_nranks", "mvicp_comm_set_callback", "mvicp_correspond",
     "mvicp_get_correspondences", "mvicp_set_correspondences", "mvicp_nn_query", "mvicp_linearize", "mvicp_optimize",
-    "mvicp_lm_solve", "mvicp_set_option", "mvicp_nn_census", "mvicp_nn_census_ex", "mvicp_reset_history", "mvicp_profile_enable", "mvicp_profile_reset", "mvicp_profile_get", "mvicp_stream", "mvicp_sync",
+    "mvicp_lm_solve", "mvicp_set_option", "mvicp_nn_census", "mvicp_nn_census_ex", "mvicp_reset_history", "mvicp_profile_enable", "mvicp_profile_reset", "mvicp_profile_get", "mvicp_profile_get_ex", "mvicp_stream", "mvicp_sync",
     "mvicp_closedform_point_to_point", "mvicp_closedform_point_to_plane",
 ]
 
@@ -61,6 +61,7 @@ def load_library(path=None):
     lib.mvicp_comm_unique_id.argtypes = [C.c_char_p, vp]
     lib.mvicp_comm_init.argtypes = [vp, C.c_char_p, vp, C.c_int, C.c_int]
     lib.mvicp_comm_set_callback.argtypes = [vp, ALLREDUCE_FN, vp]
+    lib.mvicp_comm_nranks.argtypes = [vp]
     lib.mvicp_correspond.argtypes = [vp, dp, u8p, C.c_float, C.c_int, ip, fp]
     lib.mvicp_get_correspondences.argtypes = [vp, C.c_int, C.c_int, ip, ip, dp]
     lib.mvicp_set_correspondences.argtypes = [vp, C.c_int, C.c_int, ip, ip, C.c_float]
@@ -75,6 +76,7 @@ def load_library(path=None):
     lib.mvicp_profile_enable.argtypes = [vp, C.c_int]
     lib.mvicp_profile_reset.argtypes = [vp]
     lib.mvicp_profile_get.argtypes = [vp, C.c_char_p, dp, C.POINTER(C.c_longlong), dp]
+    lib.mvicp_profile_get_ex.argtypes = [vp, C.c_char_p, dp, C.c_int]
     lib.mvicp_stream.argtypes = [vp]
     lib.mvicp_stream.restype = vp
     lib.mvicp_sync.argtypes = [vp]
@@ -222,6 +224,10 @@ class Engine:
         path = librccl_path.encode() if librccl_path else None
         _check(self.lib, self.lib.mvicp_comm_init(self.h, path, C.cast(buf, C.c_void_p), self.rank, self.world))
 
+    def comm_nranks(self):
+        """ranks of the RCCL communicator as RCCL reports them (0: none)."""
+        return int(self.lib.mvicp_comm_nranks(self.h))
+
     def comm_set_callback(self, allreduce):
         """allreduce(numpy float64 array) must sum it in place over all ranks (host-staged exchange, no RCCL)."""
         def _cb(_user, ptr, n):
@@ -336,6 +342,12 @@ class Engine:
         ms, n, b = C.c_double(), C.c_longlong(), C.c_double()
         _check(self.lib, self.lib.mvicp_profile_get(self.h, kernel.encode(), C.byref(ms), C.byref(n), C.byref(b)))
         return ms.value, n.value, b.value
+
+    def profile_get_ex(self, kernel):
+        """{"ms", "launches", "model_bytes", "survey_bytes", "queries"} of a scope ("nn" = every NN kernel together)."""
+        out = np.zeros(5)
+        _check(self.lib, self.lib.mvicp_profile_get_ex(self.h, kernel.encode(), _dp(out), 5))
+        return {"ms": float(out[0]), "launches": int(out[1]), "model_bytes": float(out[2]), "survey_bytes": float(out[3]), "queries": float(out[4])}
 
     def sync(self):
         _check(self.lib, self.lib.mvicp_sync(self.h))

@@ -43,7 +43,7 @@ def test_cpu_reference_legs_run_and_report_every_variant():
 def test_source_hash_matches_the_committed_profiles_when_present():
     sha = bench.source_sha16()
     assert len(sha) == 16 and sha == bench.source_sha16()
-    for name in ("r03_cfg4_w5s20_kernels.json", "r03_cfg4_w1s19_kernels.json", "r02_cfg4_w5s20_kernels.json"):
+    for name in ("r04_cfg4_w5s20_kernels.json", "r03_cfg4_w5s20_kernels.json", "r03_cfg4_w1s19_kernels.json", "r02_cfg4_w5s20_kernels.json"):
         p = os.path.join(ROOT, "profiles", name)
         if os.path.exists(p):
             j = json.load(open(p))
@@ -51,3 +51,29 @@ def test_source_hash_matches_the_committed_profiles_when_present():
             # a stale summary is legal (bench.py then reports traffic = null) but worth noticing in the log
             if j["source_sha16"] != sha:
                 print(f"note: {name} was measured on other sources ({j['source_sha16']} != {sha}): bench.py will not quote its traffic")
+
+
+def test_gpus_n_relaunches_itself_as_n_ranks():
+    """`python bench.py --gpus N` started WITHOUT a launcher (RANK unset) must turn into the driver's multi-GPU form — N ranks on this node,
+    rendezvous on 127.0.0.1 — instead of silently measuring one rank under an N-GPU label."""
+    argv = bench.self_launch_argv(8, ["--gpus", "8", "--steps", "20", "--warmup", "5"], port=29517)
+    assert argv[0] == sys.executable and argv[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert "--nproc-per-node=8" in argv and argv[argv.index("--master-addr") + 1] == "127.0.0.1" and argv[argv.index("--master-port") + 1] == "29517"
+    i = argv.index(os.path.join(ROOT, "bench.py"))
+    assert argv[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    assert 1024 < bench.free_port() < 65536
+
+
+def test_gpus_more_than_visible_devices_is_an_error_not_a_smaller_job():
+    """On a box with fewer GPUs than --gpus asks for (here: none) bench.py exits non-zero with a one-line reason and prints no JSON line."""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "--gpus 2 needs 2 visible GPUs" in r.stderr
+    # a launcher that started a different number of ranks than --gpus says is refused as well
+    env.update(RANK="0", WORLD_SIZE="4", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and r.stdout.strip() == "" and "WORLD_SIZE=4 but --gpus 2" in r.stderr

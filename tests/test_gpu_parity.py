@@ -668,6 +668,9 @@ def test_tile_kernel_lower_bounds_feed_the_temporal_cache(orc, mu):
     {"grid_curve": 0}, {"grid_curve": 1}, {"grid_target": 2.5}, {"nn_cell": 1}, {"nn_cell": 1, "auto_switch": 0.2}, {"nn_cell": 1, "auto_switch": 50.0}, {"nn_cell": 1, "prune_rho": 0.0},
     {"prune_rho": 3.0}, {"spec_eval": 0}, {"lin_share_p": 0}, {"tile_bounds": 0}, {"tile_bounds": 2}, {"tile_bounds": 2, "tile_mu": 0.5}, {"tile_mu": 0.005},
     {"tile_cache": 0}, {"tile_cache": 0, "list_reuse": 0}, {"tile_cache": 1, "list_reuse": 0}, {"tile_cache": 1, "tile_mu": 0.5}, {"tile_cache": 1, "auto_settle": 5.0},
+    # the matrix-pipe tile kernel (nn_mfma.hip) against the VALU one (nn_tile.hip), in every role, and its own tunables
+    {"tile_mfma": 0}, {"tile_mfma": 2}, {"tile_mfma": 2, "tile_bounds": 2}, {"tile_mfma": 0, "tile_bounds": 2}, {"tile_mfma": 2, "tile_cache": 1, "tile_mu": 0.5},
+    {"mfma_trig": 0}, {"mfma_trig": 33}, {"mfma_kacc": 4}, {"mfma_kacc": 512}, {"tile_mfma": 2, "tile_seed": 0}, {"tile_mfma": 2, "tile_waves": 6}, {"tile_mfma": 2, "tile_waves": 4},
 ])
 def test_tuning_options_never_change_results(opts):
     """Every speed knob (kernel variants, seeding, cell pruning, AUTO hand-over policy, caches) must leave the whole ICP
