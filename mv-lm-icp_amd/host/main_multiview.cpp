@@ -4,8 +4,11 @@
 // Extra flags: --rounds (20), --out DIR (write final poses as pose_<i>.txt, 4x4 row-major), --device, --copyback,
 // --keep_phantom_row (reproduce the reference's loadXYZ trailing element), --quiet, --dump_corr DIR (after the LAST round's search
 // write every Frame::neighbours[j] as corr_<src>_<j>.txt: a header line `dst weight count`, then `first second dist` rows),
-// --check_nn N (re-ask Frame::getClosestPoint for the first N correspondences of every edge and report disagreements).
+// --check_nn N (re-ask Frame::getClosestPoint for the first N correspondences of every edge and report disagreements),
+// --trace FILE (every round: one line `C round src j dst count weight-bits` per edge after the search and one line `P round frame m00 .. m33`
+// (4x4 row-major, 17 digits) per frame after the solve: the run's whole trajectory, for parity tests against a recorded one).
 #include <chrono>
+#include <cstring>
 #include <fstream>
 #include <iomanip>
 #include <iostream>
@@ -63,11 +66,21 @@ int main(int argc, char** argv) {
       std::cout << std::endl;
     }
   }
+  std::ofstream trace;
+  if (!F.s("trace", "").empty()) { trace.open(F.s("trace", "").c_str()); trace.precision(17); }
   try {
     for (int r = 0; r < rounds; ++r) {
       const auto t0 = std::chrono::steady_clock::now();
       for (auto& f : frames) f->computeClosestPointsToNeighbours(&frames, cutoff);
       const auto t1 = std::chrono::steady_clock::now();
+      if (trace.is_open())
+        for (size_t i = 0; i < frames.size(); ++i)
+          for (size_t j = 0; j < frames[i]->neighbours.size(); ++j) {
+            const OutgoingEdge& e = frames[i]->neighbours[j];
+            unsigned int bits;
+            std::memcpy(&bits, &e.weight, 4);
+            trace << "C " << r << " " << i << " " << j << " " << e.neighbourIdx << " " << e.correspondances.size() << " " << bits << "\n";
+          }
       if (r == rounds - 1 && !F.s("dump_corr", "").empty()) {
         for (size_t i = 0; i < frames.size(); ++i)
           for (size_t j = 0; j < frames[i]->neighbours.size(); ++j) {
@@ -110,6 +123,12 @@ int main(int argc, char** argv) {
       else if (angleAxis) ICP_Ceres::ceresOptimizer_ceresAngleAxis(frames, pointToPlane, robust);
       else ICP_Ceres::ceresOptimizer(frames, pointToPlane, robust);
       const auto t2 = std::chrono::steady_clock::now();
+      if (trace.is_open())
+        for (size_t i = 0; i < frames.size(); ++i) {
+          trace << "P " << r << " " << i;
+          for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) trace << " " << frames[i]->pose.m[a + 4 * b];
+          trace << "\n";
+        }
       if (!quiet)
         std::cout << "round: " << r << "  closest pts " << std::chrono::duration<double, std::milli>(t1 - t0).count() << " ms  global "
                   << std::chrono::duration<double, std::milli>(t2 - t1).count() << " ms" << std::endl;
