@@ -10,6 +10,7 @@
 
 #include "common.h"
 #include "comm.h"
+#include "nn_tie.h"
 #include "../host/se3.h"
 
 namespace mvicp {
@@ -326,11 +327,14 @@ int mvicp_destroy(mvicp_ctx* c) try {
   (void)hipStreamSynchronize(c->stream);
   comm_destroy(c);
   free_graph(c);
-  for (FrameDev& f : c->frames) { dev_free(f.pts); dev_free(f.nor); free_grid(f.grid); }
+  for (FrameDev& f : c->frames) { dev_free(f.pts); dev_free(f.nor); free_grid(f.grid); free_tie(f); }
   dev_free(c->d_split_idx); dev_free(c->d_split_d2); dev_free(c->d_scratch);
   for (auto& kv : c->tables) if (kv.second.d) (void)hipFree(kv.second.d);
   if (c->d_census) (void)hipFree(c->d_census);
   if (c->h_census) (void)hipHostFree(c->h_census);
+  if (c->d_tie_list) (void)hipFree(c->d_tie_list);
+  if (c->d_tie_count) (void)hipFree(c->d_tie_count);
+  if (c->h_tie_seen) (void)hipHostFree(c->h_tie_seen);
   if (c->d_far_list) (void)hipFree(c->d_far_list);
   if (c->d_far_count) (void)hipFree(c->d_far_count);
   for (auto& kv : c->prof) {
@@ -346,7 +350,7 @@ int mvicp_set_num_frames(mvicp_ctx* c, int n_frames) try {
   MV_CHECK(bind(c));
   if (n_frames < 0) { set_error("n_frames < 0"); return MVICP_ERR_ARG; }
   if (c->E) free_graph(c);
-  for (FrameDev& f : c->frames) { dev_free(f.pts); dev_free(f.nor); free_grid(f.grid); }
+  for (FrameDev& f : c->frames) { dev_free(f.pts); dev_free(f.nor); free_grid(f.grid); free_tie(f); }
   c->frames.assign(n_frames, FrameDev());
   c->n_frames = n_frames;
   return MVICP_OK;
@@ -358,7 +362,7 @@ int mvicp_set_frame(mvicp_ctx* c, int frame, const double* xyz, const double* nr
   if (n < 0 || (n > 0 && !xyz)) { set_error("bad cloud (n=%d)", n); return MVICP_ERR_ARG; }
   if (c->E) { set_error("set frames before mvicp_set_graph"); return MVICP_ERR_STATE; }
   FrameDev& f = c->frames[frame];
-  dev_free(f.pts); dev_free(f.nor); free_grid(f.grid);
+  dev_free(f.pts); dev_free(f.nor); free_grid(f.grid); free_tie(f);
   f.has_grid = false;
   f.n = n;
   MV_CHECK(dev_alloc(&f.pts, 3 * (size_t)n));
@@ -531,6 +535,7 @@ int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) t
     c->far_cap = cap;
   }
   MV_CHECK(warm_nn_grid(c)); MV_CHECK(warm_nn_tile(c)); MV_CHECK(warm_nn_mfma(c));
+  if (c->tie_rule) MV_CHECK(ensure_tie_trees(c, std::vector<int>(dst, dst + n_edges)));   // the reference's own trees over the targets: they decide exact distance ties
   MV_CHECK(dev_alloc(&c->d_median, E));
   MV_CHECK(dev_alloc(&c->d_chunk_edge, (size_t)c->n_chunks)); MV_CHECK(dev_alloc(&c->d_chunk_start, (size_t)c->n_chunks));
   MV_CHECK(dev_alloc(&c->d_chunk_first, E + 1));
@@ -725,6 +730,8 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   for (int e = 0; e < E && nothing_can_change; ++e)
     if (c->active[e] && !(same_edge[e] && hd[e] == 0)) nothing_can_change = false;
   c->skip_dirty_reduce = nothing_can_change;
+  // ... and the tie fix-up (nn_tie.hip) neither, if last round's search reported no tie: the same queries meet the same targets
+  c->tie_skip = nothing_can_change && c->h_tie_seen != nullptr && *c->h_tie_seen == 0u;
   // Speculative first evaluation of the solve that follows (see common.h).  Every rank decides for itself (its own last solve set
   // the flags); with N > 1 ranks the decisions are SUMMED in the "armed" slot of the one exchanged buffer and the queued blocks are
   // used only if every rank armed — a rank whose last solve failed or was skipped still takes part in the same collective (no hang).
@@ -754,6 +761,7 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   else if (method == MVICP_NN_GRID) MV_CHECK(launch_nn_grid_edges(c, bound));
   else if (method == MVICP_NN_TILE) MV_CHECK(launch_nn_tile_edges(c, bound, tile_lb, tile_cached, c->list_reuse));
   else { set_error("unknown nn_method %d", nn_method); return MVICP_ERR_ARG; }
+  c->tie_skip = false;
   // only the grid kernel and the tile kernel's BND build leave the per-query lower bounds the temporal cache needs; the cutoff must
   // not change either
   c->last_rms = -1.0;   // consumed: only a solve that follows THIS search may predict the next one
@@ -933,6 +941,8 @@ int mvicp_nn_query(mvicp_ctx* c, int frame, const double* queries, int n, int nn
   MV_CHECK(dev_alloc(&dq, 3 * (size_t)n)); MV_CHECK(dev_alloc(&di, (size_t)n)); MV_CHECK(dev_alloc(&dd, (size_t)n));
   MV_HIP(hipMemcpy(dq, queries, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice));
   int method = (nn_method == MVICP_NN_AUTO || nn_method == MVICP_NN_TILE) ? MVICP_NN_GRID : nn_method;  // raw queries are not patch-ordered
+  if (c->tie_rule) MV_CHECK(ensure_tie_trees(c, std::vector<int>(1, frame)));
+  c->tie_skip = false;
   if (method == MVICP_NN_GRID && !f.has_grid) method = MVICP_NN_BRUTE;
   int st;
   if (method == MVICP_NN_BRUTE) st = launch_nn_brute_queries(c, f, dq, n, di, dd);
@@ -975,6 +985,7 @@ int mvicp_set_option(mvicp_ctx* c, const char* name, double value) try {
   if (std::strcmp(name, "auto_settle") == 0) { c->auto_settle = value; return MVICP_OK; }
   if (std::strcmp(name, "auto_switch") == 0) { c->auto_switch = value; return MVICP_OK; }
   if (std::strcmp(name, "nn_cell") == 0) { c->nn_cell = value != 0.0; return MVICP_OK; }
+  if (std::strcmp(name, "tie_rule") == 0) { c->tie_rule = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "tile_seed") == 0) { c->tile_seed = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "tile_bounds") == 0) { c->tile_bounds = (int)value; return MVICP_OK; }
   if (std::strcmp(name, "tile_mu") == 0) { if (!(value > 0.0 && value <= 1.0)) { set_error("tile_mu outside (0, 1]"); return MVICP_ERR_ARG; } c->tile_mu = value; return MVICP_OK; }

@@ -81,6 +81,9 @@ struct FrameDev {
   GridDev grid;
   bool has_grid = false;
   double max_norm = 0.0;   // max |p| over the cloud (bounds how far a pose change can move a query)
+  // the reference's own tree over this cloud (kdvisit.h: split structure of nanoflann's buildIndex, leaf_max_size 1): decides exact distance
+  // ties the way the reference does (nn_tie.hip) and orders the k-NN lists of the normals (normals.hip); built on first use
+  void* tie_nodes = nullptr; int* tie_ord = nullptr; int* tie_slot = nullptr; double tie_box[6] = {0, 0, 0, 0, 0, 0}; bool has_tie = false;
 };
 
 struct ProfEntry {
@@ -207,6 +210,10 @@ struct mvicp_ctx {
   bool far_narrow = false;         // this grid launch expects (almost) no far queries: narrow far-kernel launch (set by mvicp_correspond)
   bool skip_dirty_reduce = false;  // set by mvicp_correspond for a search in which no list can change (see api.cpp)
   bool nn_skip_far = false;        // PROFILING ONLY: leave unresolved queries unresolved (wrong results)
+  bool tie_rule = true;            // exact distance ties are decided as nanoflann decides them (first visited; nn_tie.hip); false: lowest original index
+  unsigned long long* d_tie_list = nullptr; size_t tie_cap = 0; unsigned int* d_tie_count = nullptr; int tie_parity = 0;   // queries reported by the NN kernels
+  unsigned int* h_tie_seen = nullptr; unsigned int* d_tie_seen = nullptr;   // mapped host word: reports of the last fix-up launch (read after the round's wait)
+  bool tie_skip = false;           // set by mvicp_correspond: a search that reproduces last round's queries bit for bit after a round without any report cannot report
   bool tile_seed = true;           // tile kernel starts from last round's neighbours when there are any
   int tile_bounds = 1;             // 1: the AUTO round that would hand over to the grid kernel runs the tile kernel's BND build instead (it leaves the
                                    // temporal-cache bounds, so the grid kernel starts with cache hits one round later and the uncached grid round — the
@@ -252,6 +259,7 @@ int build_wide(FrameDev& f, const double* sorted_pts);                          
 int launch_nn_grid_queries(mvicp_ctx* c, const FrameDev& f, const double* d_q, int n, int* d_idx, double* d_d2);
 int build_grid(mvicp_ctx* c, FrameDev& f, const double* h_xyz);
 void free_grid(GridDev& g);
+void free_tie(FrameDev& f);                                                            // nn_tie.hip
 int launch_compact(mvicp_ctx* c, double d2_bound);                                    // corr.hip
 int launch_gather_stream(mvicp_ctx* c);
 int launch_select_median(mvicp_ctx* c);

@@ -5,7 +5,8 @@
 // Frame::computeClosestPointsToNeighbours (frame.cpp:117-118,131,136).  Bit-exact contract: the
 // distance is the expression of include/frame.h:70-76 evaluated in fp64, left to right, WITHOUT fma
 // contraction (this TU is built with -ffp-contract=off and uses __dmul_rn/__dadd_rn/__dsub_rn), and
-// the winner is the lowest index among equal distances (strict '<' over an ascending scan).
+// the winner is the lowest index among equal distances (strict '<' over an ascending scan); a query whose best distance was met more
+// than once is REPORTED (nn_tie.h) and re-answered the way the reference's tree decides such ties.
 //
 // Mapping (wave64, gfx950): one thread owns QPT queries in registers; the target cloud streams through
 // LDS in SoA tiles of TS points (3 x TS x 8 B); every lane reads the same LDS address per candidate
@@ -13,6 +14,9 @@
 // alone cannot fill 256 CUs the target range is split across gridDim.y and merged by a second kernel
 // (ascending split order + strict '<' keeps the lowest-index rule).
 #include "common.h"
+#include <cstring>
+
+#include "nn_tie.h"
 
 namespace mvicp {
 
@@ -29,6 +33,7 @@ struct BruteJob {
   int n, m;
   int* out_idx; double* out_d2;  // final outputs (n)
   const int* inv;                // target original index -> sorted position (null: emit original indices)
+  TieRef tie;
 };
 
 __device__ __forceinline__ void xf_point(const double* __restrict__ x, double p0, double p1, double p2, double& q0, double& q1, double& q2) {
@@ -57,11 +62,12 @@ __global__ __launch_bounds__(NT) void nn_brute_kernel(const BruteJob* __restrict
 
   double qx[QPT], qy[QPT], qz[QPT], best[QPT];
   int bi[QPT];
+  bool tie[QPT];   // the running best distance was met by a second target
 #pragma unroll
   for (int i = 0; i < QPT; ++i) {
     const int k = qbase + i * NT + tid;
     best[i] = 1.7976931348623157e308;
-    bi[i] = -1;
+    bi[i] = -1; tie[i] = false;
     if (k < job.n) {
       const double p0 = job.q[3 * (size_t)k], p1 = job.q[3 * (size_t)k + 1], p2 = job.q[3 * (size_t)k + 2];
       if (job.xf != nullptr) xf_point(sxf, p0, p1, p2, qx[i], qy[i], qz[i]);
@@ -94,7 +100,8 @@ __global__ __launch_bounds__(NT) void nn_brute_kernel(const BruteJob* __restrict
       for (int i = 0; i < QPT; ++i) {
         const double d0 = __dsub_rn(qx[i], x), d1 = __dsub_rn(qy[i], y), d2 = __dsub_rn(qz[i], z);
         const double d = __dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2));
-        if (d < best[i]) { best[i] = d; bi[i] = base + j; }
+        if (d < best[i]) { best[i] = d; bi[i] = base + j; tie[i] = false; }
+        else if (d == best[i]) tie[i] = true;
       }
     }
   }
@@ -105,9 +112,10 @@ __global__ __launch_bounds__(NT) void nn_brute_kernel(const BruteJob* __restrict
     if (n_splits == 1) {
       job.out_idx[k] = (bi[i] >= 0 && job.inv) ? job.inv[bi[i]] : bi[i];
       job.out_d2[k] = best[i];
+      if (tie[i] && bi[i] >= 0) tie_report(job.tie, (unsigned int)k);
     } else {
       const size_t o = (size_t)split_off[blockIdx.z] + (size_t)blockIdx.y * job.n + k;
-      split_idx[o] = bi[i];
+      split_idx[o] = bi[i] < 0 ? -1 : (bi[i] | (tie[i] ? 0x40000000 : 0));   // (bit 30: tie inside this split; clouds hold < 2^30 points)
       split_d2[o] = best[i];
     }
   }
@@ -120,18 +128,36 @@ __global__ __launch_bounds__(NT) void nn_brute_merge_kernel(const BruteJob* __re
   if (k >= job.n) return;
   double best = 1.7976931348623157e308;
   int bi = -1;
+  bool tie = false;
   for (int s = 0; s < n_splits; ++s) {
     const size_t o = (size_t)split_off[blockIdx.y] + (size_t)s * job.n + k;
     const double d = split_d2[o];
     const int i = split_idx[o];
-    if (i >= 0 && d < best) { best = d; bi = i; }
+    if (i < 0) continue;
+    if (d < best) { best = d; bi = i & 0x3fffffff; tie = (i & 0x40000000) != 0; }
+    else if (d == best) tie = true;
   }
   job.out_idx[k] = (bi >= 0 && job.inv) ? job.inv[bi] : bi;
   job.out_d2[k] = best;
+  if (tie && bi >= 0) tie_report(job.tie, (unsigned int)k);
 }
 
-int run_jobs(mvicp_ctx* c, const std::vector<BruteJob>& jobs, double* pairs_out) {
+int run_jobs(mvicp_ctx* c, std::vector<BruteJob>& jobs, double* pairs_out, const FrameDev* const* dst_of) {
   if (jobs.empty()) return MVICP_OK;
+  std::vector<TieJob> ties;
+  {
+    double launch_q = 0;
+    for (const BruteJob& j : jobs) launch_q += j.n;
+    const TieRef tref = tie_ref(c, (size_t)launch_q, 0u);
+    for (size_t k = 0; k < jobs.size(); ++k) {
+      jobs[k].tie = tref; jobs[k].tie.job = (unsigned int)k;
+      TieJob t;
+      std::memset(&t, 0, sizeof(t));
+      tie_job_fill(*dst_of[k], t);
+      t.q = jobs[k].q; t.xf = jobs[k].xf; t.n = jobs[k].n; t.out_idx = jobs[k].out_idx; t.out_d2 = jobs[k].out_d2; t.inv = jobs[k].inv;
+      ties.push_back(t);
+    }
+  }
   int max_n = 0;
   double pairs = 0;
   for (const BruteJob& j : jobs) { max_n = std::max(max_n, j.n); pairs += (double)j.n * j.m; }
@@ -168,6 +194,7 @@ int run_jobs(mvicp_ctx* c, const std::vector<BruteJob>& jobs, double* pairs_out)
   }
   MV_HIP(hipGetLastError());
   if (pairs_out) *pairs_out = pairs;
+  MV_CHECK(launch_tie_fixup(c, ties, 1.7976931348623157e308));   // (the brute path maintains no list)
   return MVICP_OK;
 }
 
@@ -175,6 +202,7 @@ int run_jobs(mvicp_ctx* c, const std::vector<BruteJob>& jobs, double* pairs_out)
 
 int launch_nn_brute_edges(mvicp_ctx* c) {
   std::vector<BruteJob> jobs;
+  std::vector<const FrameDev*> dsts;
   for (int e = 0; e < c->E; ++e) {
     if (!c->active[e]) continue;
     const FrameDev& s = c->frames[c->esrc[e]];
@@ -184,16 +212,17 @@ int launch_nn_brute_edges(mvicp_ctx* c) {
     j.q = s.grid.spts; j.xf = c->d_xf + (size_t)e * kEdgeXf; j.tgt = d.pts; j.n = s.n; j.m = d.n;
     j.inv = d.grid.inv;
     j.out_idx = c->d_nn_idx + c->cap_off[e]; j.out_d2 = c->d_nn_d2 + c->cap_off[e];
-    jobs.push_back(j);
+    jobs.push_back(j); dsts.push_back(&d);
   }
-  return run_jobs(c, jobs, nullptr);
+  return run_jobs(c, jobs, nullptr, dsts.data());
 }
 
 int launch_nn_brute_queries(mvicp_ctx* c, const FrameDev& f, const double* d_q, int n, int* d_idx, double* d_d2) {
   std::vector<BruteJob> jobs(1);
   jobs[0].q = d_q; jobs[0].xf = nullptr; jobs[0].tgt = f.pts; jobs[0].n = n; jobs[0].m = f.n;
   jobs[0].out_idx = d_idx; jobs[0].out_d2 = d_d2; jobs[0].inv = nullptr;
-  return run_jobs(c, jobs, nullptr);
+  const FrameDev* dst = &f;
+  return run_jobs(c, jobs, nullptr, &dst);
 }
 
 }  // namespace mvicp

@@ -37,6 +37,7 @@
 
 #include "common.h"
 #include "nn_list.h"
+#include "nn_tie.h"
 
 namespace mvicp {
 
@@ -71,6 +72,7 @@ struct GridJob {
   double* stream; long long total_cap; const double* dst_nor;   // the edge's slice of the packed operand stream (linearize.hip) + sorted dst normals
   float* out_lb;       // per query: lower bound on the distance to every target other than out_idx, fp32 ROUNDED DOWN (null: no cache)
   int seed;            // out_idx still holds last round's neighbours (from any kernel): a starting candidate for far queries
+  TieRef tie;          // where queries whose best distance was met by more than one target are reported (nn_tie.h)
 };
 
 __host__ __device__ __forceinline__ unsigned long long cell_key(int ix, int iy, int iz) {
@@ -300,6 +302,7 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
   // every other target is either a scanned candidate (>= second) or outside the block (>= m)
   if (job.out_lb != nullptr) job.out_lb[out] = resolved ? __double2float_rd(sqrt(fmin(fmin(second, m2), skipped)) * (1.0 - 1e-12)) : 0.f;
   if (job.dirty && (resolved || skip_far)) update_list(job, i, bi == 0x7fffffff ? -1 : job.inv[bi], best, bound);
+  if (resolved && bi != 0x7fffffff && second == best) tie_report(job.tie, (unsigned int)i);   // another target at exactly the same distance
   if (!resolved && !skip_far) {
     // wave-aggregated append: one atomic per wave
     const unsigned long long mask = __ballot(1);
@@ -759,6 +762,7 @@ __global__ __launch_bounds__(NT) void nn_far_kernel(const GridJob* __restrict__ 
       // every other target was scanned (>= second) or sits in a skipped box (>= its lower bound)
       if (job.out_lb != nullptr) job.out_lb[out] = bi == 0x7fffffff ? 0.f : __double2float_rd(sqrt(fmin(second, pruned)) * (1.0 - 1e-12));
       if (job.dirty) update_list(job, i, bi == 0x7fffffff ? -1 : job.inv[bi], best, bound);
+      if (bi != 0x7fffffff && second == best) tie_report(job.tie, (unsigned int)i);
     }
   }
   if (stats) {
@@ -1114,8 +1118,24 @@ GridView view_of(const FrameDev& f) {
   return v;
 }
 
-int run(mvicp_ctx* c, const std::vector<GridJob>& jobs, double bound) {
+int run(mvicp_ctx* c, std::vector<GridJob>& jobs, double bound, const FrameDev* const* dst_of) {
   if (jobs.empty()) return MVICP_OK;
+  std::vector<TieJob> ties;
+  {
+    double launch_q = 0;
+    for (const GridJob& j : jobs) launch_q += j.n;
+    const TieRef tref = tie_ref(c, (size_t)launch_q, 0u);
+    for (size_t k = 0; k < jobs.size(); ++k) {
+      GridJob& j = jobs[k];
+      j.tie = tref; j.tie.job = (unsigned int)k;
+      TieJob t;
+      std::memset(&t, 0, sizeof(t));
+      tie_job_fill(*dst_of[k], t);
+      t.q = j.q; t.xf = j.xf; t.n = j.n; t.out_idx = j.out_idx; t.out_d2 = j.out_d2; t.inv = j.inv;
+      t.list = ListRef{j.qpos, j.second, j.cd2, j.dirty, j.dirty_slots, j.stream, j.total_cap, j.dst_nor, j.dst.srec};
+      ties.push_back(t);
+    }
+  }
   int max_n = 0;
   double nq = 0;
   for (const GridJob& j : jobs) { max_n = std::max(max_n, j.n); nq += j.n; }
@@ -1189,6 +1209,7 @@ int run(mvicp_ctx* c, const std::vector<GridJob>& jobs, double bound) {
     MV_HIP(hipMemcpyAsync(c->h_census, d_stats + 8 * slots, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     c->census_pending = true; c->census_nq = nq; c->census_kind = c->nn_tree_only ? 1 : (use_cell ? 3 : 0); c->census_scope = "nn_grid";
   }
+  MV_CHECK(launch_tie_fixup(c, ties, bound));   // exact distance ties: the reference's own descent decides (nn_tie.hip)
   return MVICP_OK;
 }
 }  // namespace
@@ -1217,6 +1238,7 @@ int warm_nn_grid(mvicp_ctx* c) {
 
 int launch_nn_grid_edges(mvicp_ctx* c, double d2_bound) {
   std::vector<GridJob> jobs;
+  std::vector<const FrameDev*> dsts;
   for (int e = 0; e < c->E; ++e) {
     if (!c->active[e]) continue;
     const FrameDev& s = c->frames[c->esrc[e]];
@@ -1232,21 +1254,23 @@ int launch_nn_grid_edges(mvicp_ctx* c, double d2_bound) {
     j.stream = c->d_stream + c->cap_off[e]; j.total_cap = c->total_cap; j.dst_nor = d.grid.snor;
     j.dirty_slots = c->d_dirty_slots + c->dslot_off[e];
     j.seed = ((int)c->nn_cache_edge.size() == c->E && c->nn_cache_edge[e]) ? 1 : 0;
-    jobs.push_back(j);
+    jobs.push_back(j); dsts.push_back(&d);
   }
-  return run(c, jobs, d2_bound);
+  return run(c, jobs, d2_bound, dsts.data());
 }
 
 int launch_nn_grid_queries(mvicp_ctx* c, const FrameDev& f, const double* d_q, int n, int* d_idx, double* d_d2) {
   if (!f.has_grid) { set_error("grid NN structure missing"); return MVICP_ERR_STATE; }
   std::vector<GridJob> jobs(1);
+  std::memset(&jobs[0], 0, sizeof(GridJob));
   jobs[0].dst = view_of(f);
   jobs[0].q = d_q; jobs[0].qidx = nullptr; jobs[0].xf = nullptr; jobs[0].n = n;
   jobs[0].out_idx = d_idx; jobs[0].out_d2 = d_d2;
   jobs[0].inv = nullptr; jobs[0].out_lb = nullptr;
   jobs[0].qpos = nullptr; jobs[0].second = nullptr; jobs[0].cd2 = nullptr; jobs[0].dirty = nullptr; jobs[0].dirty_slots = nullptr;
   jobs[0].stream = nullptr; jobs[0].total_cap = 0; jobs[0].dst_nor = nullptr;
-  return run(c, jobs, 1.7976931348623157e308);
+  const FrameDev* dst = &f;
+  return run(c, jobs, 1.7976931348623157e308, &dst);
 }
 
 }  // namespace mvicp

@@ -42,6 +42,7 @@ struct LaneM {         // per-lane query state
   int bi;                // original index of the running best (0x7fffffff: none)
   int bpos;              // its sorted position (-1: none)
   bool active;
+  bool tie;              // some target other than the running best was met at exactly the running best's distance (reported: nn_tie.h)
   double second;         // BND builds only: smallest exact d2 among the fp64-evaluated targets other than the running best
   // block-local (valid while the wave scans one block)
   float a2, amax, dab;   // |a~|^2, max |alpha coordinate|, delta_a + delta_b (all in the block's scaled units)
@@ -168,15 +169,18 @@ __device__ __forceinline__ bool confirm(const TileView& g, int tile, LaneM& L, u
         const double d0 = __dsub_rn(L.qx, u.x), d1 = __dsub_rn(L.qy, u.y), d2 = __dsub_rn(L.qz, v.x);
         const double d = __dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2));
         const int oi = (int)__double_as_longlong(v.y);
-        if (BND) {
-          if (d < L.best || (d == L.best && oi < L.bi)) {
-            L.second = fmin(L.second, L.best);   // the old best (or the cutoff bound: only lowers the bound) is now "another target"
-            L.best = d; L.bi = oi; L.bpos = k; changed = true;
-          } else if (oi != L.bi) {
-            L.second = fmin(L.second, d);
+        // strictly nearer: the new best.  EXACTLY as near as the best (rare): the lower original index keeps the place for now and the query
+        // is reported, so that nn_tie.hip lets the reference's own tree decide (nanoflann keeps the target it visits first)
+        if (d < L.best) {
+          if (BND) L.second = fmin(L.second, L.best);   // the old best (or the cutoff bound: only lowers the bound) is now "another target"
+          L.best = d; L.bi = oi; L.bpos = k; changed = true;
+        } else if (d == L.best) {
+          if (oi != L.bi) {
+            if (BND) L.second = fmin(L.second, d); else L.tie = true;   // (BND builds read the tie off second == best at the end)
+            if (oi < L.bi) { L.bi = oi; L.bpos = k; changed = true; }
           }
-        } else if (d <= L.best) {
-          if (d < L.best || oi < L.bi) { L.best = d; L.bi = oi; L.bpos = k; changed = true; }
+        } else if (BND) {
+          L.second = fmin(L.second, d);
         }
       }
     }
@@ -394,7 +398,7 @@ __global__ __launch_bounds__(NT, WPE) void nn_mfma_kernel(const TileJob* __restr
 
   LaneM L;
   L.active = i < job.n;
-  L.best = bound; L.bi = 0x7fffffff; L.bpos = -1;
+  L.best = bound; L.bi = 0x7fffffff; L.bpos = -1; L.tie = false;
   L.second = 1.7976931348623157e308;
   L.qx = L.qy = L.qz = 0.0;
   L.a2 = 0.f; L.amax = 0.f; L.dab = 0.f; L.inrange = false;
@@ -488,6 +492,7 @@ __global__ __launch_bounds__(NT, WPE) void nn_mfma_kernel(const TileJob* __restr
     // fp64 roundings of this line.  No neighbour inside the cutoff: 0 forces a full search next round, like the grid kernel does.
     if (BND) job.out_lb[out] = L.bpos < 0 ? 0.f : __double2float_rd(fmin(sqrt(L.second), sqrt(L.best) + (double)G.mu) * (1.0 - 1e-9));
     if (job.list.dirty) update_list_entry(job.list, i, L.bpos, L.best, bound, false);
+    if ((BND ? L.second == L.best : L.tie) && L.bpos >= 0) tie_report(job.tie, (unsigned int)i);
   }
   if (CEN && stats && (threadIdx.x & 63) == 0) {
     const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + wave;
@@ -602,7 +607,8 @@ int launch_nn_mfma_edges(mvicp_ctx* c, double d2_bound, bool with_bounds, bool w
   std::vector<TileJob> jobs;
   int max_n = 0;
   double nq = 0;
-  MV_CHECK(build_tile_jobs(c, with_bounds, with_cache, with_list, jobs, max_n, nq));
+  std::vector<TieJob> ties;
+  MV_CHECK(build_tile_jobs(c, with_bounds, with_cache, with_list, jobs, max_n, nq, ties));
   if (jobs.empty() || max_n == 0) return MVICP_OK;
   TileJob* d_jobs = nullptr;
   MV_CHECK(cached_upload(c, jobs[0].xf ? "tile_jobs" : "tile_jobs_raw", jobs.data(), sizeof(TileJob) * jobs.size(), (void**)&d_jobs));
@@ -628,6 +634,7 @@ int launch_nn_mfma_edges(mvicp_ctx* c, double d2_bound, bool with_bounds, bool w
 #undef MVICP_MFMA_K
   }
   MV_HIP(hipGetLastError());
+  MV_CHECK(launch_tie_fixup(c, ties, d2_bound));     // exact distance ties: the reference's own descent decides (nn_tie.hip); before the lists are read
   if (with_list) MV_CHECK(launch_dirty_reduce(c));   // per-edge OR of the "list membership changed" slots
   if (d_stats) MV_CHECK(census_collect(c, d_stats, slots, nq, "nn_mfma"));
   return MVICP_OK;

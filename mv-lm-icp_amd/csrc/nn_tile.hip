@@ -49,6 +49,7 @@ struct Lane {          // per-lane query state
   float thr;             // fp32 screen threshold, always >= (sqrt(best) + slack + mu)^2 (see leaf_scan; mu = 0 unless BND)
   int bi;
   bool active;
+  bool tie;              // another target met at exactly the running best's distance (nn_tie.h)
   double second;         // BND builds only: smallest exact d2 among the fp64-evaluated targets other than the running best
 };
 struct Group {         // wave-uniform patch description
@@ -135,23 +136,21 @@ __device__ __forceinline__ void leaf_scan(const TileView& g, int leaf, Lane& L, 
         if (h[j] && k < cnt) {
           const double d0 = __dsub_rn(L.qx, T->x[k]), d1 = __dsub_rn(L.qy, T->y[k]), d2 = __dsub_rn(L.qz, T->z[k]);
           const double d = __dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2));
-          if (BND) {
+          // strictly nearer: the new best.  EXACTLY as near (rare): the lower original index keeps the place and the query is reported —
+          // nn_tie.hip then lets the reference's own tree decide (nanoflann keeps the target it visits first)
+          if (d < L.best) {
+            if (BND) L.second = fmin(L.second, L.best);   // the old best (or the cutoff bound: only lowers the bound) is now "another target"
+            L.best = d; L.bi = T->id[k];
+            const float r = __builtin_amdgcn_sqrtf(d32[j]) * 1.000001f + 2.f * slack + (BND ? mu : 0.f);
+            thr = fminf(thr, r * r * 1.000002f);
+          } else if (d == L.best) {
             const int oi = T->id[k];
-            if (d < L.best || (d == L.best && oi < L.bi)) {
-              L.second = fmin(L.second, L.best);   // the old best (or the cutoff bound: only lowers the bound) is now "another target"
-              L.best = d; L.bi = oi;
-              const float r = __builtin_amdgcn_sqrtf(d32[j]) * 1.000001f + 2.f * slack + mu;
-              thr = fminf(thr, r * r * 1.000002f);
-            } else if (oi != L.bi) {               // (the running best itself comes by again when its tile is scanned after a seed)
-              L.second = fmin(L.second, d);
+            if (oi != L.bi) {                        // (the running best itself comes by again when its tile is scanned after a seed)
+              if (BND) L.second = fmin(L.second, d); else L.tie = true;   // (BND builds read the tie off second == best at the end)
+              if (oi < L.bi) L.bi = oi;
             }
-          } else if (d <= L.best) {
-            const int oi = T->id[k];
-            if (d < L.best || oi < L.bi) {
-              L.best = d; L.bi = oi;
-              const float r = __builtin_amdgcn_sqrtf(d32[j]) * 1.000001f + 2.f * slack;
-              thr = fminf(thr, r * r * 1.000002f);
-            }
+          } else if (BND) {
+            L.second = fmin(L.second, d);
           }
         }
       }
@@ -254,7 +253,7 @@ __global__ __launch_bounds__(NT, WPE) void nn_tile_kernel(const TileJob* __restr
 
   Lane L;
   L.active = i < job.n;
-  L.best = bound; L.bi = 0x7fffffff;
+  L.best = bound; L.bi = 0x7fffffff; L.tie = false;
   L.second = 1.7976931348623157e308;
   L.qx = L.qy = L.qz = 0.0;
   double p0 = 0.0, p1 = 0.0, p2 = 0.0;
@@ -354,6 +353,7 @@ __global__ __launch_bounds__(NT, WPE) void nn_tile_kernel(const TileJob* __restr
     // keeps its acceptance patches its own entry and operands, so compaction + gather only run for edges whose MEMBERSHIP changed —
     // also in the plain seeded rounds, where nearly every neighbour changes but hardly any acceptance does (round 3)
     if (job.list.dirty) update_list_entry(job.list, i, L.bi == 0x7fffffff ? -1 : job.inv[L.bi], L.best, bound, false);
+    if ((BND ? L.second == L.best : L.tie) && L.bi != 0x7fffffff) tie_report(job.tie, (unsigned int)i);
   }
   if (stats && (threadIdx.x & 63) == 0) {
     // wave-uniform counters: candidates examined PER LANE x active lanes, boxes tested per wave
@@ -431,7 +431,8 @@ int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound, bool with_bounds, bool w
   std::vector<TileJob> jobs;
   int max_n = 0;
   double nq = 0;
-  MV_CHECK(build_tile_jobs(c, with_bounds, with_cache, with_list, jobs, max_n, nq));
+  std::vector<TieJob> ties;
+  MV_CHECK(build_tile_jobs(c, with_bounds, with_cache, with_list, jobs, max_n, nq, ties));
   if (jobs.empty() || max_n == 0) return MVICP_OK;
   TileJob* d_jobs = nullptr;
   MV_CHECK(cached_upload(c, jobs[0].xf ? "tile_jobs" : "tile_jobs_raw", jobs.data(), sizeof(TileJob) * jobs.size(), (void**)&d_jobs));
@@ -458,6 +459,7 @@ int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound, bool with_bounds, bool w
 #undef MVICP_TILE_K
   }
   MV_HIP(hipGetLastError());
+  MV_CHECK(launch_tie_fixup(c, ties, d2_bound));     // exact distance ties: the reference's own descent decides (nn_tie.hip); before the lists are read
   if (with_list) MV_CHECK(launch_dirty_reduce(c));   // per-edge OR of the "list membership changed" slots
   if (d_stats) MV_CHECK(census_collect(c, d_stats, slots, nq, "nn_tile"));
   return MVICP_OK;

@@ -11,6 +11,7 @@
 
 #include "common.h"
 #include "nn_list.h"
+#include "nn_tie.h"
 
 namespace mvicp {
 
@@ -51,6 +52,7 @@ struct TileJob {
   int cache;
   ListRef list;
   float kacc; int trig;   // nn_mfma.hip tunables (ctx::mfma_kacc, mfma_trig)
+  TieRef tie;             // where lanes whose best distance was met by more than one target report (nn_tie.h)
 };
 
 __device__ __forceinline__ void xf_point(const double* __restrict__ x, double p0, double p1, double p2, double& q0, double& q1, double& q2) {
@@ -140,8 +142,11 @@ TileView view_of(const FrameDev& f) {
 }
 
 // the per-edge job table of a launch (one TileJob per active edge of this rank)
-inline int build_tile_jobs(mvicp_ctx* c, bool with_bounds, bool with_cache, bool with_list, std::vector<TileJob>& jobs, int& max_n, double& nq) {
+inline int build_tile_jobs(mvicp_ctx* c, bool with_bounds, bool with_cache, bool with_list, std::vector<TileJob>& jobs, int& max_n, double& nq, std::vector<TieJob>& ties) {
   max_n = 0; nq = 0;
+  double launch_q = 0;
+  for (int e = 0; e < c->E; ++e) if (c->active[e]) launch_q += c->frames[c->esrc[e]].n;
+  const TieRef tref = tie_ref(c, (size_t)launch_q, 0u);
   for (int e = 0; e < c->E; ++e) {
     if (!c->active[e]) continue;
     const FrameDev& s = c->frames[c->esrc[e]];
@@ -161,6 +166,14 @@ inline int build_tile_jobs(mvicp_ctx* c, bool with_bounds, bool with_cache, bool
                        c->d_stream + c->cap_off[e], c->total_cap, d.grid.snor, (const PointRec*)d.grid.srec};
     }
     j.kacc = (float)c->mfma_kacc; j.trig = c->mfma_trig;
+    j.tie = tref; j.tie.job = (unsigned int)jobs.size();
+    {
+      TieJob t;
+      std::memset(&t, 0, sizeof(t));
+      tie_job_fill(d, t);
+      t.q = j.q; t.xf = j.xf; t.n = j.n; t.out_idx = j.out_idx; t.out_d2 = j.out_d2; t.inv = j.inv; t.list = j.list;
+      ties.push_back(t);
+    }
     jobs.push_back(j);
     max_n = std::max(max_n, s.n);
     nq += s.n;

@@ -70,16 +70,65 @@ def test_nn_edge_cases(eng, orc, method):
         eng.nn_query(0, q[:5], method)
 
 
-def test_duplicate_targets_pick_lowest_index(eng, orc):
+def test_duplicate_targets_follow_nanoflanns_visit_order(eng, orc, refnn):
+    """Exact distance ties (duplicated target points): the reference keeps the target its tree VISITS first (nanoflann.hpp:1205-1212,
+    1222-1233), which depends on the query — neither the lowest nor the highest index.  Every kernel must return what the REAL
+    nanoflann (oracle/_ref) returns; with the rule switched off ("tie_rule" 0) they return the lowest index, like the oracle's scan."""
+    assert refnn is not None, "oracle/_ref (real nanoflann) was not built"
     rng = np.random.default_rng(4)
     dst = rng.uniform(-0.1, 0.1, (600, 3))
-    dst[300:] = dst[:300]  # exact duplicates: lowest index must win in every kernel
+    dst[300:] = dst[:300][rng.permutation(300)]  # every point exists twice, at unrelated indices
     eng.set_frames([dst], None)
-    q = dst[:300] + 1e-4
+    q = np.vstack([dst[:300] + 1e-4, dst[100:200], rng.uniform(-0.1, 0.1, (50, 3))])   # near a pair, exactly on a pair (d2 = 0 twice), generic
+    ri, rd = refnn.query(dst, q)
+    oi, od = orc.nn_brute(dst, q)
+    assert np.array_equal(rd, od) and not np.array_equal(ri, oi), "the data must make the two tie rules disagree"
     for m in METHODS:
         idx, d2 = eng.nn_query(0, q, m)
-        oi, od = orc.nn_brute(dst, q)
-        assert np.array_equal(idx, oi) and np.array_equal(d2, od) and idx.max() < 300
+        assert np.array_equal(d2, rd) and np.array_equal(idx, ri), (m, int((idx != ri).sum()))
+    eng.set_option("tie_rule", 0)
+    try:
+        for m in METHODS:
+            idx, d2 = eng.nn_query(0, q, m)
+            assert np.array_equal(idx, oi) and np.array_equal(d2, od)
+    finally:
+        eng.set_option("tie_rule", 1)
+
+
+@pytest.mark.parametrize("opts", [{}, {"tile_mfma": 0}, {"tile_mfma": 2, "tile_bounds": 2}, {"nn_cache": 0}])
+@pytest.mark.parametrize("method", [L.NN_BRUTE, L.NN_GRID, L.NN_TILE, L.NN_AUTO])
+def test_duplicate_targets_through_the_correspondence_path(refnn, orc, method, opts):
+    """The same on the edge path, round after round (seeded, bounds-leaving and cache-aware rounds included): the `second` index of every
+    correspondence is the real nanoflann's, the lists / weights / poses follow the reference-equivalent CPU path."""
+    import cpupath
+    assert refnn is not None
+    pb = synth.make_problem(3, 3000)
+    rng = np.random.default_rng(11)
+    pts = [p.copy() for p in pb["pts"]]; nor = [n.copy() for n in pb["nor"]]
+    for k in range(3):   # a third of every cloud exists twice
+        pick = rng.choice(len(pts[k]), len(pts[k]) // 3, replace=False)
+        pts[k] = np.vstack([pts[k], pts[k][pick]]); nor[k] = np.vstack([nor[k], nor[k][pick]])
+    e = mvicp.Engine(0)
+    for k, v in opts.items():
+        e.set_option(k, v)
+    e.set_frames(pts, nor); e.set_graph(pb["src"], pb["dst"])
+    cpu = cpupath.CpuPath(pts, nor, pb["src"], pb["dst"], pb["fixed"], 2, 1, orc=orc, ref=refnn)
+    poses = pb["init"].copy()
+    disagreements = 0
+    for r in range(7):
+        c, w = e.correspond(poses, pb["fixed"], 0.05, method)
+        corr = cpu.correspond(poses)
+        for k in range(e.E):
+            gf, gs, gd = e.get_correspondences(k)
+            f, s2, d, wk = corr[k]
+            assert np.array_equal(gf, f) and np.array_equal(gd, d) and (len(f) == 0 or w[k] == wk), (r, k)
+            assert np.array_equal(gs, s2), (r, k, int((gs != s2).sum()))
+            if len(f):
+                lo = orc.correspond_edge(pts[pb["src"][k]], poses[pb["src"][k]], pts[pb["dst"][k]], poses[pb["dst"][k]], 0.05)[1]
+                disagreements += int((lo != s2).sum())
+        poses, sm = e.optimize(poses, pb["fixed"], L.PARAM_SOPHUS_SE3, 1, True, 50)
+    assert disagreements > 0, "the data must make the two tie rules disagree somewhere"
+    cpu.close(); e.close()
 
 
 # ---------------------------------------------------------------- S1 / correspond
