@@ -39,7 +39,12 @@ WORKLOADS = {
     "cfg5": (64, 1_000_000, 1, 2, "cfg5: multiview 64 views x 1M pts, point-to-plane, SophusSE3 (E=126)"),
     "shard8": (5, 200_000, 1, 2, "shard8: 5 views x 200k pts (E=8): the per-rank share of cfg4 on 8 GPUs, for fixed-cost analysis"),
     "shard8_cfg5": (9, 1_000_000, 1, 2, "shard8_cfg5: 9 views x 1M pts (E=16): the per-rank share of cfg5 on 8 GPUs, for fixed-cost analysis"),
+    # NOT a BASELINE config: cfg4's shape with views that only partly overlap (20-degree cones: a third of a view's points has no counterpart in
+    # a ring neighbour) and a cutoff (5 mm) well inside the non-overlap band, so the filter of frame.cpp:156-160 rejects ~1/3 of the queries
+    # and the membership of every list changes while the poses move (compaction + gather every moving round, no shared source operands)
+    "cfg4_partial": (32, 200_000, 1, 2, "cfg4_partial: 32 views x 200k pts, 20-degree views (partial overlap), cutoff 5 mm, point-to-plane, SophusSE3 (E=62)"),
 }
+WORKLOAD_EXTRAS = {"cfg4_partial": {"cone_deg": 20.0, "sigma": 0.004, "sigmat": 0.002, "cutoff": 0.005}}
 ROUNDS_PER_REGISTRATION = 20   # main_multiview.cpp:150
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
 PROFILE_ROUND = "r04"
@@ -59,7 +64,7 @@ def source_sha16():
     return h.hexdigest()[:16]
 
 
-def cpu_reference_legs(pb, plane, param, gpu_poses_after, gpu_iters, window_rounds, moved_by_round, cpu_rounds):
+def cpu_reference_legs(pb, plane, param, gpu_poses_after, gpu_iters, window_rounds, moved_by_round, cpu_rounds, cutoff=0.05):
     """The two CPU legs of the line, both on tests/cpupath.py = the reference-equivalent CPU path (real vendored nanoflann from
     oracle/_ref + the oracle's Jet/autodiff restatement of Ceres; Ceres itself is not installed).  Run AFTER the timed region.
 
@@ -81,7 +86,7 @@ def cpu_reference_legs(pb, plane, param, gpu_poses_after, gpu_iters, window_roun
     per_round = []
     fast = cpupath.fast_build_usable()
     # ---- (1) all edges, every usable core
-    cp = cpupath.CpuPath(pb["pts"], pb["nor"], pb["src"], pb["dst"], pb["fixed"], param, plane, fast=fast, threads=ncores)
+    cp = cpupath.CpuPath(pb["pts"], pb["nor"], pb["src"], pb["dst"], pb["fixed"], param, plane, cutoff=cutoff, fast=fast, threads=ncores)
     P = pb["init"].copy()
     dev_t, dev_r = [], []
     for r in range(cpu_rounds):
@@ -125,7 +130,7 @@ def cpu_reference_legs(pb, plane, param, gpu_poses_after, gpu_iters, window_roun
     r_fix = last_fixed["round"]
     starts = {"moving": (r_mov, pb["init"] if r_mov == 1 else gpu_poses_after[r_mov - 2]), "fixed_point": (r_fix, pb["init"] if r_fix == 1 else gpu_poses_after[r_fix - 2])}
     for name, use_fast in (("O2_1thread", False),) + ((("O3_avx2_1thread", True),) if fast else ()):
-        c1 = cpupath.CpuPath(pb["pts"][:Ks], pb["nor"][:Ks], pb["src"][keep], pb["dst"][keep], pb["fixed"][:Ks], param, plane, fast=use_fast, threads=1)
+        c1 = cpupath.CpuPath(pb["pts"][:Ks], pb["nor"][:Ks], pb["src"][keep], pb["dst"][keep], pb["fixed"][:Ks], param, plane, cutoff=cutoff, fast=use_fast, threads=1)
         c1.correspond(np.ascontiguousarray(pb["init"][:Ks]))   # build the trees outside the timed rounds
         kinds = {}
         for kind, (r, P0) in starts.items():
@@ -225,7 +230,9 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     K, N, plane, param, desc = WORKLOADS[args.workload]
-    pb = synth.make_problem(K, N)
+    extra = dict(WORKLOAD_EXTRAS.get(args.workload, {}))
+    cutoff = extra.pop("cutoff", 0.05)
+    pb = synth.make_problem(K, N, **extra)
     eng = mvicp.Engine(local, rank, world)
     if args.grid_target:
         eng.set_option("grid_target", args.grid_target)
@@ -277,7 +284,7 @@ def main():
     np.copyto(Pc, init_c)
     raw = []                                       # per global round: (g, t_nn, t_lm, iterations, evaluations, successful_steps, corr, poses after)
     state = {"g": 0}              # global round counter (warm-up + timed): round g % 20 + 1 of registration g // 20 + 1
-    thresh32 = np.float32(0.05)
+    thresh32 = np.float32(cutoff)
 
     def step():
         g = state["g"]
@@ -487,7 +494,7 @@ def main():
             "metric": "ICP iterations/sec (NN+Jacobian+LM)", "value": args.steps / elapsed, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": desc, "views": K, "pts_per_view": N, "edges": int(eng.E), "cutoff": 0.05, "knn": 2, "robust": True,
+            "config": {"workload": desc, "views": K, "pts_per_view": N, "edges": int(eng.E), "cutoff": cutoff, "knn": 2, "robust": True,
                        "parallelism": f"edge-sharded x{world}, {exchange}" if world > 1 else "single GPU", "nn": args.nn},
             "protocol": {"rounds_per_registration": ROUNDS_PER_REGISTRATION,
                          "registrations": [{"registration": int(r), "timed_rounds": [int(min(l["round"] for l in log if l["registration"] == r)),
@@ -533,7 +540,7 @@ def main():
             try:
                 moved_by_round = [bool(np.any(poses_after[r] != (pb["init"] if r == 1 else poses_after[r - 1]))) for r in sorted(poses_after)]
                 legs = cpu_reference_legs(pb, plane, param, [poses_after[r] for r in range(1, cpu_rounds + 1)], [iters_of[r] for r in range(1, cpu_rounds + 1)],
-                                          window_rounds, moved_by_round, cpu_rounds)
+                                          window_rounds, moved_by_round, cpu_rounds, cutoff)
                 out.update(legs)
                 out["speedup_vs_cpu_baseline"] = {"value": out["value"] / out["cpu_baseline"]["value"],
                                                   "vs_all_cores": out["value"] / [v for k, v in out["cpu_baseline"]["variants"].items() if "allcores" in k or "threadpool" in k][0]["value"],

@@ -32,6 +32,14 @@ int abi_exception() noexcept {
   return MVICP_ERR_INTERNAL;
 }
 
+// squared search radius of the NN kernels for a cutoff whose squared bound is d2_bound (ctx::nn_search_factor)
+double search_bound(const mvicp_ctx* c, double d2_bound) {
+  if (!(c->nn_search_factor > 0.0)) return 1.7976931348623157e308;
+  const double f = std::max(1.0, c->nn_search_factor);
+  const double b = d2_bound * f * f * (1.0 + 1e-9);
+  return std::isfinite(b) ? b : 1.7976931348623157e308;
+}
+
 int cached_upload(mvicp_ctx* c, const char* key, const void* src, size_t bytes, void** dptr) {
   mvicp_ctx::CachedTable& t = c->tables[key];
   if (t.d && t.bytes.size() == bytes && std::memcmp(t.bytes.data(), src, bytes) == 0) { *dptr = t.d; return MVICP_OK; }
@@ -985,6 +993,7 @@ int mvicp_set_option(mvicp_ctx* c, const char* name, double value) try {
   if (std::strcmp(name, "auto_settle") == 0) { c->auto_settle = value; return MVICP_OK; }
   if (std::strcmp(name, "auto_switch") == 0) { c->auto_switch = value; return MVICP_OK; }
   if (std::strcmp(name, "nn_cell") == 0) { c->nn_cell = value != 0.0; return MVICP_OK; }
+  if (std::strcmp(name, "nn_search_factor") == 0) { if (!(value >= 0.0)) { set_error("nn_search_factor < 0"); return MVICP_ERR_ARG; } c->nn_search_factor = value; c->nn_cache_valid = false; return MVICP_OK; }
   if (std::strcmp(name, "tie_rule") == 0) { c->tie_rule = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "tile_seed") == 0) { c->tile_seed = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "tile_bounds") == 0) { c->tile_bounds = (int)value; return MVICP_OK; }

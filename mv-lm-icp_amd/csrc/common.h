@@ -210,6 +210,9 @@ struct mvicp_ctx {
   bool far_narrow = false;         // this grid launch expects (almost) no far queries: narrow far-kernel launch (set by mvicp_correspond)
   bool skip_dirty_reduce = false;  // set by mvicp_correspond for a search in which no list can change (see api.cpp)
   bool nn_skip_far = false;        // PROFILING ONLY: leave unresolved queries unresolved (wrong results)
+  double nn_search_factor = 4.0;   // the kernels look for a neighbour within this many cutoffs (0 = unbounded, like the reference's findNeighbors): a query the
+                                   // cutoff rejects then still has a neighbour to seed next round's search with and a temporal-cache bound, instead of being
+                                   // searched from scratch every round (partial overlap: a third of the queries); the filter of frame.cpp:156 is applied after
   bool tie_rule = true;            // exact distance ties are decided as nanoflann decides them (first visited; nn_tie.hip); false: lowest original index
   unsigned long long* d_tie_list = nullptr; size_t tie_cap = 0; unsigned int* d_tie_count = nullptr; int tie_parity = 0;   // queries reported by the NN kernels
   unsigned int* h_tie_seen = nullptr; unsigned int* d_tie_seen = nullptr;   // mapped host word: reports of the last fix-up launch (read after the round's wait)
@@ -249,7 +252,8 @@ namespace mvicp {
 // kernels (each defined in its own TU)
 int launch_nn_brute_edges(mvicp_ctx* c);                                             // nn_brute.hip
 int launch_nn_brute_queries(mvicp_ctx* c, const FrameDev& f, const double* d_q, int n, int* d_idx, double* d_d2);
-int launch_nn_grid_edges(mvicp_ctx* c, double d2_bound);                              // nn_grid.hip
+int launch_nn_grid_edges(mvicp_ctx* c, double d2_bound);                              // nn_grid.hip (d2_bound = the cutoff's; the search radius is search_bound())
+double search_bound(const mvicp_ctx* c, double d2_bound);                               // api.cpp                              // nn_grid.hip
 int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound, bool with_bounds, bool with_cache, bool with_list);
 int launch_nn_mfma_edges(mvicp_ctx* c, double d2_bound, bool with_bounds, bool with_cache, bool with_list);   // nn_mfma.hip
 int build_mfma(FrameDev& f, const double* sorted_pts);                                 // nn_mfma.hip (host, called by build_grid)

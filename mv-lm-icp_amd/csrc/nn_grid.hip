@@ -134,7 +134,7 @@ __global__ void dirty_reduce_kernel(int E, const int* __restrict__ slot_off, int
 
 // ---- phase 1: spatial-hash block lookup for every query; queries it cannot prove optimal go to the far list ----
 template <bool TREE_ONLY>
-__global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__ jobs, double bound, unsigned long long* __restrict__ stats, int skip_far,
+__global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__ jobs, double bound, double search, unsigned long long* __restrict__ stats, int skip_far,
                                                      int2* __restrict__ far_list, unsigned int* __restrict__ far_count, double prune_rho) {
   __shared__ double sxf[kEdgeXf];
   __shared__ uint2 s_rng[8][NT];   // per lane: (start, count) of the 8 block cells (written and read by the same thread only)
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
   }
   const int out = i;   // results live in the SORTED order of the source cloud (coalesced; the pipeline stays in that order)
 
-  double best = bound;      // nothing at or beyond the cutoff bound needs resolving (frame.cpp:156)
+  double best = search;     // nothing at or beyond the search radius (>= the cutoff: search_bound()) needs resolving; frame.cpp:156 filters later
   int bi = 0x7fffffff;
   bool resolved = false;
   unsigned int n_cand = 0;
@@ -175,6 +175,16 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
   double rp2 = -1.0;   // < 0: scan the whole block
   if (!TREE_ONLY && job.seed) {
     const int pi = job.out_idx[out];   // sorted position of last round's neighbour
+    if (pi < 0 && slack == 0.0 && job.out_lb != nullptr && job.out_lb[out] == -1.f) {
+      // last search found NO target within the search radius, and the host found this edge's query transform bit-identical to that
+      // search's (slack 0: dM = dv = 0): the same query has the same answer — nothing to search, nothing to write
+      if (stats) {
+        unsigned long long c1 = __reduce_add_u64(1ull);
+        const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + (threadIdx.x >> 6);
+        if (__lane0()) atomicAdd(&stats[8 * slot + 3], c1);
+      }
+      return;
+    }
     if (pi >= 0 && pi < g.n) {
       // (the 24-B point of the sorted cloud, not its 32-B record: a cache hit needs no index — round 3 byte diet, 68 -> 56 B per hit)
       const double* tp = g.spts + 3 * (size_t)pi;
@@ -443,7 +453,7 @@ __device__ __forceinline__ void cell_scan(const GridView& g, CellLane& L, const 
   L.n_cand += cnt;
 }
 
-__global__ __launch_bounds__(NT, 5) void nn_cell_kernel(const GridJob* __restrict__ jobs, double bound, unsigned long long* __restrict__ stats,
+__global__ __launch_bounds__(NT, 5) void nn_cell_kernel(const GridJob* __restrict__ jobs, double bound, double search_r2, unsigned long long* __restrict__ stats,
                                                         int2* __restrict__ far_list, unsigned int* __restrict__ far_count, double prune_rho) {
   __shared__ double sxf[kEdgeXf];
   __shared__ unsigned long long s_hkey[NT / 64][CELL_HS];
@@ -471,7 +481,7 @@ __global__ __launch_bounds__(NT, 5) void nn_cell_kernel(const GridJob* __restric
 
   CellLane L;
   L.qx = L.qy = L.qz = 0.0;
-  L.best = bound;        // nothing at or beyond the cutoff bound needs resolving (frame.cpp:156)
+  L.best = search_r2;    // nothing at or beyond the search radius needs resolving (frame.cpp:156 filters later)
   L.bpos = -1; L.second = big; L.n_cand = 0; L.ovf = false;
   double TA2 = big;      // pass A scans the home cells within this squared distance (seeded: old-neighbour distance + margin)
   double p0 = 0.0, p1 = 0.0, p2 = 0.0;
@@ -760,7 +770,8 @@ __global__ __launch_bounds__(NT) void nn_far_kernel(const GridJob* __restrict__ 
       job.out_idx[out] = bi == 0x7fffffff ? -1 : (job.inv ? job.inv[bi] : bi);
       job.out_d2[out] = best;
       // every other target was scanned (>= second) or sits in a skipped box (>= its lower bound)
-      if (job.out_lb != nullptr) job.out_lb[out] = bi == 0x7fffffff ? 0.f : __double2float_rd(sqrt(fmin(second, pruned)) * (1.0 - 1e-12));
+      // (-1: no target within the search radius — re-usable as it is while the query does not move at all, see the prologue of phase 1)
+      if (job.out_lb != nullptr) job.out_lb[out] = bi == 0x7fffffff ? -1.f : __double2float_rd(sqrt(fmin(second, pruned)) * (1.0 - 1e-12));
       if (job.dirty) update_list(job, i, bi == 0x7fffffff ? -1 : job.inv[bi], best, bound);
       if (bi != 0x7fffffff && second == best) tie_report(job.tie, (unsigned int)i);
     }
@@ -1120,6 +1131,7 @@ GridView view_of(const FrameDev& f) {
 
 int run(mvicp_ctx* c, std::vector<GridJob>& jobs, double bound, const FrameDev* const* dst_of) {
   if (jobs.empty()) return MVICP_OK;
+  const double search = search_bound(c, bound);
   std::vector<TieJob> ties;
   {
     double launch_q = 0;
@@ -1179,11 +1191,11 @@ int run(mvicp_ctx* c, std::vector<GridJob>& jobs, double bound, const FrameDev* 
     use_cell = c->nn_cell && !c->nn_tree_only && !c->nn_skip_far && edge_path;
     for (const GridJob& j : jobs) if (j.dst.bricks == nullptr || j.xf == nullptr) use_cell = false;
     if (c->nn_tree_only)
-      hipLaunchKernelGGL((nn_grid_kernel<true>), grid, dim3(NT), 0, c->stream, d_jobs, bound, d_stats, 0, (int2*)c->d_far_list, far_cnt, 0.0);
+      hipLaunchKernelGGL((nn_grid_kernel<true>), grid, dim3(NT), 0, c->stream, d_jobs, bound, search, d_stats, 0, (int2*)c->d_far_list, far_cnt, 0.0);
     else if (use_cell)
-      hipLaunchKernelGGL(nn_cell_kernel, grid, dim3(NT), 0, c->stream, d_jobs, bound, d_stats, (int2*)c->d_far_list, far_cnt, c->prune_rho);
+      hipLaunchKernelGGL(nn_cell_kernel, grid, dim3(NT), 0, c->stream, d_jobs, bound, search, d_stats, (int2*)c->d_far_list, far_cnt, c->prune_rho);
     else
-      hipLaunchKernelGGL((nn_grid_kernel<false>), grid, dim3(NT), 0, c->stream, d_jobs, bound, d_stats, c->nn_skip_far ? 1 : 0, (int2*)c->d_far_list, far_cnt,
+      hipLaunchKernelGGL((nn_grid_kernel<false>), grid, dim3(NT), 0, c->stream, d_jobs, bound, search, d_stats, c->nn_skip_far ? 1 : 0, (int2*)c->d_far_list, far_cnt,
                          c->prune_rho);
   }
   {

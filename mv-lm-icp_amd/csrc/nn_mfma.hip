@@ -79,6 +79,7 @@ __device__ __forceinline__ float box_thr(float rbest, float slack) { const float
 __device__ __forceinline__ void tau_pieces(const LaneM& L, float scale_f, float mu_s, float en, float kAcc, _Float16& t1, _Float16& t2, _Float16& t3) {
   if (!L.active) { t1 = (_Float16)60000.f; t2 = (_Float16)0.f; t3 = (_Float16)0.f; return; }    // V >= -3.2e6 + 2.4e8 > 0: never a hit
   if (!L.inrange) { t1 = (_Float16)-60000.f; t2 = (_Float16)0.f; t3 = (_Float16)0.f; return; }  // operands zeroed: V = n - 2.4e8 < 0, every point is confirmed
+  if (!(L.rbest < 1.0e18f)) { t1 = (_Float16)-60000.f; t2 = (_Float16)0.f; t3 = (_Float16)0.f; return; }   // no finite threshold yet (unbounded search, nothing found so far): V = S - 2.4e8 < 0 for every point, order kept
   const float rb = (L.rbest * scale_f + mu_s + L.dab) * 1.000001f;
   const float U = rb * rb * 1.000001f;
   const float s = U + L.a2;
@@ -383,7 +384,7 @@ __device__ void visit(const TileView& g, int first, int nchild, LaneM& L, const 
 }
 
 template <int WPE, int TOP, bool BND, bool CEN>
-__global__ __launch_bounds__(NT, WPE) void nn_mfma_kernel(const TileJob* __restrict__ jobs, double bound, unsigned long long* __restrict__ stats) {
+__global__ __launch_bounds__(NT, WPE) void nn_mfma_kernel(const TileJob* __restrict__ jobs, double bound, double search, unsigned long long* __restrict__ stats) {
   __shared__ float2 s_box[NT / 64][2 * 3 * FAN];   // levels 1 and 2: 64 child boxes x 24 B each, per wave
   __shared__ double sxf[kEdgeXf];
   const TileJob& job = jobs[blockIdx.y];
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(NT, WPE) void nn_mfma_kernel(const TileJob* __restr
 
   LaneM L;
   L.active = i < job.n;
-  L.best = bound; L.bi = 0x7fffffff; L.bpos = -1; L.tie = false;
+  L.best = search; L.bi = 0x7fffffff; L.bpos = -1; L.tie = false;
   L.second = 1.7976931348623157e308;
   L.qx = L.qy = L.qz = 0.0;
   L.a2 = 0.f; L.amax = 0.f; L.dab = 0.f; L.inrange = false;
@@ -425,6 +426,12 @@ __global__ __launch_bounds__(NT, WPE) void nn_mfma_kernel(const TileJob* __restr
   }
   // Temporal cache (BND builds in cache-aware rounds): see nn_tile.hip — a lane whose neighbour provably did not change is finished here.
   unsigned int n_hit = 0;
+  if (BND && job.cache && has_xf && job.seed && L.active && seed_pi < 0 && sxf[24] == 0.0 && job.out_lb[i] == -1.f) {
+    // last search found NO target within the search radius and this edge's query transform is bit-identical to that search's (allowance 0:
+    // dM = dv = 0): the query is the same, so is the answer — nothing to search, nothing to write
+    L.active = false;
+    n_hit = 1;
+  }
   if (BND && job.cache && has_xf && seed_pi >= 0) {
     const double cslack = sxf[24];
     if (cslack >= 0.0) {
@@ -490,7 +497,7 @@ __global__ __launch_bounds__(NT, WPE) void nn_mfma_kernel(const TileJob* __restr
     job.out_d2[out] = L.best;
     // every other target was evaluated exactly (>= second) or rejected by a screen (> sqrt(best) + mu away); 1e-9 relative covers the
     // fp64 roundings of this line.  No neighbour inside the cutoff: 0 forces a full search next round, like the grid kernel does.
-    if (BND) job.out_lb[out] = L.bpos < 0 ? 0.f : __double2float_rd(fmin(sqrt(L.second), sqrt(L.best) + (double)G.mu) * (1.0 - 1e-9));
+    if (BND) job.out_lb[out] = L.bpos < 0 ? -1.f : __double2float_rd(fmin(sqrt(L.second), sqrt(L.best) + (double)G.mu) * (1.0 - 1e-9));
     if (job.list.dirty) update_list_entry(job.list, i, L.bpos, L.best, bound, false);
     if ((BND ? L.second == L.best : L.tie) && L.bpos >= 0) tie_report(job.tie, (unsigned int)i);
   }
@@ -620,8 +627,8 @@ int launch_nn_mfma_edges(mvicp_ctx* c, double d2_bound, bool with_bounds, bool w
     const dim3 grid((max_n + NT - 1) / NT, (unsigned)jobs.size());
     int top = jobs[0].dst.levels - 1;   // same depth everywhere -> the traversal specialised for it
     for (const TileJob& j : jobs) if (j.dst.levels - 1 != top) top = -1;
-#define MVICP_MFMA_K(W, T, B) do { if (d_stats) hipLaunchKernelGGL((nn_mfma_kernel<W, T, B, true>), grid, dim3(NT), 0, c->stream, d_jobs, d2_bound, d_stats); \
-                                 else hipLaunchKernelGGL((nn_mfma_kernel<W, T, B, false>), grid, dim3(NT), 0, c->stream, d_jobs, d2_bound, d_stats); } while (0)
+#define MVICP_MFMA_K(W, T, B) do { if (d_stats) hipLaunchKernelGGL((nn_mfma_kernel<W, T, B, true>), grid, dim3(NT), 0, c->stream, d_jobs, d2_bound, search_bound(c, d2_bound), d_stats); \
+                                 else hipLaunchKernelGGL((nn_mfma_kernel<W, T, B, false>), grid, dim3(NT), 0, c->stream, d_jobs, d2_bound, search_bound(c, d2_bound), d_stats); } while (0)
     const int waves = c->tile_waves;
     if (with_bounds) {
       if (top == 2) MVICP_MFMA_K(5, 2, true); else MVICP_MFMA_K(5, -1, true);

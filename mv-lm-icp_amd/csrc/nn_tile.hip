@@ -237,7 +237,7 @@ __device__ void visit(const TileView& g, int first, int nchild, Lane& L, const G
 // TOP >= 0: every target of the launch has exactly TOP + 1 hierarchy levels (the common case: clouds of similar size), so
 // only that traversal is compiled in; TOP = -1: generic (per-job switch over the depth).
 template <int WPE, int TOP, bool BND>
-__global__ __launch_bounds__(NT, WPE) void nn_tile_kernel(const TileJob* __restrict__ jobs, double bound, unsigned long long* __restrict__ stats) {
+__global__ __launch_bounds__(NT, WPE) void nn_tile_kernel(const TileJob* __restrict__ jobs, double bound, double search, unsigned long long* __restrict__ stats) {
   __shared__ TileLds s_tile[NT / 64];
   __shared__ float2 s_box[NT / 64][2 * 3 * FAN];   // levels 1 and 2: 64 child boxes x 24 B each, per wave
   __shared__ double sxf[kEdgeXf];
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(NT, WPE) void nn_tile_kernel(const TileJob* __restr
 
   Lane L;
   L.active = i < job.n;
-  L.best = bound; L.bi = 0x7fffffff; L.tie = false;
+  L.best = search; L.bi = 0x7fffffff; L.tie = false;
   L.second = 1.7976931348623157e308;
   L.qx = L.qy = L.qz = 0.0;
   double p0 = 0.0, p1 = 0.0, p2 = 0.0;
@@ -282,6 +282,12 @@ __global__ __launch_bounds__(NT, WPE) void nn_tile_kernel(const TileJob* __restr
   // finished here and sits the traversal out: the wave walks the hierarchy for its MISSED lanes only — a patch of a few queries opens
   // one or two tiles instead of six — and a wave without a miss leaves at once.
   unsigned int n_hit = 0;
+  if (BND && job.cache && has_xf && job.seed && L.active && seed_pi < 0 && sxf[24] == 0.0 && job.out_lb[i] == -1.f) {
+    // last search found NO target within the search radius and this edge's query transform is bit-identical to that search's (allowance 0:
+    // dM = dv = 0): the query is the same, so is the answer — nothing to search, nothing to write
+    L.active = false;
+    n_hit = 1;
+  }
   if (BND && job.cache && has_xf && seed_pi >= 0) {
     const double cslack = sxf[24];
     if (cslack >= 0.0) {
@@ -348,7 +354,7 @@ __global__ __launch_bounds__(NT, WPE) void nn_tile_kernel(const TileJob* __restr
     job.out_d2[out] = L.best;
     // every other target was evaluated exactly (>= second) or rejected by a screen (> sqrt(best) + mu away); 1e-9 relative covers the
     // fp64 roundings of this line.  No neighbour inside the cutoff: 0 forces a full search next round, like the grid kernel does.
-    if (BND) job.out_lb[out] = L.bi == 0x7fffffff ? 0.f : __double2float_rd(fmin(sqrt(L.second), sqrt(L.best) + (double)G.mu) * (1.0 - 1e-9));
+    if (BND) job.out_lb[out] = L.bi == 0x7fffffff ? -1.f : __double2float_rd(fmin(sqrt(L.second), sqrt(L.best) + (double)G.mu) * (1.0 - 1e-9));
     // the edge's compacted list is maintained in place (nn_list.h) whenever the host handed it over (list.dirty != null): a query that
     // keeps its acceptance patches its own entry and operands, so compaction + gather only run for edges whose MEMBERSHIP changed —
     // also in the plain seeded rounds, where nearly every neighbour changes but hardly any acceptance does (round 3)
@@ -444,7 +450,7 @@ int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound, bool with_bounds, bool w
     const dim3 grid((max_n + NT - 1) / NT, (unsigned)jobs.size());
     int top = jobs[0].dst.levels - 1;   // same depth everywhere -> the traversal specialised for it
     for (const TileJob& j : jobs) if (j.dst.levels - 1 != top) top = -1;
-#define MVICP_TILE_K(W, T, B) hipLaunchKernelGGL((nn_tile_kernel<W, T, B>), grid, dim3(NT), 0, c->stream, d_jobs, d2_bound, d_stats)
+#define MVICP_TILE_K(W, T, B) hipLaunchKernelGGL((nn_tile_kernel<W, T, B>), grid, dim3(NT), 0, c->stream, d_jobs, d2_bound, search_bound(c, d2_bound), d_stats)
     const int waves = c->tile_waves;   // 0 = pick: 7 waves per SIMD for the depth-3 build, 6 otherwise
     // depth-3 build: 7 waves per SIMD (no spills at 66 VGPRs); 6 and 8 measure 4-10 % slower (profiles/r03_tile_ab.txt)
     if (with_bounds) {   // hand-over round: one more fp64 register pair per lane, so one wave per SIMD fewer

@@ -64,7 +64,7 @@ def gt_pose(k, K):
     return T
 
 
-def make_view(k, K, N, seed_base=1000):
+def make_view(k, K, N, seed_base=1000, cone_deg=CONE_DEG):
     rng = np.random.Generator(np.random.PCG64(seed_base + k))
     T = gt_pose(k, K)
     R = T[:3, :3]
@@ -72,7 +72,7 @@ def make_view(k, K, N, seed_base=1000):
     # orthonormal frame around c
     a = np.cross(c, [0.0, 1.0, 0.0]); a /= np.linalg.norm(a)
     b = np.cross(c, a)
-    cos_a = rng.uniform(np.cos(np.deg2rad(CONE_DEG)), 1.0, N)
+    cos_a = rng.uniform(np.cos(np.deg2rad(cone_deg)), 1.0, N)
     beta = rng.uniform(0, 2 * np.pi, N)
     sin_a = np.sqrt(1 - cos_a ** 2)
     dirs = cos_a[:, None] * c + sin_a[:, None] * (np.cos(beta)[:, None] * a + np.sin(beta)[:, None] * b)
@@ -104,10 +104,12 @@ def make_poses(K, sigma=0.02, sigmat=0.01, knn=2, pose_seed=5489):
     return {"gt": np.array(gt), "init": np.array(init), "src": src, "dst": dst, "fixed": fixed}
 
 
-def make_problem(K, N, sigma=0.02, sigmat=0.01, knn=2, seed_base=1000, pose_seed=5489):
+def make_problem(K, N, sigma=0.02, sigmat=0.01, knn=2, seed_base=1000, pose_seed=5489, cone_deg=CONE_DEG):
+    """cone_deg: half-angle of the cone of directions a view sees (100 = the BASELINE configs: ring neighbours overlap almost fully;
+    20 = a partial-overlap variant: a third of a view's points have no counterpart in a ring neighbour)."""
     pts, nor = [], []
     for k in range(K):
-        p, n = make_view(k, K, N, seed_base)
+        p, n = make_view(k, K, N, seed_base, cone_deg)
         pts.append(p); nor.append(n)
     pb = make_poses(K, sigma, sigmat, knn, pose_seed)
     pb["pts"] = pts; pb["nor"] = nor
