@@ -343,6 +343,7 @@ int mvicp_destroy(mvicp_ctx* c) try {
   if (c->d_tie_list) (void)hipFree(c->d_tie_list);
   if (c->d_tie_count) (void)hipFree(c->d_tie_count);
   if (c->h_tie_seen) (void)hipHostFree(c->h_tie_seen);
+  if (c->h_far_seen) (void)hipHostFree(c->h_far_seen);
   if (c->d_far_list) (void)hipFree(c->d_far_list);
   if (c->d_far_count) (void)hipFree(c->d_far_count);
   for (auto& kv : c->prof) {
@@ -591,7 +592,7 @@ int mvicp_reset_history(mvicp_ctx* c) try {
   c->nn_cache_valid = false; c->nn_cache_thresh = -1.f;
   c->prev_q.assign((size_t)E * 12, 0.0); c->prev_xf.assign((size_t)E * 24, 0.0);
   c->nn_cache_edge.assign(E, 0);                      // no seeds, no temporal cache: d_nn_idx / d_nn_lb are dead until the next search rewrites them
-  c->auto_prev_dist = 0.0; c->auto_last_method = -1; c->last_rms = -1.0;
+  c->auto_prev_dist = 0.0; c->auto_last_method = -1; c->last_rms = -1.0; c->prev_grid_kernel = false;
   c->list_valid.assign(E, 0);                          // every list is re-compacted and re-gathered
   c->sel_med1.assign(E, -1.0); c->sel_med2.assign(E, -1.0);
   c->spec_ready = false; c->spec_arm = false; c->spec_flags_valid = false;
@@ -740,6 +741,7 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   c->skip_dirty_reduce = nothing_can_change;
   // ... and the tie fix-up (nn_tie.hip) neither, if last round's search reported no tie: the same queries meet the same targets
   c->tie_skip = nothing_can_change && c->h_tie_seen != nullptr && *c->h_tie_seen == 0u;
+  c->far_skip = nothing_can_change && c->h_far_seen != nullptr && *c->h_far_seen == 0u && c->prev_grid_kernel && method == MVICP_NN_GRID;
   // Speculative first evaluation of the solve that follows (see common.h).  Every rank decides for itself (its own last solve set
   // the flags); with N > 1 ranks the decisions are SUMMED in the "armed" slot of the one exchanged buffer and the queued blocks are
   // used only if every rank armed — a rank whose last solve failed or was skipped still takes part in the same collective (no hang).
@@ -769,7 +771,8 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   else if (method == MVICP_NN_GRID) MV_CHECK(launch_nn_grid_edges(c, bound));
   else if (method == MVICP_NN_TILE) MV_CHECK(launch_nn_tile_edges(c, bound, tile_lb, tile_cached, c->list_reuse));
   else { set_error("unknown nn_method %d", nn_method); return MVICP_ERR_ARG; }
-  c->tie_skip = false;
+  c->tie_skip = false; c->far_skip = false;
+  c->prev_grid_kernel = method == MVICP_NN_GRID;
   // only the grid kernel and the tile kernel's BND build leave the per-query lower bounds the temporal cache needs; the cutoff must
   // not change either
   c->last_rms = -1.0;   // consumed: only a solve that follows THIS search may predict the next one

@@ -207,6 +207,9 @@ struct mvicp_ctx {
   void* d_census = nullptr; size_t census_bytes = 0;
   void* d_far_list = nullptr; size_t far_cap = 0; unsigned int* d_far_count = nullptr;  // nn_grid far-query list
   int far_parity = 0;              // d_far_count holds TWO counters used alternately; a launch zeroes the one the next launch will use
+  unsigned int* h_far_seen = nullptr; unsigned int* d_far_seen = nullptr;   // mapped host word: far-list length of the last nn_far_kernel launch
+  bool prev_grid_kernel = false;   // the previous search ran nn_grid_kernel + nn_far_kernel (so h_far_seen describes it)
+  bool far_skip = false;           // set by mvicp_correspond: bit-identical queries after a grid round without far queries -> no far query, no phase-2 launch
   bool far_narrow = false;         // this grid launch expects (almost) no far queries: narrow far-kernel launch (set by mvicp_correspond)
   bool skip_dirty_reduce = false;  // set by mvicp_correspond for a search in which no list can change (see api.cpp)
   bool nn_skip_far = false;        // PROFILING ONLY: leave unresolved queries unresolved (wrong results)

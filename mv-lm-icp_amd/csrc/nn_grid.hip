@@ -664,13 +664,13 @@ __device__ __forceinline__ double oct_box_lb(double qx, double qy, double qz, co
 
 __global__ __launch_bounds__(NT) void nn_far_kernel(const GridJob* __restrict__ jobs, const int2* __restrict__ far_list, double bound,
                                                     const unsigned int* __restrict__ far_count, unsigned int* __restrict__ next_far_count,
-                                                    unsigned long long* __restrict__ stats, size_t stats_slots) {
+                                                    unsigned long long* __restrict__ stats, size_t stats_slots, unsigned int* __restrict__ seen) {
   __shared__ int s_id[NT / 8][OCT_STACK];
   __shared__ double s_lb[NT / 8][OCT_STACK];
   const unsigned int nfar = *far_count;
   // two far-list counters alternate between launches: this launch consumes one, and leaves the OTHER one — which nothing touches
   // during this launch — zeroed for the next phase 1 (no memset and no clean-up kernel in the per-round sequence)
-  if (blockIdx.x == 0 && threadIdx.x == 0) *next_far_count = 0u;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { *next_far_count = 0u; if (seen) *seen = nfar; }
   const int oct = threadIdx.x >> 3, l = threadIdx.x & 7;
   const int lane = threadIdx.x & 63, obase = lane & ~7;
   unsigned long long n_cand = 0, n_nodes = 0;
@@ -1207,7 +1207,16 @@ int run(mvicp_ctx* c, std::vector<GridJob>& jobs, double bound, const FrameDev* 
     // 0.2 % far queries (the 96 %-hit round of a hand-over) the narrow launch measured 0.1 ms SLOWER than the wide one.
     const size_t far_wide = (edge_path && c->far_narrow) ? 128 : 256 * 8;
     const unsigned int far_blocks = (unsigned int)std::min<size_t>(far_wide, (total_q * 8 + NT - 1) / NT);
-    hipLaunchKernelGGL(nn_far_kernel, dim3(far_blocks), dim3(NT), 0, c->stream, d_jobs, (const int2*)c->d_far_list, bound, (const unsigned int*)far_cnt, far_next, d_stats, slots);
+    if (!c->h_far_seen) {
+      MV_HIP(hipHostMalloc((void**)&c->h_far_seen, sizeof(unsigned int), hipHostMallocMapped));
+      *c->h_far_seen = 1u;   // unknown until a launch has written it
+      MV_HIP(hipHostGetDevicePointer((void**)&c->d_far_seen, c->h_far_seen, 0));
+    }
+    // (at the fixed point — every query bit-identical to last round's — a round that follows one without far queries has none either:
+    // its counter stays zero and phase 2 is not launched at all, api.cpp far_skip)
+    if (!(edge_path && c->far_skip))
+      hipLaunchKernelGGL(nn_far_kernel, dim3(far_blocks), dim3(NT), 0, c->stream, d_jobs, (const int2*)c->d_far_list, bound, (const unsigned int*)far_cnt, far_next, d_stats, slots,
+                         edge_path ? c->d_far_seen : nullptr);
     // per-edge OR of the "list changed" slots — not needed when the host already knows that nothing can change (api.cpp: every
     // transform bit-identical, every list valid): no query marks a slot then
     if (edge_path && !c->skip_dirty_reduce)
