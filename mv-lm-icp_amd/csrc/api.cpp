@@ -744,7 +744,8 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   c->far_skip = nothing_can_change && c->h_far_seen != nullptr && *c->h_far_seen == 0u && c->prev_grid_kernel && method == MVICP_NN_GRID;
   // Speculative first evaluation of the solve that follows (see common.h).  Every rank decides for itself (its own last solve set
   // the flags); with N > 1 ranks the decisions are SUMMED in the "armed" slot of the one exchanged buffer and the queued blocks are
-  // used only if every rank armed — a rank whose last solve failed or was skipped still takes part in the same collective (no hang).
+  // used only if every rank armed — a rank that did not arm still takes part in the same collective with the same size.  (A rank that fails
+  // LOCALLY before the exchange — a launch error — returns without it and its peers block in the collective: a failed launch is fatal for the job.)
   const bool exchange = c->comm != nullptr || c->ar_fn != nullptr;
   c->spec_ready = false;
   c->spec_arm = c->spec_enable && c->spec_flags_valid;
@@ -795,6 +796,12 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   if (exchange) {
     c->lin_out = c->d_out;
     if (c->spec_arm) st_q = launch_linearize(c, c->spec_q_plane, c->spec_q_robust);
+    else {
+      // this rank queued no evaluation: its share of the block region and of the scale slots is ZERO, not whatever the last exchange left
+      // there (already-summed values would be summed again round after round).  Every rank sends the same buffer size whatever it decided.
+      if (hipMemsetAsync(c->d_out, 0, sizeof(double) * nb, c->stream) != hipSuccess ||
+          hipMemsetAsync(c->d_out + nb + 2 * (size_t)E + 1, 0, sizeof(double) * (size_t)E, c->stream) != hipSuccess) { set_error("hipMemsetAsync of the exchange buffer failed"); st_q = MVICP_ERR_HIP; }
+    }
     if (st_q == MVICP_OK) { ProfScope pc(c, "comm", 8.0 * (double)(nb + ntail)); st_q = comm_allreduce_sum(c, c->d_out, nb + ntail); }
     if (st_q == MVICP_OK && hipMemcpyAsync(c->h_pin + c->pin_spec_off, c->d_out, sizeof(double) * (nb + ntail), hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
       set_error("hipMemcpyAsync of the exchanged buffer failed"); st_q = MVICP_ERR_HIP;

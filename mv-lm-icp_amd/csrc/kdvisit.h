@@ -37,7 +37,7 @@ MV_HD inline bool visited_before(const VisitTree& T, double qx, double qy, doubl
 // Host: the split structure nanoflann's KDTreeSingleIndexAdaptor builds for this cloud with leaf_max_size = 1 (buildIndex ->
 // divideTree -> middleSplit_ -> planeSplit, nanoflann.hpp:859-867,1034-1174), restated — only the topology and the cut values are
 // kept, which is all the visit order depends on.  Points are handled through an index permutation `ord` that starts as 0..n-1.
-namespace {
+namespace kdv_detail {   // (a named namespace: the inline builder below has external linkage and must see the same types in every translation unit)
 
 struct Box3 { double lo[3], hi[3]; };
 
@@ -104,14 +104,14 @@ struct VisitBuilder {
   }
 };
 
-}  // namespace
+}  // namespace kdv_detail
 
 inline int build_visit_tree(const double* xyz, int n, std::vector<VisitNode>& nodes, std::vector<int>& slot) {
-  VisitBuilder B;
+  kdv_detail::VisitBuilder B;
   B.xyz = xyz; B.ord.resize(n);
   for (int i = 0; i < n; ++i) B.ord[i] = i;
   B.nodes.reserve(2 * (size_t)n);
-  Box3 box;
+  kdv_detail::Box3 box;
   for (int a = 0; a < 3; ++a) box.lo[a] = box.hi[a] = xyz[a];
   for (int i = 1; i < n; ++i)
     for (int a = 0; a < 3; ++a) { const double v = xyz[3 * (size_t)i + a]; if (v < box.lo[a]) box.lo[a] = v; if (v > box.hi[a]) box.hi[a] = v; }

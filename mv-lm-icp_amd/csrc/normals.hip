@@ -22,6 +22,7 @@
 
 #include "common.h"
 #include "kdvisit.h"
+#include "nn_tie.h"
 
 namespace mvicp {
 
@@ -185,33 +186,28 @@ __global__ __launch_bounds__(NT) void normals_kernel(NormJob job) {
 int launch_normals(mvicp_ctx* c, FrameDev& f, int k, int* d_knn) {
   if (!f.has_grid) { set_error("normals need the per-cloud hash structure"); return MVICP_ERR_STATE; }
   if (k < 3 || k > KMAX) { set_error("k = %d outside [3, %d]", k, KMAX); return MVICP_ERR_ARG; }
-  // tie order: nanoflann's tree for this cloud (host, O(n log n), one-off like the reference's own lazy build, frame.cpp:209-214)
-  std::vector<double> h_xyz(3 * (size_t)f.n);
-  MV_HIP(hipMemcpy(h_xyz.data(), f.pts, sizeof(double) * 3 * (size_t)f.n, hipMemcpyDeviceToHost));
-  std::vector<VisitNode> nodes; std::vector<int> slot;
-  MV_CHECK(build_visit_tree(h_xyz.data(), f.n, nodes, slot));
-  VisitNode* d_nodes = nullptr; int* d_slot = nullptr;
-  MV_HIP(hipMalloc((void**)&d_nodes, sizeof(VisitNode) * nodes.size()));
-  if (hipMalloc((void**)&d_slot, sizeof(int) * (size_t)f.n) != hipSuccess) { (void)hipFree(d_nodes); set_error("out of device memory (visit tree)"); return MVICP_ERR_HIP; }
-  hipError_t e1 = hipMemcpy(d_nodes, nodes.data(), sizeof(VisitNode) * nodes.size(), hipMemcpyHostToDevice);
-  hipError_t e2 = hipMemcpy(d_slot, slot.data(), sizeof(int) * (size_t)f.n, hipMemcpyHostToDevice);
+  // tie order: nanoflann's tree for this cloud — built once per cloud upload and kept with the frame (nn_tie.hip; the 1-NN kernels'
+  // tie rule uses the same tree), like the reference's own lazy index (frame.cpp:209-214)
+  {
+    int fi = -1;
+    for (int t = 0; t < c->n_frames; ++t) if (&c->frames[t] == &f) fi = t;
+    if (fi < 0) { set_error("normals: frame is not part of the context"); return MVICP_ERR_ARG; }
+    MV_CHECK(ensure_tie_trees(c, std::vector<int>(1, fi)));
+  }
   NormJob j;
   const GridDev& g = f.grid;
-  j.tie.nodes = d_nodes; j.tie.slot = d_slot;
+  j.tie.nodes = static_cast<const VisitNode*>(f.tie_nodes); j.tie.slot = f.tie_slot;
   j.srec = (const PointRec*)g.crec; j.inv = g.inv; j.n = f.n;
   j.table = (const HashEntry*)g.table; j.mask = g.table_mask; j.shift = g.table_shift;
   j.ox = g.origin[0]; j.oy = g.origin[1]; j.oz = g.origin[2]; j.h = g.cell; j.inv_h = g.inv_cell;
   j.dx = g.dims[0]; j.dy = g.dims[1]; j.dz = g.dims[2];
   j.k = k; j.nor_out = f.nor; j.snor_out = f.grid.snor; j.knn_out = d_knn;
-  hipError_t e3 = hipSuccess;
-  if (e1 == hipSuccess && e2 == hipSuccess) {
+  {
     ProfScope ps(c, "normals", 0.0);
     hipLaunchKernelGGL(normals_kernel, dim3((f.n + NT - 1) / NT), dim3(NT), 0, c->stream, j);
-    e3 = hipGetLastError();
   }
-  const hipError_t e4 = hipStreamSynchronize(c->stream);   // the tree buffers are freed below
-  (void)hipFree(d_nodes); (void)hipFree(d_slot);
-  for (hipError_t e : {e1, e2, e3, e4}) if (e != hipSuccess) { set_error("normals: %s", hipGetErrorString(e)); return MVICP_ERR_HIP; }
+  MV_HIP(hipGetLastError());
+  MV_HIP(hipStreamSynchronize(c->stream));
   return MVICP_OK;
 }
 
