@@ -197,9 +197,10 @@ __global__ __launch_bounds__(NT) void nn_grid_kernel(const GridJob* __restrict__
         const double e2 = sxf[27] * p0 + sxf[30] * p1 + sxf[33] * p2 + sxf[36];
         const double eps = sqrt(e0 * e0 + e1 * e1 + e2 * e2) * (1.0 + 1e-9) + slack;
         const double nlb = (double)job.out_lb[out] - eps;
-        if (sqrt(d) * (1.0 + 1e-12) < nlb) {
-          // eps == 0 only when the host found the edge's query transform bit-identical to last round's (slack 0, dM = dv = 0): the
-          // query, its distance, its bound and its list entry are then exactly what is stored already — nothing to write
+        // eps == 0 only when the host found the edge's query transform bit-identical to last search's (slack 0, dM = dv = 0): the query is
+        // the same bit for bit, so last search's exact answer — whatever its bound — its distance, its bound and its list entry are exactly
+        // what is stored already: nothing to search, nothing to write
+        if (eps == 0.0 || sqrt(d) * (1.0 + 1e-12) < nlb) {
           if (eps != 0.0) {
             job.out_d2[out] = d;
             job.out_lb[out] = __double2float_rd(nlb);
@@ -1133,7 +1134,7 @@ int run(mvicp_ctx* c, std::vector<GridJob>& jobs, double bound, const FrameDev* 
   if (jobs.empty()) return MVICP_OK;
   const double search = search_bound(c, bound);
   std::vector<TieJob> ties;
-  {
+  if (!(c->tie_skip && jobs[0].dirty_slots != nullptr)) {
     double launch_q = 0;
     for (const GridJob& j : jobs) launch_q += j.n;
     const TieRef tref = tie_ref(c, (size_t)launch_q, 0u);
@@ -1198,7 +1199,8 @@ int run(mvicp_ctx* c, std::vector<GridJob>& jobs, double bound, const FrameDev* 
       hipLaunchKernelGGL((nn_grid_kernel<false>), grid, dim3(NT), 0, c->stream, d_jobs, bound, search, d_stats, c->nn_skip_far ? 1 : 0, (int2*)c->d_far_list, far_cnt,
                          c->prune_rho);
   }
-  {
+  const bool launch_far = !(edge_path && c->far_skip), launch_dirty = edge_path && !c->skip_dirty_reduce;
+  if (launch_far || launch_dirty) {
     ProfScope ps(c, "nn_far", 0.0);   // phase 2 + the list flags: their own scope, so that "nn_grid" times one kernel ("nn" = every nn_* scope together)
     // phase 2: persistent grid-stride launch (the far count is only known on the device)
     // With the temporal cache on, at most a fraction of a per cent of the queries ever reach the far list (0.1-0.2 % in the hand-over rounds,
@@ -1214,12 +1216,12 @@ int run(mvicp_ctx* c, std::vector<GridJob>& jobs, double bound, const FrameDev* 
     }
     // (at the fixed point — every query bit-identical to last round's — a round that follows one without far queries has none either:
     // its counter stays zero and phase 2 is not launched at all, api.cpp far_skip)
-    if (!(edge_path && c->far_skip))
+    if (launch_far)
       hipLaunchKernelGGL(nn_far_kernel, dim3(far_blocks), dim3(NT), 0, c->stream, d_jobs, (const int2*)c->d_far_list, bound, (const unsigned int*)far_cnt, far_next, d_stats, slots,
                          edge_path ? c->d_far_seen : nullptr);
     // per-edge OR of the "list changed" slots — not needed when the host already knows that nothing can change (api.cpp: every
     // transform bit-identical, every list valid): no query marks a slot then
-    if (edge_path && !c->skip_dirty_reduce)
+    if (launch_dirty)
       hipLaunchKernelGGL(dirty_reduce_kernel, dim3(c->E), dim3(256), 0, c->stream, c->E, c->d_dslot_off, c->d_dirty_slots, c->d_dirty);
   }
   MV_HIP(hipGetLastError());

@@ -440,7 +440,7 @@ __global__ __launch_bounds__(NT, WPE) void nn_mfma_kernel(const TileJob* __restr
       const double e2 = sxf[27] * p0 + sxf[30] * p1 + sxf[33] * p2 + sxf[36];
       const double eps = sqrt(e0 * e0 + e1 * e1 + e2 * e2) * (1.0 + 1e-9) + cslack;
       const double nlb = (double)job.out_lb[i] - eps;
-      if (sqrt(seed_d) * (1.0 + 1e-12) < nlb) {
+      if (eps == 0.0 || sqrt(seed_d) * (1.0 + 1e-12) < nlb) {   // (eps == 0: the same query bit for bit keeps last search's exact answer)
         if (eps != 0.0) {   // (eps == 0: bit-identical query transform, everything stored is already exact)
           job.out_d2[i] = seed_d;
           job.out_lb[i] = __double2float_rd(nlb);
