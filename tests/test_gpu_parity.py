@@ -1055,3 +1055,34 @@ def test_random_shapes_knn_lists_equal_nanoflann(eng, refnn, seed):
     myd = (e[:, :, 0] * e[:, :, 0] + e[:, :, 1] * e[:, :, 1]) + e[:, :, 2] * e[:, :, 2]
     assert np.array_equal(myd, gd), seed
     assert np.array_equal(knn, gi), (seed, int((~np.all(knn == gi, axis=1)).sum()))
+
+
+@pytest.mark.parametrize("factor", [0.0, 1.0, 4.0])
+@pytest.mark.parametrize("mfma", [0, 2])
+def test_far_queries_and_unbounded_search(orc, factor, mfma):
+    """Queries far outside the target, in units of the target's own blocks (the matrix-pipe kernel's f16 operands cover 4096 scaled units
+    around a block: beyond that, and while no finite threshold exists, it must fall back to confirming exhaustively), with the search
+    radius unbounded / equal to the cutoff / the default: the kept correspondences are the oracle's in every case, round after round."""
+    rng = np.random.default_rng(77)
+    small = rng.uniform(-1e-3, 1e-3, (3000, 3))                       # a 2 mm target ...
+    far = rng.uniform(-1e-3, 1e-3, (2500, 3)) + np.array([0.9, -0.4, 0.2])   # ... asked from a metre away (|alpha| ~ 1e5 scaled units)
+    mixed = np.vstack([rng.uniform(-0.2, 0.2, (1500, 3)), small[:700] + 1e-5])   # some near, some far
+    pts = [small, far, mixed]
+    src = np.array([1, 2, 2], dtype=np.int32); dst = np.array([0, 0, 1], dtype=np.int32)
+    fixed = np.array([1, 0, 0], dtype=np.int32)
+    e = mvicp.Engine(0)
+    try:
+        e.set_option("tile_mfma", mfma); e.set_option("nn_search_factor", factor)
+        e.set_frames(pts, None); e.set_graph(src, dst)
+        poses = np.stack([np.eye(4)] * 3)
+        for thresh in (np.float32(2.0), np.float32(0.05), np.float32(2.0)):
+            for r in range(3):
+                poses[1, :3, 3] += rng.normal(0, 1e-4, 3); poses[2, :3, 3] += rng.normal(0, 1e-4, 3)
+                counts, weights = e.correspond(poses, fixed, thresh, L.NN_TILE)
+                for k, (s, d) in enumerate(zip(src, dst)):
+                    f, sec, dist, w, _, _ = orc.correspond_edge(pts[s], poses[s], pts[d], poses[d], thresh)
+                    gf, gs, gd = e.get_correspondences(k)
+                    assert counts[k] == len(f), (factor, mfma, float(thresh), r, k)
+                    assert np.array_equal(gf, f) and np.array_equal(gs, sec) and np.array_equal(gd, dist), (factor, mfma, float(thresh), r, k)
+    finally:
+        e.close()
