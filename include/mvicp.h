@@ -180,7 +180,10 @@ int mvicp_closedform_point_to_plane(const double* src, const double* dst, const 
  * (nn_mfma_kernel) — 1: except in cache-aware rounds, 2: always, 0: never (the fp32 VALU screen of nn_tile_kernel); "mfma_kacc" (default
  * 34): allowance for the fp32 accumulation inside one matrix instruction, in units of 2^-24 x sum |terms| (34 = seventeen truncating
  * additions; lower values are a measured, not a proven, bound); "mfma_trig" (default 2): a lane with more screen hits than this in one
- * tile makes the wave confirm nearest-first and screen the tile again; "sel_bracket" (0/1, default 1): one-pass median select around last round's median
+ * tile makes the wave confirm nearest-first and screen the tile again; "mfma_lbt" (0/1, default 1): launches without any seed test a tile's box per
+ * lane before screening it; "nn_search_factor" (default 4; 0 = unbounded): the kernels look for a neighbour within this many cutoffs (a query the
+ * cutoff rejects keeps a seed and a temporal-cache bound; results are filtered by the cutoff afterwards, like the reference); "tie_rule" (0/1,
+ * default 1): exact distance ties are decided the way nanoflann decides them (first visited target; 0 = lowest original index); "sel_bracket" (0/1, default 1): one-pass median select around last round's median
  * once it has settled; "spec_eval" (0/1, default 1): mvicp_correspond queues the first linearization of the following
  * mvicp_optimize (same poses, previous solve's flags) behind its own kernels so the round waits once, not twice; "lin_share_p"
  * (0/1, default 1): the linearization reads the source points of an all-accepted edge from the shared sorted cloud; "nn_cell"

@@ -1009,6 +1009,7 @@ int mvicp_set_option(mvicp_ctx* c, const char* name, double value) try {
   if (std::strcmp(name, "tile_bounds") == 0) { c->tile_bounds = (int)value; return MVICP_OK; }
   if (std::strcmp(name, "tile_mu") == 0) { if (!(value > 0.0 && value <= 1.0)) { set_error("tile_mu outside (0, 1]"); return MVICP_ERR_ARG; } c->tile_mu = value; return MVICP_OK; }
   if (std::strcmp(name, "mfma_kacc") == 0) { if (!(value >= 1.0 && value <= 1024.0)) { set_error("mfma_kacc outside [1, 1024]"); return MVICP_ERR_ARG; } c->mfma_kacc = value; return MVICP_OK; }
+  if (std::strcmp(name, "mfma_lbt") == 0) { c->mfma_lbt = (int)value; return MVICP_OK; }
   if (std::strcmp(name, "mfma_trig") == 0) { c->mfma_trig = (int)value; return MVICP_OK; }
   if (std::strcmp(name, "tile_mfma") == 0) { c->tile_mfma = (int)value; return MVICP_OK; }
   if (std::strcmp(name, "tile_waves") == 0) { c->tile_waves = (int)value; return MVICP_OK; }

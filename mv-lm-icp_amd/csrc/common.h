@@ -231,6 +231,7 @@ struct mvicp_ctx {
   int tile_mfma = 1;               // tile method: 1 = the screen of an opened tile runs on the matrix pipe (nn_mfma.hip) except in cache-aware rounds, 2 = always,
                                    // 0 = never (the fp32 VALU screen of nn_tile.hip)
   double mfma_kacc = 34.0;         // nn_mfma.hip: allowance for the fp32 accumulation inside one matrix instruction, in units of 2^-24 x sum |terms| (see tau_pieces)
+  int mfma_lbt = 1;                // nn_mfma.hip: unseeded launches test every tile's box per lane before screening it (scan_block LBT)
   int mfma_trig = 2;               // nn_mfma.hip: a lane with more than this many screen hits in a tile triggers the nearest-first second screen
   int tile_waves = 0;              // nn_tile_kernel variant: waves per SIMD it is compiled for (0 = the measured best for the depth)
   double auto_prev_dist = 0.0; int auto_last_method = -1; double auto_settle = 0.5;   // MVICP_NN_AUTO policy state (api.cpp)

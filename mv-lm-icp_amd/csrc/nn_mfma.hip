@@ -225,8 +225,10 @@ __device__ __forceinline__ int pick_tile(unsigned long long pm, bool pend, float
 }
 
 // One block (level-0 node): its `nchild` tiles [first, first + nchild), one per lane.
-template <bool BND, bool CEN>
-__device__ void scan_block(const TileView& g, int first, int nchild, LaneM& L, const GroupM& G, Census& C, float kacc, int trig) {
+// LBT (unseeded launches only): the boxes of the block's tiles are parked in wave-private LDS and a tile is screened only if some lane's OWN box
+// test passes — with no seed the wave's largest threshold lets in twice the tiles any lane needs (42 against 21 per wave on cfg4 round 1).
+template <bool BND, bool CEN, bool LBT>
+__device__ void scan_block(const TileView& g, int first, int nchild, LaneM& L, const GroupM& G, Census& C, float kacc, int trig, float2* __restrict__ tbox) {
   const int lane = threadIdx.x & 63;
   const float inf = __int_as_float(0x7f800000);
   float ddf = inf, key = inf;
@@ -234,6 +236,7 @@ __device__ void scan_block(const TileView& g, int first, int nchild, LaneM& L, c
     const float* base = g.wide + g.off[0] + first + lane;
     const long long st = g.cnt[0];
     const float b0 = base[0], b1 = base[st], b2 = base[2 * st], b3 = base[3 * st], b4 = base[4 * st], b5 = base[5 * st];
+    if (LBT) { tbox[lane] = make_float2(b0, b3); tbox[FAN + lane] = make_float2(b1, b4); tbox[2 * FAN + lane] = make_float2(b2, b5); }
     const float e0 = fmaxf(fmaxf(b0 - G.hi[0], G.lo[0] - b3), 0.f);
     const float e1 = fmaxf(fmaxf(b1 - G.hi[1], G.lo[1] - b4), 0.f);
     const float e2 = fmaxf(fmaxf(b2 - G.hi[2], G.lo[2] - b5), 0.f);
@@ -242,6 +245,11 @@ __device__ void scan_block(const TileView& g, int first, int nchild, LaneM& L, c
     const float k1 = fmaxf(fmaxf(b1 - G.c[1], G.c[1] - b4), 0.f);
     const float k2 = fmaxf(fmaxf(b2 - G.c[2], G.c[2] - b5), 0.f);
     key = k0 * k0 + k1 * k1 + k2 * k2;                 // visiting order only
+  }
+  if (LBT) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   MV_CEN(C.box += (unsigned)nchild);
   const float sm = G.slack + G.mu;
@@ -301,8 +309,15 @@ __device__ void scan_block(const TileView& g, int first, int nchild, LaneM& L, c
       a_nxt = g.mf_ops[(size_t)(first + c_nxt) * 64 + lane];
     }
     const int tile = first + c_cur;
-    const bool any = tile_scan<BND, CEN>(g, tile, __builtin_bit_cast(h8, a_cur), L, K, c_nxt < 0, C);
-    MV_CEN(C.cand += (unsigned)min(LEAF, g.n - tile * LEAF));
+    bool any = false, need = true;
+    if (LBT) {
+      const float2 u = tbox[c_cur], v = tbox[FAN + c_cur], w = tbox[2 * FAN + c_cur];
+      need = __ballot(L.active && box_lb32(L, u.x, v.x, w.x, u.y, v.y, w.y) <= box_thr(L.rbest, sm)) != 0ull;
+    }
+    if (need) {
+      any = tile_scan<BND, CEN>(g, tile, __builtin_bit_cast(h8, a_cur), L, K, c_nxt < 0, C);
+      MV_CEN(C.cand += (unsigned)min(LEAF, g.n - tile * LEAF));
+    }
     if (any) {
       gmax = box_thr(wave_max_f(L.active ? L.rbest : 0.f), sm);
       pend = pend && ddf <= gmax;
@@ -323,9 +338,9 @@ __device__ void scan_block(const TileView& g, int first, int nchild, LaneM& L, c
 }
 
 // Levels >= 1: as nn_tile.hip's visit (coarse cull against the patch box, per-lane box test, children nearest-first).
-template <int LEVEL, bool BND, bool CEN>
+template <int LEVEL, bool BND, bool CEN, bool LBT>
 __device__ void visit(const TileView& g, int first, int nchild, LaneM& L, const GroupM& G, float2* __restrict__ sbox, Census& C) {
-  if constexpr (LEVEL == 0) { scan_block<BND, CEN>(g, first, nchild, L, G, C, G.kacc, G.trig); return; } else {
+  if constexpr (LEVEL == 0) { scan_block<BND, CEN, LBT>(g, first, nchild, L, G, C, G.kacc, G.trig, sbox + 2 * 3 * FAN); return; } else {
   const int lane = threadIdx.x & 63;
   const float inf = __int_as_float(0x7f800000);
   float b0 = inf, b1 = inf, b2 = inf, b3 = -inf, b4 = -inf, b5 = -inf;
@@ -377,15 +392,15 @@ __device__ void visit(const TileView& g, int first, int nchild, LaneM& L, const 
     const float lb = box_lb32(L, c0, c1, c2, c3, c4, c5);
     if (__ballot(L.active && lb <= box_thr(L.rbest, sm)) == 0ull) continue;
     const int cf = (first + c) * FAN;
-    visit<(LEVEL > 0 ? LEVEL - 1 : 0), BND, CEN>(g, cf, min(FAN, g.cnt[LEVEL > 0 ? LEVEL - 1 : 0] - cf), L, G, sbox, C);
+    visit<(LEVEL > 0 ? LEVEL - 1 : 0), BND, CEN, LBT>(g, cf, min(FAN, g.cnt[LEVEL > 0 ? LEVEL - 1 : 0] - cf), L, G, sbox, C);
     gmax = box_thr(wave_max_f(L.active ? L.rbest : 0.f), sm);
   }
   }
 }
 
-template <int WPE, int TOP, bool BND, bool CEN>
+template <int WPE, int TOP, bool BND, bool CEN, bool LBT>
 __global__ __launch_bounds__(NT, WPE) void nn_mfma_kernel(const TileJob* __restrict__ jobs, double bound, double search, unsigned long long* __restrict__ stats) {
-  __shared__ float2 s_box[NT / 64][2 * 3 * FAN];   // levels 1 and 2: 64 child boxes x 24 B each, per wave
+  __shared__ float2 s_box[NT / 64][(LBT ? 3 : 2) * 3 * FAN];   // levels 1 and 2 (LBT: and the tiles of the current block): 64 child boxes x 24 B each, per wave
   __shared__ double sxf[kEdgeXf];
   const TileJob& job = jobs[blockIdx.y];
   if (blockIdx.x * NT >= job.n) return;
@@ -483,13 +498,13 @@ __global__ __launch_bounds__(NT, WPE) void nn_mfma_kernel(const TileJob* __restr
   Census C = {0u, 0u, 0u, 0u, 0u, 0u};
   const int top = g.levels - 1;
   float2* sbox = s_box[wave];
-  if (TOP >= 0) visit<(TOP >= 0 ? TOP : 0), BND, CEN>(g, 0, g.cnt[TOP >= 0 ? TOP : 0], L, G, sbox, C);
+  if (TOP >= 0) visit<(TOP >= 0 ? TOP : 0), BND, CEN, LBT>(g, 0, g.cnt[TOP >= 0 ? TOP : 0], L, G, sbox, C);
   else switch (top) {
-    case 0: visit<0, BND, CEN>(g, 0, g.cnt[0], L, G, sbox, C); break;
-    case 1: visit<1, BND, CEN>(g, 0, g.cnt[1], L, G, sbox, C); break;
-    case 2: visit<2, BND, CEN>(g, 0, g.cnt[2], L, G, sbox, C); break;
-    case 3: visit<3, BND, CEN>(g, 0, g.cnt[3], L, G, sbox, C); break;
-    default: visit<4, BND, CEN>(g, 0, g.cnt[4], L, G, sbox, C); break;
+    case 0: visit<0, BND, CEN, LBT>(g, 0, g.cnt[0], L, G, sbox, C); break;
+    case 1: visit<1, BND, CEN, LBT>(g, 0, g.cnt[1], L, G, sbox, C); break;
+    case 2: visit<2, BND, CEN, LBT>(g, 0, g.cnt[2], L, G, sbox, C); break;
+    case 3: visit<3, BND, CEN, LBT>(g, 0, g.cnt[3], L, G, sbox, C); break;
+    default: visit<4, BND, CEN, LBT>(g, 0, g.cnt[4], L, G, sbox, C); break;
   }
   if (L.active) {
     const int out = i;   // sorted order of the source cloud
@@ -627,10 +642,14 @@ int launch_nn_mfma_edges(mvicp_ctx* c, double d2_bound, bool with_bounds, bool w
     const dim3 grid((max_n + NT - 1) / NT, (unsigned)jobs.size());
     int top = jobs[0].dst.levels - 1;   // same depth everywhere -> the traversal specialised for it
     for (const TileJob& j : jobs) if (j.dst.levels - 1 != top) top = -1;
-#define MVICP_MFMA_K(W, T, B) do { if (d_stats) hipLaunchKernelGGL((nn_mfma_kernel<W, T, B, true>), grid, dim3(NT), 0, c->stream, d_jobs, d2_bound, search_bound(c, d2_bound), d_stats); \
-                                 else hipLaunchKernelGGL((nn_mfma_kernel<W, T, B, false>), grid, dim3(NT), 0, c->stream, d_jobs, d2_bound, search_bound(c, d2_bound), d_stats); } while (0)
+#define MVICP_MFMA_L(W, T, B, C, Lb) hipLaunchKernelGGL((nn_mfma_kernel<W, T, B, C, Lb>), grid, dim3(NT), 0, c->stream, d_jobs, d2_bound, search_bound(c, d2_bound), d_stats)
+#define MVICP_MFMA_K(W, T, B) do { if (d_stats) MVICP_MFMA_L(W, T, B, true, false); else MVICP_MFMA_L(W, T, B, false, false); } while (0)
     const int waves = c->tile_waves;
-    if (with_bounds) {
+    bool unseeded = c->mfma_lbt != 0;
+    for (const TileJob& j : jobs) if (j.seed) unseeded = false;
+    if (unseeded && !with_bounds && top == 2 && !d_stats) MVICP_MFMA_L(5, 2, false, false, true);   // no seed anywhere: per-lane box test per tile (scan_block)
+    else if (unseeded && !with_bounds && top == 2) MVICP_MFMA_L(5, 2, false, true, true);
+    else if (with_bounds) {
       if (top == 2) MVICP_MFMA_K(5, 2, true); else MVICP_MFMA_K(5, -1, true);
     }
     else if (top == 2 && waves == 6) MVICP_MFMA_K(6, 2, false);
@@ -638,6 +657,7 @@ int launch_nn_mfma_edges(mvicp_ctx* c, double d2_bound, bool with_bounds, bool w
     else if (top == 2) MVICP_MFMA_K(5, 2, false);
     else if (top == 1) MVICP_MFMA_K(5, 1, false);
     else MVICP_MFMA_K(5, -1, false);
+#undef MVICP_MFMA_L
 #undef MVICP_MFMA_K
   }
   MV_HIP(hipGetLastError());

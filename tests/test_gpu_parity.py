@@ -719,7 +719,7 @@ def test_tile_kernel_lower_bounds_feed_the_temporal_cache(orc, mu):
     {"tile_cache": 0}, {"tile_cache": 0, "list_reuse": 0}, {"tile_cache": 1, "list_reuse": 0}, {"tile_cache": 1, "tile_mu": 0.5}, {"tile_cache": 1, "auto_settle": 5.0},
     # the matrix-pipe tile kernel (nn_mfma.hip) against the VALU one (nn_tile.hip), in every role, and its own tunables
     {"tile_mfma": 0}, {"tile_mfma": 2}, {"tile_mfma": 2, "tile_bounds": 2}, {"tile_mfma": 0, "tile_bounds": 2}, {"tile_mfma": 2, "tile_cache": 1, "tile_mu": 0.5},
-    {"mfma_trig": 0}, {"mfma_trig": 33}, {"mfma_kacc": 4}, {"mfma_kacc": 512}, {"tile_mfma": 2, "tile_seed": 0}, {"tile_mfma": 2, "tile_waves": 6}, {"tile_mfma": 2, "tile_waves": 4},
+    {"mfma_trig": 0}, {"mfma_trig": 33}, {"mfma_kacc": 4}, {"mfma_kacc": 512}, {"tile_mfma": 2, "tile_seed": 0}, {"mfma_lbt": 0}, {"mfma_lbt": 0, "tile_seed": 0}, {"tile_mfma": 2, "tile_waves": 6}, {"tile_mfma": 2, "tile_waves": 4},
 ])
 def test_tuning_options_never_change_results(opts):
     """Every speed knob (kernel variants, seeding, cell pruning, AUTO hand-over policy, caches) must leave the whole ICP
