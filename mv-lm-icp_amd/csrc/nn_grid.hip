@@ -43,7 +43,10 @@ namespace mvicp {
 
 namespace {
 
-constexpr int NT = 256;
+#ifndef MVICP_GRID_THREADS
+#define MVICP_GRID_THREADS 256
+#endif
+constexpr int NT = MVICP_GRID_THREADS;
 constexpr unsigned long long EMPTY = ~0ull;
 
 struct HashEntry { unsigned long long key; unsigned int start, count; };

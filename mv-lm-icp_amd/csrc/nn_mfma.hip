@@ -29,6 +29,11 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 
+#ifndef MVICP_MFMA_THREADS
+#define MVICP_MFMA_THREADS 128
+#endif
+constexpr int MT = MVICP_MFMA_THREADS;   // threads per workgroup of nn_mfma_kernel: its waves share nothing but the edge transform, and small workgroups let the
+                                         // dispatcher refill a SIMD wave by wave (256 -> 128 threads: -4.5 % on cfg4 rounds 2-5; 64: -4 %)
 static_assert(LEAF == 32 && FAN == 64, "the fragment maps below are those of 32-point tiles in blocks of 64");
 constexpr float kQueryRange = 4096.f;  // a query farther than this from the block's origin (scaled, per axis) confirms the block's opened tiles exhaustively
 // fp32 accumulation inside the instruction: 16 products (exact: 11 x 11 bits) + C summed by at most 17 additions, each at worst a truncating
@@ -399,16 +404,16 @@ __device__ void visit(const TileView& g, int first, int nchild, LaneM& L, const 
 }
 
 template <int WPE, int TOP, bool BND, bool CEN, bool LBT>
-__global__ __launch_bounds__(NT, WPE) void nn_mfma_kernel(const TileJob* __restrict__ jobs, double bound, double search, unsigned long long* __restrict__ stats) {
-  __shared__ float2 s_box[NT / 64][(LBT ? 3 : 2) * 3 * FAN];   // levels 1 and 2 (LBT: and the tiles of the current block): 64 child boxes x 24 B each, per wave
+__global__ __launch_bounds__(MT, WPE) void nn_mfma_kernel(const TileJob* __restrict__ jobs, double bound, double search, unsigned long long* __restrict__ stats) {
+  __shared__ float2 s_box[MT / 64][(LBT ? 3 : 2) * 3 * FAN];   // levels 1 and 2 (LBT: and the tiles of the current block): 64 child boxes x 24 B each, per wave
   __shared__ double sxf[kEdgeXf];
   const TileJob& job = jobs[blockIdx.y];
-  if (blockIdx.x * NT >= job.n) return;
+  if (blockIdx.x * MT >= job.n) return;
   const bool has_xf = job.xf != nullptr;
   if (has_xf && threadIdx.x < kEdgeXf) sxf[threadIdx.x] = job.xf[threadIdx.x];
   __syncthreads();
   const int wave = threadIdx.x >> 6;
-  const int i = blockIdx.x * NT + threadIdx.x;
+  const int i = blockIdx.x * MT + threadIdx.x;
   if ((i & ~63) >= job.n) return;  // whole wave beyond the end
   const TileView& g = job.dst;
 
@@ -468,7 +473,7 @@ __global__ __launch_bounds__(NT, WPE) void nn_mfma_kernel(const TileJob* __restr
   }
   if (BND && job.cache && __ballot(L.active) == 0ull) {
     if (stats) {   // census (profiling only): all 64 lanes answered by the cache
-      const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + wave;
+      const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (MT / 64) + wave;
       const unsigned long long hits = __popcll(__ballot(n_hit != 0u));
       if ((threadIdx.x & 63) == 0) stats[8 * slot + 3] = hits;
     }
@@ -517,7 +522,7 @@ __global__ __launch_bounds__(NT, WPE) void nn_mfma_kernel(const TileJob* __restr
     if ((BND ? L.second == L.best : L.tie) && L.bpos >= 0) tie_report(job.tie, (unsigned int)i);
   }
   if (CEN && stats && (threadIdx.x & 63) == 0) {
-    const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + wave;
+    const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (MT / 64) + wave;
     const unsigned long long act = (unsigned long long)min(64, job.n - (i & ~63));
     stats[8 * slot] = C.cand; stats[8 * slot + 1] = C.box; stats[8 * slot + 2] = (unsigned long long)C.cand * act;
     stats[8 * slot + 4] = C.rescreen; stats[8 * slot + 5] = C.rounds; stats[8 * slot + 6] = C.blocks;
@@ -525,11 +530,11 @@ __global__ __launch_bounds__(NT, WPE) void nn_mfma_kernel(const TileJob* __restr
   if (CEN && stats) {   // fp64 confirmations: per lane
     unsigned int v = C.conf;
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if ((threadIdx.x & 63) == 0) stats[8 * (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + wave) + 7] = v;
+    if ((threadIdx.x & 63) == 0) stats[8 * (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (MT / 64) + wave) + 7] = v;
   }
   if (stats && BND && job.cache) {
     const unsigned long long hits = __popcll(__ballot(n_hit != 0u));
-    if ((threadIdx.x & 63) == 0) stats[8 * (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + wave) + 3] = hits;
+    if ((threadIdx.x & 63) == 0) stats[8 * (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (MT / 64) + wave) + 3] = hits;
   }
 }
 
@@ -635,14 +640,14 @@ int launch_nn_mfma_edges(mvicp_ctx* c, double d2_bound, bool with_bounds, bool w
   TileJob* d_jobs = nullptr;
   MV_CHECK(cached_upload(c, jobs[0].xf ? "tile_jobs" : "tile_jobs_raw", jobs.data(), sizeof(TileJob) * jobs.size(), (void**)&d_jobs));
   unsigned long long* d_stats = nullptr;
-  const size_t slots = (size_t)((max_n + NT - 1) / NT) * jobs.size() * (NT / 64);
+  const size_t slots = (size_t)((max_n + MT - 1) / MT) * jobs.size() * (MT / 64);
   MV_CHECK(census_scratch(c, slots, &d_stats));
   {
     ProfScope ps(c, "nn_mfma", 36.0 * nq);  // query read 24 B + result write 12 B; tile-operand / box bytes come from the census
-    const dim3 grid((max_n + NT - 1) / NT, (unsigned)jobs.size());
+    const dim3 grid((max_n + MT - 1) / MT, (unsigned)jobs.size());
     int top = jobs[0].dst.levels - 1;   // same depth everywhere -> the traversal specialised for it
     for (const TileJob& j : jobs) if (j.dst.levels - 1 != top) top = -1;
-#define MVICP_MFMA_L(W, T, B, C, Lb) hipLaunchKernelGGL((nn_mfma_kernel<W, T, B, C, Lb>), grid, dim3(NT), 0, c->stream, d_jobs, d2_bound, search_bound(c, d2_bound), d_stats)
+#define MVICP_MFMA_L(W, T, B, C, Lb) hipLaunchKernelGGL((nn_mfma_kernel<W, T, B, C, Lb>), grid, dim3(MT), 0, c->stream, d_jobs, d2_bound, search_bound(c, d2_bound), d_stats)
 #define MVICP_MFMA_K(W, T, B) do { if (d_stats) MVICP_MFMA_L(W, T, B, true, false); else MVICP_MFMA_L(W, T, B, false, false); } while (0)
     const int waves = c->tile_waves;
     bool unseeded = c->mfma_lbt != 0;

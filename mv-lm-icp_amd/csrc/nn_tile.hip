@@ -39,6 +39,11 @@ namespace {
 
 typedef float f2v __attribute__((ext_vector_type(2)));
 
+#ifndef MVICP_TILE_THREADS
+#define MVICP_TILE_THREADS 128
+#endif
+constexpr int TT = MVICP_TILE_THREADS;   // threads per workgroup of nn_tile_kernel
+
 struct Lane {          // per-lane query state
   double qx, qy, qz, best;
   // fp32 copies for the screens, kept as splatted PAIRS (the packed-math operands of leaf_scan).  As four adjacent floats
@@ -237,17 +242,17 @@ __device__ void visit(const TileView& g, int first, int nchild, Lane& L, const G
 // TOP >= 0: every target of the launch has exactly TOP + 1 hierarchy levels (the common case: clouds of similar size), so
 // only that traversal is compiled in; TOP = -1: generic (per-job switch over the depth).
 template <int WPE, int TOP, bool BND>
-__global__ __launch_bounds__(NT, WPE) void nn_tile_kernel(const TileJob* __restrict__ jobs, double bound, double search, unsigned long long* __restrict__ stats) {
-  __shared__ TileLds s_tile[NT / 64];
-  __shared__ float2 s_box[NT / 64][2 * 3 * FAN];   // levels 1 and 2: 64 child boxes x 24 B each, per wave
+__global__ __launch_bounds__(TT, WPE) void nn_tile_kernel(const TileJob* __restrict__ jobs, double bound, double search, unsigned long long* __restrict__ stats) {
+  __shared__ TileLds s_tile[TT / 64];
+  __shared__ float2 s_box[TT / 64][2 * 3 * FAN];   // levels 1 and 2: 64 child boxes x 24 B each, per wave
   __shared__ double sxf[kEdgeXf];
   const TileJob& job = jobs[blockIdx.y];
-  if (blockIdx.x * NT >= job.n) return;
+  if (blockIdx.x * TT >= job.n) return;
   const bool has_xf = job.xf != nullptr;
   if (has_xf && threadIdx.x < kEdgeXf) sxf[threadIdx.x] = job.xf[threadIdx.x];
   __syncthreads();
   const int wave = threadIdx.x >> 6;
-  const int i = blockIdx.x * NT + threadIdx.x;
+  const int i = blockIdx.x * TT + threadIdx.x;
   if ((i & ~63) >= job.n) return;  // whole wave beyond the end
   const TileView& g = job.dst;
 
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(NT, WPE) void nn_tile_kernel(const TileJob* __restr
   }
   if (BND && job.cache && __ballot(L.active) == 0ull) {
     if (stats) {   // census (profiling only): all 64 lanes answered by the cache
-      const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + wave;
+      const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (TT / 64) + wave;
       const unsigned long long hits = __popcll(__ballot(n_hit != 0u));
       if ((threadIdx.x & 63) == 0) stats[8 * slot + 3] = hits;
     }
@@ -363,13 +368,13 @@ __global__ __launch_bounds__(NT, WPE) void nn_tile_kernel(const TileJob* __restr
   }
   if (stats && (threadIdx.x & 63) == 0) {
     // wave-uniform counters: candidates examined PER LANE x active lanes, boxes tested per wave
-    const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + wave;
+    const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (TT / 64) + wave;
     const unsigned long long act = (unsigned long long)min(64, job.n - (i & ~63));
     stats[8 * slot] = n_cand; stats[8 * slot + 1] = n_box; stats[8 * slot + 2] = (unsigned long long)n_cand * act;
   }
   if (stats && BND && job.cache) {
     const unsigned long long hits = __popcll(__ballot(n_hit != 0u));
-    if ((threadIdx.x & 63) == 0) stats[8 * (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + wave) + 3] = hits;
+    if ((threadIdx.x & 63) == 0) stats[8 * (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (TT / 64) + wave) + 3] = hits;
   }
 }
 
@@ -443,14 +448,14 @@ int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound, bool with_bounds, bool w
   TileJob* d_jobs = nullptr;
   MV_CHECK(cached_upload(c, jobs[0].xf ? "tile_jobs" : "tile_jobs_raw", jobs.data(), sizeof(TileJob) * jobs.size(), (void**)&d_jobs));
   unsigned long long* d_stats = nullptr;
-  const size_t slots = (size_t)((max_n + NT - 1) / NT) * jobs.size() * (NT / 64);
+  const size_t slots = (size_t)((max_n + TT - 1) / TT) * jobs.size() * (TT / 64);
   MV_CHECK(census_scratch(c, slots, &d_stats));
   {
     ProfScope ps(c, "nn_tile", 36.0 * nq);  // query read 24 B + result write 12 B; candidate / box bytes come from the census
-    const dim3 grid((max_n + NT - 1) / NT, (unsigned)jobs.size());
+    const dim3 grid((max_n + TT - 1) / TT, (unsigned)jobs.size());
     int top = jobs[0].dst.levels - 1;   // same depth everywhere -> the traversal specialised for it
     for (const TileJob& j : jobs) if (j.dst.levels - 1 != top) top = -1;
-#define MVICP_TILE_K(W, T, B) hipLaunchKernelGGL((nn_tile_kernel<W, T, B>), grid, dim3(NT), 0, c->stream, d_jobs, d2_bound, search_bound(c, d2_bound), d_stats)
+#define MVICP_TILE_K(W, T, B) hipLaunchKernelGGL((nn_tile_kernel<W, T, B>), grid, dim3(TT), 0, c->stream, d_jobs, d2_bound, search_bound(c, d2_bound), d_stats)
     const int waves = c->tile_waves;   // 0 = pick: 7 waves per SIMD for the depth-3 build, 6 otherwise
     // depth-3 build: 7 waves per SIMD (no spills at 66 VGPRs); 6 and 8 measure 4-10 % slower (profiles/r03_tile_ab.txt)
     if (with_bounds) {   // hand-over round: one more fp64 register pair per lane, so one wave per SIMD fewer
