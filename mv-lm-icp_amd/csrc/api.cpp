@@ -653,6 +653,11 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   int* hd = hn + E;
   std::memcpy(hn, nsrc.data(), sizeof(int) * E);
 
+  if (c->tie_rule) {   // a cloud uploaded after mvicp_set_graph has no tree yet (the reference builds its index lazily as well, frame.cpp:188-193)
+    std::vector<int> need;
+    for (int e = 0; e < E; ++e) if (c->active[e] && !c->frames[c->edst[e]].has_tie) need.push_back(c->edst[e]);
+    if (!need.empty()) MV_CHECK(ensure_tie_trees(c, need));
+  }
   const double bound = sqrt_bound((double)thresh);
   double t_mark = now_ms();
   auto mark = [&](const char* nm) { if (c->profile) { const double t = now_ms(); ProfEntry& pe = c->prof[nm]; pe.ms += t - t_mark; pe.launches += 1; t_mark = t; } };

@@ -17,7 +17,8 @@ namespace mvicp {
 
 namespace {
 
-constexpr int TIE_STACK = 192;   // nanoflann recurses once per level; a balanced tree of 2^30 points has 30 levels, skewed clouds more
+constexpr int TIE_STACK = 128;   // pending subtrees: at most one per level of the descent; a balanced tree of 2^30 points has 30 levels, skewed clouds more
+                                 // (40 B each, in scratch memory: 5 KB per lane of this small kernel only)
 
 __device__ __forceinline__ void xf_point(const double* __restrict__ x, double p0, double p1, double p2, double& q0, double& q1, double& q2) {
   double g[3], u[3];
