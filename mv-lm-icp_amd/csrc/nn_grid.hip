@@ -3,9 +3,9 @@
 // Replaces nanoflann's KD-tree (include/nanoflann.hpp:859-867 build, :900-911/:1199-1247 search) behind
 // Frame::getClosestPoint (src/internal/frame.cpp:187-206) and the per-query transform of
 // Frame::computeClosestPointsToNeighbours (frame.cpp:117-118,131,136).  Same bit-exact contract as K1:
-// fp64 distance d0*d0+d1*d1+d2*d2 left to right, no fma (include/frame.h:70-76), lowest original index
-// wins exact ties — independent of traversal order because every comparison is the total order
-// (d2, index).
+// fp64 distance d0*d0+d1*d1+d2*d2 left to right, no fma (include/frame.h:70-76).  Inside the kernels the lowest original
+// index wins exact ties — independent of traversal order because every comparison is the total order (d2, index) — and a
+// query whose best distance was met twice (second == best) is reported to nn_tie.hip, which decides it the way nanoflann does.
 //
 // Per cloud, built ONCE at upload (clouds are static in their local frame, like the reference's lazily
 // built tree, frame.cpp:188-193):

@@ -1,13 +1,13 @@
 // K2m — the wave-cooperative exact 1-NN of nn_tile.hip with the screen of an opened tile on the MATRIX pipe.
 //
 // Same contract as K1 / K2 / K2t (bit-exact indices and squared distances of the reference's Frame::getClosestPoint,
-// src/internal/frame.cpp:187-206, metric include/frame.h:70-76, query transform frame.cpp:117-118,131,136; lowest original index wins
-// exact ties), same job table, same outputs (neighbour, d2, BND lower bounds, in-place list maintenance: nn_tile_common.h, nn_list.h).
+// src/internal/frame.cpp:187-206, metric include/frame.h:70-76, query transform frame.cpp:117-118,131,136; exact ties: the lowest original
+// index keeps the place and the query is reported to nn_tie.hip, which decides it the way nanoflann does), same job table, same outputs (neighbour, d2, BND lower bounds, in-place list maintenance: nn_tile_common.h, nn_list.h).
 //
 // nn_tile.hip is VALU-issue bound and a third of its instructions are the fp32 screen of the 32 points of every opened tile by all 64
 // lanes, of which ~15 need the tile (profiles/r03_tile_ab.txt runs D, F, G).  Here that screen is ONE v_mfma_f32_32x32x16_f16 per 32
 // queries: for a tile's points i and the wave's queries j, in coordinates local to the tile's BLOCK (64 tiles = one level-0 node of
-// the 64-wide hierarchy; origin c, power-of-two scale so that the block's points lie in [-128, 128]^3),
+// the 64-wide hierarchy; origin c, power-of-two scale so that the block's points lie in [-127, 127]^3),
 //     V_ij = |b_i|^2 - 2 a_j . b_i - T_j          (norm expansion of |a_j - b_i|^2 minus the query's own threshold)
 // with every factor split into f16 pieces (b = bh + bl, a = ah + al, |b|^2 = n1 + n2 + n3, -T = 4096 t1 + t2 + t3): 15 of the 16 k-slots
 //     A (points, PRECOMPUTED per cloud, 16 B per lane per tile):  [-2bh.xyz | -2bl.xyz | n1 n2 || -2bh.xyz | n3 | 4096 1 1 | 0]
@@ -17,8 +17,9 @@
 // rigorous allowance for everything the pieces drop (al . bl, the split residuals, the fp32 accumulation inside the instruction: kAcc
 // ulps of the sum of the |terms|, see tau_pieces), so a point is skipped only when it is provably farther than the lane's running best;
 // the slot of the running best itself (the seed: last round's neighbour) is masked, so in a converged round hardly any lane leaves the
-// screen.  No LDS staging, no per-lane box tests below the block level, confirmations read the 32-B sorted records straight from
-// memory.  Levels >= 1 of the hierarchy are walked exactly as in nn_tile.hip.
+// screen.  No LDS staging, no per-lane box tests below the block level (except in launches without any seed: the LBT build, scan_block),
+// confirmations read the 32-B sorted records straight from memory.  Levels >= 1 of the hierarchy are walked exactly as in nn_tile.hip.
+// Workgroups are 128 threads: the waves share nothing but the edge transform.
 #include "nn_tile_common.h"
 
 namespace mvicp {
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(MT, WPE) void nn_mfma_kernel(const TileJob* __restr
     G.m = m;
     G.kacc = job.kacc; G.trig = job.trig;
   }
-  L.rbest = L.active ? (float)sqrt(L.best) * 1.000001f : 0.f;
+  L.rbest = L.active ? sqrt_up(L.best) : 0.f;   // (fp32: an fp64 sqrt is ~30 instructions; a denormal best only loses what the guard bands cover many times over)
   Census C = {0u, 0u, 0u, 0u, 0u, 0u};
   const int top = g.levels - 1;
   float2* sbox = s_box[wave];
@@ -539,8 +540,9 @@ __global__ __launch_bounds__(MT, WPE) void nn_mfma_kernel(const TileJob* __restr
 }
 
 // ---- host: f16 pieces of the targets (exact arithmetic, so the error terms in the block records are maxima, not estimates) ----
-unsigned short f16_bits(double x) {   // round to nearest even; |x| < 65520
+unsigned short f16_bits(double x) {   // round to nearest even; |x| < 65520 (anything else, NaN included: the largest finite value)
   if (x == 0.0) return 0;
+  if (!(std::fabs(x) < 65520.0)) return (unsigned short)((x < 0 ? 0x8000 : 0) | 0x7bff);
   const unsigned short sign = x < 0 ? 0x8000 : 0;
   const double a = std::fabs(x);
   int e;

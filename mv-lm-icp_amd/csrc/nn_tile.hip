@@ -2,7 +2,8 @@
 //
 // Same contract as K1/K2 (bit-exact indices and squared distances of the reference's
 // Frame::getClosestPoint, src/internal/frame.cpp:187-206, metric include/frame.h:70-76, query transform
-// frame.cpp:117-118,131,136; lowest original index wins exact ties).
+// frame.cpp:117-118,131,136; on an exact tie the lowest original index keeps the place and the query is reported to nn_tie.hip, which decides it
+// the way nanoflann does).
 //
 // Both clouds are stored in a balanced k-d order whose aligned runs of 32 * 2^k points are subtrees (nn_grid.hip, kd_order; or
 // sorted by the Hilbert index of their grid cell, grid_curve 1: ~1.7x more tiles opened per wave).  A WAVE owns 64
