@@ -1067,6 +1067,7 @@ def test_far_queries_and_unbounded_search(orc, factor, mfma):
     small = rng.uniform(-1e-3, 1e-3, (3000, 3))                       # a 2 mm target ...
     far = rng.uniform(-1e-3, 1e-3, (2500, 3)) + np.array([0.9, -0.4, 0.2])   # ... asked from a metre away (|alpha| ~ 1e5 scaled units)
     mixed = np.vstack([rng.uniform(-0.2, 0.2, (1500, 3)), small[:700] + 1e-5])   # some near, some far
+    # (the near ones are IN RANGE of the 2 mm block with a threshold of metres: -T is beyond the f16 pieces and the lane must admit everything)
     pts = [small, far, mixed]
     src = np.array([1, 2, 2], dtype=np.int32); dst = np.array([0, 0, 1], dtype=np.int32)
     fixed = np.array([1, 0, 0], dtype=np.int32)
