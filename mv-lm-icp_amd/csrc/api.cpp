@@ -79,7 +79,8 @@ int scratch_upload(mvicp_ctx* c, const void* src, size_t bytes, void** dptr) {
 
 ProfScope::ProfScope(mvicp_ctx* ctx, const char* nm, double bytes) : c(ctx), name(nm), on(ctx->profile) {
   // level 2: only the two roofline scopes (every event pair is two extra queue packets between kernels)
-  if (on && ctx->profile_level >= 2 && std::strncmp(nm, "nn_", 3) != 0 && std::strcmp(nm, "linearize") != 0 && std::strcmp(nm, "comm") != 0) on = false;
+  if (on && ctx->profile_level >= 2 && ((std::strncmp(nm, "nn_", 3) != 0 && std::strcmp(nm, "linearize") != 0 && std::strcmp(nm, "comm") != 0) ||
+                                        std::strcmp(nm, "nn_tie") == 0)) on = false;   // (the tie fix-up is a few microseconds per moving round: not worth two packets)
   if (!on) return;
   ProfEntry& pe = c->prof[name];
   auto get = [&]() {
@@ -515,7 +516,7 @@ int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) t
   c->d_rel = c->d_ctl + c->ctl_r2_off; c->d_a = c->d_rel + (size_t)E * kEdgeRel;
   MV_CHECK(dev_alloc(&c->d_nn_idx, cap)); MV_CHECK(dev_alloc(&c->d_nn_d2, cap)); MV_CHECK(dev_alloc(&c->d_nn_lb, cap));
   c->nn_cache_valid = false; c->prev_q.assign((size_t)E * 12, 0.0); c->nn_cache_edge.assign(E, 0);
-  c->auto_prev_dist = 0.0; c->auto_last_method = -1;
+  c->auto_prev_dist = 0.0; c->auto_last_method = -1; c->corr_tie_seen = c->corr_far_seen = 1u;
   MV_CHECK(dev_alloc(&c->d_first, cap)); MV_CHECK(dev_alloc(&c->d_second, cap)); MV_CHECK(dev_alloc(&c->d_cd2, cap));
   MV_CHECK(dev_alloc(&c->d_stream, 10 * cap));
   MV_CHECK(dev_alloc(&c->d_qpos, cap));
@@ -544,7 +545,11 @@ int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) t
     c->far_cap = cap;
   }
   MV_CHECK(warm_nn_grid(c)); MV_CHECK(warm_nn_tile(c)); MV_CHECK(warm_nn_mfma(c));
-  if (c->tie_rule) MV_CHECK(ensure_tie_trees(c, std::vector<int>(dst, dst + n_edges)));   // the reference's own trees over the targets: they decide exact distance ties
+  if (c->tie_rule) {   // the reference's own trees over the targets of the edges THIS RANK owns: they decide exact distance ties (the others are never searched here)
+    std::vector<int> need;
+    for (int e = 0; e < E; ++e) if (c->owned[e]) need.push_back(dst[e]);
+    MV_CHECK(ensure_tie_trees(c, need));
+  }
   MV_CHECK(dev_alloc(&c->d_median, E));
   MV_CHECK(dev_alloc(&c->d_chunk_edge, (size_t)c->n_chunks)); MV_CHECK(dev_alloc(&c->d_chunk_start, (size_t)c->n_chunks));
   MV_CHECK(dev_alloc(&c->d_chunk_first, E + 1));
@@ -593,6 +598,7 @@ int mvicp_reset_history(mvicp_ctx* c) try {
   c->prev_q.assign((size_t)E * 12, 0.0); c->prev_xf.assign((size_t)E * 24, 0.0);
   c->nn_cache_edge.assign(E, 0);                      // no seeds, no temporal cache: d_nn_idx / d_nn_lb are dead until the next search rewrites them
   c->auto_prev_dist = 0.0; c->auto_last_method = -1; c->last_rms = -1.0; c->prev_grid_kernel = false;
+  c->corr_tie_seen = c->corr_far_seen = 1u;
   c->list_valid.assign(E, 0);                          // every list is re-compacted and re-gathered
   c->sel_med1.assign(E, -1.0); c->sel_med2.assign(E, -1.0);
   c->spec_ready = false; c->spec_arm = false; c->spec_flags_valid = false;
@@ -740,13 +746,15 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   // A search whose every edge has last round's exact transform and a valid list reproduces every query bit for bit: no list can
   // change, so the (data-dependent, early-exiting) list-maintenance kernels — dirty-flag reduction, compaction, gather — are not
   // even launched.
-  bool nothing_can_change = method == MVICP_NN_GRID && c->list_reuse && !c->nn_tree_only && !c->nn_skip_far && same_active_set;
+  // (not with the cell-staging variant: nn_cell_kernel has no bit-identical-query shortcut, so a fixed-point round is not a pure no-op there)
+  bool nothing_can_change = method == MVICP_NN_GRID && c->list_reuse && !c->nn_tree_only && !c->nn_skip_far && same_active_set && !c->nn_cell;
   for (int e = 0; e < E && nothing_can_change; ++e)
     if (c->active[e] && !(same_edge[e] && hd[e] == 0)) nothing_can_change = false;
   c->skip_dirty_reduce = nothing_can_change;
   // ... and the tie fix-up (nn_tie.hip) neither, if last round's search reported no tie: the same queries meet the same targets
-  c->tie_skip = nothing_can_change && c->h_tie_seen != nullptr && *c->h_tie_seen == 0u;
-  c->far_skip = nothing_can_change && c->h_far_seen != nullptr && *c->h_far_seen == 0u && c->prev_grid_kernel && method == MVICP_NN_GRID;
+  c->tie_skip = nothing_can_change && c->corr_tie_seen == 0u;
+  c->far_skip = nothing_can_change && c->corr_far_seen == 0u && c->prev_grid_kernel && method == MVICP_NN_GRID;
+  const bool tie_launched = c->tie_rule && !c->tie_skip, far_launched = method == MVICP_NN_GRID && !c->far_skip;
   // Speculative first evaluation of the solve that follows (see common.h).  Every rank decides for itself (its own last solve set
   // the flags); with N > 1 ranks the decisions are SUMMED in the "armed" slot of the one exchanged buffer and the queued blocks are
   // used only if every rank armed — a rank that did not arm still takes part in the same collective with the same size.  (A rank that fails
@@ -821,6 +829,10 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   if (st_q == MVICP_OK) st_q = stream_wait(c);
   if (st_q != MVICP_OK) { c->spec_flags_valid = false; c->spec_arm = false; return st_q; }
   census_resolve(c);
+  // what THIS search's tie fix-up / far launch reported (a skipped launch keeps last search's zero): the next search's skip decisions
+  if (tie_launched) c->corr_tie_seen = c->h_tie_seen ? *c->h_tie_seen : 1u;
+  if (far_launched) c->corr_far_seen = c->h_far_seen ? *c->h_far_seen : 1u;
+  else if (method != MVICP_NN_GRID) c->corr_far_seen = 1u;
   mark("host.corr.wait");
   const double* hr = exchange ? c->h_pin + c->pin_spec_off + nb : c->h_pin + c->pin_res_off;
   bool spec_bad = false;
@@ -1063,7 +1075,10 @@ static void prof_sum(mvicp_ctx* c, const char* kernel, double out[5]) {
   const std::string key = kernel ? kernel : "";
   for (const auto& kv : c->prof) {
     if (!(kv.first == key || (key == "nn" && kv.first.compare(0, 3, "nn_") == 0))) continue;
-    out[0] += kv.second.ms; out[1] += (double)kv.second.launches; out[2] += kv.second.bytes; out[3] += kv.second.survey_bytes; out[4] += kv.second.queries;
+    out[0] += kv.second.ms;
+    // "nn": the auxiliary scopes (nn_far: phase 2 + list flags, nn_tie: the tie fix-up) add their time, but a search is ONE launch of a primary kernel
+    if (key == "nn" && (kv.first == "nn_far" || kv.first == "nn_tie")) continue;
+    out[1] += (double)kv.second.launches; out[2] += kv.second.bytes; out[3] += kv.second.survey_bytes; out[4] += kv.second.queries;
   }
 }
 int mvicp_profile_get(mvicp_ctx* c, const char* kernel, double* total_ms, long long* launches, double* alg_bytes) try {

@@ -219,6 +219,8 @@ struct mvicp_ctx {
   bool tie_rule = true;            // exact distance ties are decided as nanoflann decides them (first visited; nn_tie.hip); false: lowest original index
   unsigned long long* d_tie_list = nullptr; size_t tie_cap = 0; unsigned int* d_tie_count = nullptr; int tie_parity = 0;   // queries reported by the NN kernels
   unsigned int* h_tie_seen = nullptr; unsigned int* d_tie_seen = nullptr;   // mapped host word: reports of the last fix-up launch (read after the round's wait)
+  unsigned int corr_tie_seen = 1u, corr_far_seen = 1u;   // what the LAST mvicp_correspond's own fix-up / far launch reported (read after its wait; 1 = unknown).
+                                   // mvicp_nn_query runs the same launches and overwrites the mapped words, so the skip decisions below use these copies
   bool tie_skip = false;           // set by mvicp_correspond: a search that reproduces last round's queries bit for bit after a round without any report cannot report
   bool tile_seed = true;           // tile kernel starts from last round's neighbours when there are any
   int tile_bounds = 1;             // 1: the AUTO round that would hand over to the grid kernel runs the tile kernel's BND build instead (it leaves the

@@ -93,8 +93,11 @@ __device__ __forceinline__ void tau_pieces(const LaneM& L, float scale_f, float 
                   s * (2.f * kAcc * 1.002f / 16777216.f + 1.0e-6f);
   float tau = -((U - L.a2) + E);
   tau -= fabsf(tau) * 2.4e-7f;                                  // (the two fp32 roundings above, downwards)
-  // a threshold too large for the pieces (a huge search radius on a tiny block: -T beyond 60000 x 4096, t1 would overflow f16): admit everything
-  if (!(tau > -2.4e8f)) { t1 = (_Float16)-60000.f; t2 = (_Float16)0.f; t3 = (_Float16)0.f; return; }
+  // a threshold too large for the pieces (a huge search radius on a tiny block): admit everything.  The bound is 2^27, not f16's range of
+  // t1 alone: from |t1| = 2^15 on, f16 spacing is 32, so r1 = tau - 4096 t1 reaches +-65536 and t2 = (f16)r1 would round to +-inf (then t3
+  // NaN, V NaN, and a NaN never has its sign bit tested as a hit: the true neighbour could be skipped).  Below 2^27, |t1| < 2^15 has
+  // spacing <= 16, |r1| <= 32768 and |r2| <= 8: every piece finite (tests/test_mfma_guard_band.py).
+  if (!(tau > -134217728.f)) { t1 = (_Float16)-60000.f; t2 = (_Float16)0.f; t3 = (_Float16)0.f; return; }
   t1 = (_Float16)(tau * (1.f / 4096.f));
   const float r1 = __builtin_fmaf(-4096.f, (float)t1, tau);     // exact
   t2 = (_Float16)r1;

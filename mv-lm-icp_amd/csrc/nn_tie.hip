@@ -175,12 +175,17 @@ int ensure_tie_trees(mvicp_ctx* c, const std::vector<int>& frames) {
   }
   for (size_t k = 0; k < todo.size(); ++k) {
     FrameDev& F = c->frames[todo[k]];
-    MV_HIP(hipMalloc(&F.tie_nodes, sizeof(VisitNode) * B[k].nodes.size()));
-    MV_HIP(hipMemcpy(F.tie_nodes, B[k].nodes.data(), sizeof(VisitNode) * B[k].nodes.size(), hipMemcpyHostToDevice));
-    MV_HIP(hipMalloc((void**)&F.tie_ord, sizeof(int) * B[k].ord.size()));
-    MV_HIP(hipMemcpy(F.tie_ord, B[k].ord.data(), sizeof(int) * B[k].ord.size(), hipMemcpyHostToDevice));
-    MV_HIP(hipMalloc((void**)&F.tie_slot, sizeof(int) * B[k].slot.size()));
-    MV_HIP(hipMemcpy(F.tie_slot, B[k].slot.data(), sizeof(int) * B[k].slot.size(), hipMemcpyHostToDevice));
+    auto upload = [&]() -> int {
+      MV_HIP(hipMalloc(&F.tie_nodes, sizeof(VisitNode) * B[k].nodes.size()));
+      MV_HIP(hipMemcpy(F.tie_nodes, B[k].nodes.data(), sizeof(VisitNode) * B[k].nodes.size(), hipMemcpyHostToDevice));
+      MV_HIP(hipMalloc((void**)&F.tie_ord, sizeof(int) * B[k].ord.size()));
+      MV_HIP(hipMemcpy(F.tie_ord, B[k].ord.data(), sizeof(int) * B[k].ord.size(), hipMemcpyHostToDevice));
+      MV_HIP(hipMalloc((void**)&F.tie_slot, sizeof(int) * B[k].slot.size()));
+      MV_HIP(hipMemcpy(F.tie_slot, B[k].slot.data(), sizeof(int) * B[k].slot.size(), hipMemcpyHostToDevice));
+      return MVICP_OK;
+    };
+    const int st = upload();
+    if (st != MVICP_OK) { free_tie(F); return st; }   // a half-uploaded tree is released, not leaked at the next attempt
     for (int a = 0; a < 6; ++a) F.tie_box[a] = B[k].box[a];
     F.has_tie = true;
   }

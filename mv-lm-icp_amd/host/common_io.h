@@ -17,23 +17,24 @@
 
 namespace mvicp {
 
-// common.h:224-239: `x y z nx ny nz` per row.  The reference's read loop pushes one extra element after the last
-// row (the stream only fails on the NEXT extraction); keep_phantom reproduces that element with the C++11 stream
-// semantics (first field zeroed, the others keep the previous row's values), default drops it.
-inline bool loadXYZ(const std::string& filename, std::vector<Vector3d>& pts, std::vector<Vector3d>& nor, bool keep_phantom = false) {
+// common.h:224-239: `x y z nx ny nz` per row.  The reference's read loop `while(file){ Vector3d pt,no; file >> ...; push_back }` pushes one
+// extra element after the last row: the stream only fails on the NEXT extraction, and an extraction whose sentry fails at end of file
+// stores nothing, so the loop-local pt / no still hold the LAST ROW's values — the cloud ends with an exact duplicate of its last point.
+// (Pinned, not guessed: with that duplicate the pairwise known-answer test reproduces README.md:141-146 to all six printed digits;
+// without it, or with a zeroed first field, the fourth digit differs — profiles/r05_lm_pin_sweep.txt.)  keep_phantom = true is the
+// reference's behaviour and the default; false (--drop_phantom_row) loads exactly the rows of the file.
+inline bool loadXYZ(const std::string& filename, std::vector<Vector3d>& pts, std::vector<Vector3d>& nor, bool keep_phantom = true) {
   std::ifstream file(filename.c_str());
   if (file.fail()) { std::cerr << filename << " could not be opened" << std::endl; return false; }
-  double a[6] = {0, 0, 0, 0, 0, 0};
   while (true) {
     double b[6];
     bool ok = true;
     for (int i = 0; i < 6 && ok; ++i) ok = static_cast<bool>(file >> b[i]);
     if (!ok) break;
-    std::copy(b, b + 6, a);
-    pts.push_back(Vector3d(a[0], a[1], a[2]));
-    nor.push_back(Vector3d(a[3], a[4], a[5]));
+    pts.push_back(Vector3d(b[0], b[1], b[2]));
+    nor.push_back(Vector3d(b[3], b[4], b[5]));
   }
-  if (keep_phantom && !pts.empty()) { pts.push_back(Vector3d(0.0, a[1], a[2])); nor.push_back(Vector3d(a[3], a[4], a[5])); }
+  if (keep_phantom && !pts.empty()) { pts.push_back(pts.back()); nor.push_back(nor.back()); }
   return true;
 }
 
@@ -57,19 +58,38 @@ inline void saveMatrix4d(const std::string& filename, const Isometry3d& P) {
 
 // common.h:36-67: file-scope default-seeded std::mt19937 + std::normal_distribution<double>(0,1); draw order w then t;
 // noisyPose = pose * Exp(sigma w) (rotation appended on the right), translation += sigmat t.
+// std::normal_distribution's algorithm is implementation-defined: libstdc++ (this build, and the reference on the README's Ubuntu)
+// and libc++ (the reference on OS X) run the same polar method on the same uniform stream but hand out a pair's variates in opposite
+// order.  noiseStream() = 1 (--noise_stream libc++) restates libc++'s order — the stream the numbers of README.md:141-146 come from.
 inline std::mt19937& noiseGenerator() { static std::mt19937 g; return g; }
+inline int& noiseStream() { static int s = 0; return s; }
+struct LibcxxNormal {   // libc++ <random> normal_distribution::operator(): first-drawn coordinate first, second kept for the next call
+  bool hot = false; double saved = 0.0;
+  double operator()(std::mt19937& g) {
+    if (hot) { hot = false; return saved; }
+    double u, v, s;
+    do {
+      u = 2.0 * std::generate_canonical<double, 53>(g) - 1.0;
+      v = 2.0 * std::generate_canonical<double, 53>(g) - 1.0;
+      s = u * u + v * v;
+    } while (s > 1.0 || s == 0.0);
+    const double f = std::sqrt(-2.0 * std::log(s) / s);
+    saved = v * f; hot = true;
+    return u * f;
+  }
+};
 inline Isometry3d addNoise(const Isometry3d& pose, double sigma, double sigmat) {
-  std::normal_distribution<double> normal(0.0, 1.0);
   std::mt19937& gen = noiseGenerator();
-  double w[3] = {normal(gen), normal(gen), normal(gen)};
-  for (double& x : w) x *= sigma;
+  double z[6];
+  if (noiseStream() == 1) { LibcxxNormal normal; for (double& x : z) x = normal(gen); }
+  else { std::normal_distribution<double> normal(0.0, 1.0); for (double& x : z) x = normal(gen); }
+  double w[3] = {z[0] * sigma, z[1] * sigma, z[2] * sigma};
   double Rw[9];
   se3::aa_to_R(w, Rw);  // SO3::exp(w)
   Isometry3d out = pose;
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) out(i, j) = pose(i, 0) * Rw[0 + 3 * j] + pose(i, 1) * Rw[1 + 3 * j] + pose(i, 2) * Rw[2 + 3 * j];
-  double t[3] = {normal(gen), normal(gen), normal(gen)};
-  for (int i = 0; i < 3; ++i) out.m[12 + i] = pose.m[12 + i] + t[i] * sigmat;
+  for (int i = 0; i < 3; ++i) out.m[12 + i] = pose.m[12 + i] + z[3 + i] * sigmat;
   return out;
 }
 

@@ -2,7 +2,8 @@
 //   loadFrames (:53-100) -> frames[0]->fixed = true (:141) -> computePoseNeighbours (:104-117, once) ->
 //   20 x { computeClosestPoints (:119-127) ; ceresOptimizer* (:158-161) }
 // Extra flags: --rounds (20), --out DIR (write final poses as pose_<i>.txt, 4x4 row-major), --device, --copyback,
-// --keep_phantom_row (reproduce the reference's loadXYZ trailing element), --quiet, --dump_corr DIR (after the LAST round's search
+// --drop_phantom_row (load exactly the files' rows; default: the reference's loadXYZ, which appends a duplicate of the last row),
+// --noise_stream libstdc++|libc++ (std::normal_distribution's variate order for addNoise; default = this build's libstdc++), --quiet, --dump_corr DIR (after the LAST round's search
 // write every Frame::neighbours[j] as corr_<src>_<j>.txt: a header line `dst weight count`, then `first second dist` rows),
 // --check_nn N (re-ask Frame::getClosestPoint for the first N correspondences of every edge and report disagreements),
 // --trace FILE (every round: one line `C round src j dst count weight-bits` per edge after the search and one line `P round frame m00 .. m33`
@@ -29,7 +30,7 @@ static void loadFrames(const Flags& F, std::vector<std::shared_ptr<Frame>>& fram
   for (int i = 0; i < (int)clouds.size() && i < limit * step; i += step) {
     std::shared_ptr<Frame> f(new Frame());
     const int j = F.b("fake", false) ? 0 : i;
-    loadXYZ(clouds[j], f->pts, f->nor, F.b("keep_phantom_row", false));
+    loadXYZ(clouds[j], f->pts, f->nor, !F.b("drop_phantom_row", false));
     if (F.b("recomputeNormals", true)) f->recomputeNormals();  // main_multiview.cpp:49,68-70 (default on)
     if (groundtruth.size() == clouds.size()) {
       f->pose = loadMatrix4d(poses[i]);
@@ -51,6 +52,7 @@ int main(int argc, char** argv) {
   const std::string dir = F.s("dir", "../samples/Bunny_RealData"), out = F.s("out", "");
   Session::get().device = F.i("device", 0);
   Session::get().copy_back = F.b("copyback", true);
+  noiseStream() = F.s("noise_stream", "libstdc++") == "libc++" ? 1 : 0;
 
   std::vector<std::shared_ptr<Frame>> frames;
   loadFrames(F, frames, dir);

@@ -1,7 +1,10 @@
 // Headless counterpart of the reference's src/main_pairwise.cpp:29-134: load one cloud, apply a known noisy transform,
 // recover it with each parameterization from index-aligned pairs, print timings and poseDiff.  Flags: --pointToPlane
 // (false), --cloud FILE (../samples/Bunny_RealData/cloudXYZ_0.xyz), --device, --dump_P FILE (write the ground-truth
-// transform P of this run, 4x4 row-major), --precision N.
+// transform P of this run, 4x4 row-major), --precision N, --drop_phantom_row (load exactly the file's rows; default: the reference's
+// loadXYZ, which appends a duplicate of the last row), --noise_stream libstdc++|libc++ (std::normal_distribution's variate order;
+// default libstdc++ = this build's own).  `pairwise --noise_stream libc++` on the reference's cloudXYZ_0.xyz prints the README's own
+// lines (README.md:141-146): ceres CeresAngleAxis diff_tra:7.76957e-11, ceres EigenQuaternion diff_tra:6.31278e-11.
 #include <chrono>
 #include <iostream>
 
@@ -16,7 +19,8 @@ int main(int argc, char** argv) {
   const bool pointToPlane = F.b("pointToPlane", false);
   Session::get().device = F.i("device", 0);
   std::vector<Vector3d> pts, nor;
-  if (!loadXYZ(F.s("cloud", "../samples/Bunny_RealData/cloudXYZ_0.xyz"), pts, nor, F.b("keep_phantom_row", false)) || pts.empty()) return 1;
+  if (!loadXYZ(F.s("cloud", "../samples/Bunny_RealData/cloudXYZ_0.xyz"), pts, nor, !F.b("drop_phantom_row", false)) || pts.empty()) return 1;
+  noiseStream() = F.s("noise_stream", "libstdc++") == "libc++" ? 1 : 0;
   // main_pairwise.cpp:44-56: q = Rx(pi/4) Ry(1) Rz(-0.2), t = (.01,-.01,-.005), P = addNoise(Pclean, 0.1, 0.1)
   auto rot = [](int axis, double a) {
     Isometry3d R;

@@ -5,16 +5,14 @@ import os
 import numpy as np
 
 
-def load_xyz(path, phantom_row=False):
-    """`x y z nx ny nz` per row (common.h:224-239).  The reference's `while(file){ file >> ...; push_back }` loop
-    appends one extra garbage element after the last row (the stream only fails on the NEXT read); that phantom
-    row is dropped here unless phantom_row=True, in which case the C++11 stream semantics are reproduced
-    (first field zeroed, the rest keep the previous row's values)."""
+def load_xyz(path, phantom_row=True):
+    """`x y z nx ny nz` per row (common.h:224-239).  The reference's `while(file){ Vector3d pt,no; file >> ...; push_back }` loop
+    appends one extra element after the last row (the stream only fails on the NEXT read, and a failed extraction at end of file
+    stores nothing): an exact DUPLICATE of the last row.  phantom_row=True (default) reproduces it — with it the pairwise known-answer
+    test matches README.md:141-146 to six digits (profiles/r05_lm_pin_sweep.txt); False loads exactly the rows of the file."""
     a = np.loadtxt(path, dtype=np.float64).reshape(-1, 6)
     if phantom_row and len(a):
-        ph = a[-1].copy()
-        ph[0] = 0.0
-        a = np.vstack([a, ph])
+        a = np.vstack([a, a[-1:]])
     return np.ascontiguousarray(a[:, :3]), np.ascontiguousarray(a[:, 3:6])
 
 
@@ -37,7 +35,7 @@ def _sorted_files(folder, prefix):
     return sorted(out, key=lambda s: (len(s), s))
 
 
-def load_frames(folder, limit=40, step=2):
+def load_frames(folder, limit=40, step=2, phantom_row=True):
     """loadFrames (main_multiview.cpp:53-100) without the noise step: returns (pts, nor, poses, groundtruth or None)."""
     clouds = _sorted_files(folder, "cloud")
     poses = _sorted_files(folder, "pose")
@@ -45,7 +43,7 @@ def load_frames(folder, limit=40, step=2):
     pts, nor, P, G = [], [], [], []
     i = 0
     while i < len(clouds) and i < limit * step:
-        p, n = load_xyz(clouds[i])
+        p, n = load_xyz(clouds[i], phantom_row)
         pts.append(p); nor.append(n)
         P.append(load_matrix4(poses[i]))
         if len(gts) == len(clouds):

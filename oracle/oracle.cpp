@@ -695,19 +695,48 @@ void orc_optimize(const orc_problem* p, double* poses, int max_iterations, orc_s
 // method: compiled here with the same g++ <random>, this IS the reference's pose noise.  reset != 0 re-seeds the generator to
 // its default state first (= a fresh process: main_pairwise.cpp calls addNoise exactly once, main_multiview.cpp once per
 // non-first frame in file order).
+//
+// std::normal_distribution's ALGORITHM is implementation-defined.  libc++ (clang on the author's OS X, README "Mac OSX (>=El Capitan)") runs
+// the same Marsaglia polar method on the same uniform stream (uniform_real_distribution(-1, 1) over generate_canonical<double, 53>) but
+// hands out the pair's variates in the opposite order: FIRST-drawn coordinate first, where libstdc++ returns the second-drawn one and
+// keeps the first.  stdlib = 1 restates that (libc++ <random>: normal_distribution::operator()); it is the stream the numbers of
+// README.md:141-146 were produced with (profiles/r05_lm_pin_sweep.txt: both published diff_tra values reproduced to all six digits).
 static std::mt19937 g_noise_generator;
-void orc_add_noise(const double* pose16, double sigma, double sigmat, int reset, double* out16) {
+struct LibcxxNormal {   // a fresh object per addNoise call, like the reference's local distribution (no saved variate survives a call)
+  bool hot = false; double saved = 0.0;
+  double operator()(std::mt19937& g) {
+    if (hot) { hot = false; return saved; }
+    double u, v, s;
+    do {
+      u = 2.0 * std::generate_canonical<double, 53>(g) - 1.0;
+      v = 2.0 * std::generate_canonical<double, 53>(g) - 1.0;
+      s = u * u + v * v;
+    } while (s > 1.0 || s == 0.0);
+    const double f = std::sqrt(-2.0 * std::log(s) / s);
+    saved = v * f; hot = true;
+    return u * f;
+  }
+};
+static void add_noise_from(const double* pose16, double sigma, double sigmat, const double* z6, double* out16);
+void orc_add_noise_stream(const double* pose16, double sigma, double sigmat, int reset, int stdlib, double* out16) {
   if (reset) g_noise_generator = std::mt19937();
-  std::normal_distribution<double> normal(0.0, 1.0);
-  double w[3] = {normal(g_noise_generator), normal(g_noise_generator), normal(g_noise_generator)};
+  double z[6];
+  if (stdlib == 1) { LibcxxNormal normal; for (int i = 0; i < 6; ++i) z[i] = normal(g_noise_generator); }
+  else { std::normal_distribution<double> normal(0.0, 1.0); for (int i = 0; i < 6; ++i) z[i] = normal(g_noise_generator); }
+  add_noise_from(pose16, sigma, sigmat, z, out16);
+}
+void orc_add_noise(const double* pose16, double sigma, double sigmat, int reset, double* out16) {
+  orc_add_noise_stream(pose16, sigma, sigmat, reset, 0, out16);
+}
+static void add_noise_from(const double* pose16, double sigma, double sigmat, const double* z6, double* out16) {
+  double w[3] = {z6[0], z6[1], z6[2]};
   for (int i = 0; i < 3; ++i) w[i] *= sigma;
   double Rw[9];
   AngleAxisToRotationMatrix(w, Rw);   // column-major, = Sophus::SO3d::exp(w).matrix()
   for (int k = 0; k < 16; ++k) out16[k] = pose16[k];
   for (int j = 0; j < 3; ++j)
     for (int i = 0; i < 3; ++i) out16[i + 4 * j] = pose16[i + 4 * 0] * Rw[0 + 3 * j] + pose16[i + 4 * 1] * Rw[1 + 3 * j] + pose16[i + 4 * 2] * Rw[2 + 3 * j];
-  double t[3] = {normal(g_noise_generator), normal(g_noise_generator), normal(g_noise_generator)};
-  for (int i = 0; i < 3; ++i) out16[12 + i] = pose16[12 + i] + t[i] * sigmat;
+  for (int i = 0; i < 3; ++i) out16[12 + i] = pose16[12 + i] + z6[3 + i] * sigmat;
 }
 
 // common.h:259-282 poseDiff: ||t1 - t2|| and acos(2 <q1,q2>^2 - 1) in degrees.

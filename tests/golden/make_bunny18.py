@@ -9,8 +9,10 @@ ground-truth pose, the others addNoise(gt, 0.02, 0.01) from ONE default-seeded s
 
 What is stored (data only — inputs and expected outputs; no reference source text):
   xyz_e8, row_off : every row of the 18 clouds as int32 multiples of 1e-8 m (the files hold at most 8 decimals, and int / 1e8 is the
-                    correctly rounded value of the decimal text: the same double the reference parses), concatenated; frame i = rows row_off[i] : row_off[i + 1]   (ragged sizes kept; the phantom trailing
-                    element of the reference's loadXYZ, common.h:233-238, is not stored)
+                    correctly rounded value of the decimal text: the same double the reference parses), concatenated; frame i = rows row_off[i] : row_off[i + 1]   (ragged sizes kept).  The phantom trailing
+                    element of the reference's loadXYZ (common.h:233-238: an exact duplicate of the last row, pinned by
+                    profiles/r05_lm_pin_sweep.txt) is NOT stored: the loaders append it (the default), and every recorded
+                    output below is for the clouds WITH it — row_off[i + 1] - row_off[i] + 1 points per view
   gt              : poses_{0,2,...,34}.txt (18 x 4 x 4)
   init            : the noisy initial poses (default-seeded stream, compiled C++: oracle orc_add_noise)
   src, dst        : the pose graph INCLUDING frame 0's own (never searched) edges, as the driver builds it
@@ -21,7 +23,7 @@ What is stored (data only — inputs and expected outputs; no reference source t
                     normals themselves are recomputed by the path under test, as the reference does)
   cfg1_*          : the same fields for the 2-view point-to-point run
 CPU path = tests/cpupath.py: REAL nanoflann (oracle/_ref) for every search, the oracle's Jet / LM restatement of Ceres for the solves
-(parity unpinned for that half: Ceres is not installed anywhere)."""
+(pinned on the reference's published pairwise vector, README.md:141-146: tests/test_oracle_lm.py::test_readme_known_answer_reproduced)."""
 import os
 import sys
 
@@ -76,16 +78,16 @@ def main():
     ids = list(range(0, 36, 2))
     pts, gt, um = [], [], []
     for i in ids:
-        p, _ = mio.load_xyz(os.path.join(REF, f"cloudXYZ_{i}.xyz"))
+        p, _ = mio.load_xyz(os.path.join(REF, f"cloudXYZ_{i}.xyz"), phantom_row=False)
         u = np.rint(p * 1e8).astype(np.int32)
         assert np.array_equal(u / 1e8, p), "the cloud does not sit on the 1e-8 lattice"
-        pts.append(p); um.append(u)
+        pts.append(np.vstack([p, p[-1:]])); um.append(u)   # the reference's cloud = the file's rows + the duplicated last row
         gt.append(mio.load_matrix4(os.path.join(REF, f"poses_{i}.txt")))
     nor = []
     for p in pts:
         ki, _ = ref.knn_self(p, 10)
         nor.append(pca_normals(p, ki))
-    out = {"xyz_e8": np.concatenate(um), "row_off": np.cumsum([0] + [len(p) for p in pts]).astype(np.int64), "gt": np.array(gt),
+    out = {"xyz_e8": np.concatenate(um), "row_off": np.cumsum([0] + [len(u) for u in um]).astype(np.int64), "gt": np.array(gt),
            "nor_mean": np.array([n.mean(axis=0) for n in nor])}
     print("cfg default: 18 views, rows", [len(p) for p in pts])
     out.update(run(orc, pts, nor, np.array(gt), 1))

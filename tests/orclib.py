@@ -168,10 +168,12 @@ class Oracle:
         self.lib.orc_local_plus(param, _p(x), _p(d), _p(out))
         return out
 
-    def add_noise(self, pose, sigma, sigmat, reset=False):
-        """common.h:36-67 with the reference's default-seeded std::mt19937 stream (libstdc++)."""
+    def add_noise(self, pose, sigma, sigmat, reset=False, stdlib="libstdc++"):
+        """common.h:36-67 with the reference's default-seeded std::mt19937 stream.  stdlib picks std::normal_distribution's
+        implementation-defined variate order: "libstdc++" (g++) or "libc++" (clang / OS X: the stream behind README.md:141-146)."""
         out = np.zeros(16)
-        self.lib.orc_add_noise(_p(to_c([pose])[0]), C.c_double(sigma), C.c_double(sigmat), C.c_int(1 if reset else 0), _p(out))
+        self.lib.orc_add_noise_stream(_p(to_c([pose])[0]), C.c_double(sigma), C.c_double(sigmat), C.c_int(1 if reset else 0),
+                                      C.c_int({"libstdc++": 0, "libc++": 1}[stdlib]), _p(out))
         return from_c(out)[0]
 
     def pose_diff(self, P1, P2):

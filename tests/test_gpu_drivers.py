@@ -31,7 +31,7 @@ def test_multiview_driver_matches_engine_loop(tmp_path, flags, param, plane):
     d = tmp_path / "data"; o = tmp_path / "out"
     d.mkdir(); o.mkdir()
     write_dataset(str(d), pb)
-    cmd = [os.path.join(BIN, "multiview"), "--dir", str(d), "--out", str(o), "--step", "1", "--limit", "40", "--rounds", "4", "--quiet", "--norecomputeNormals"] + flags
+    cmd = [os.path.join(BIN, "multiview"), "--dir", str(d), "--out", str(o), "--step", "1", "--limit", "40", "--rounds", "4", "--quiet", "--norecomputeNormals", "--drop_phantom_row"] + flags
     subprocess.check_call(cmd)
     got = np.array([np.loadtxt(os.path.join(str(o), f"pose_{i}.txt")) for i in range(5)])
     # same loop through the Python binding; the driver's graph includes the fixed frame's own (inactive) edges
@@ -66,7 +66,7 @@ def test_correspondence_copy_back_through_frame_api(tmp_path):
     d.mkdir(); o.mkdir()
     write_dataset(str(d), pb)
     out = subprocess.check_output([os.path.join(BIN, "multiview"), "--dir", str(d), "--out", str(o), "--step", "1", "--rounds", "1", "--quiet", "--copyback",
-                                   "--norecomputeNormals", "--dump_corr", str(o), "--check_nn", "300"]).decode()
+                                   "--norecomputeNormals", "--drop_phantom_row", "--dump_corr", str(o), "--check_nn", "300"]).decode()
     m = re.search(r"getClosestPoint check: (\d+) queries, (\d+) mismatches", out)
     assert m and int(m.group(1)) >= 1000 and int(m.group(2)) == 0, out
     src, dst = synth.pose_graph_knn(pb["init"], 2, skip_fixed0=False)
@@ -98,7 +98,7 @@ def test_multiview_driver_default_flags_recompute_normals(tmp_path):
     d = tmp_path / "data"; o = tmp_path / "out"
     d.mkdir(); o.mkdir()
     write_dataset(str(d), pb)
-    subprocess.check_call([os.path.join(BIN, "multiview"), "--dir", str(d), "--out", str(o), "--step", "1", "--rounds", "3", "--quiet"])
+    subprocess.check_call([os.path.join(BIN, "multiview"), "--dir", str(d), "--out", str(o), "--step", "1", "--rounds", "3", "--quiet", "--drop_phantom_row"])
     got = np.array([np.loadtxt(os.path.join(str(o), f"pose_{i}.txt")) for i in range(4)])
     src, dst = synth.pose_graph_knn(pb["init"], 2, skip_fixed0=False)
     eng = mvicp.Engine(0)
@@ -132,6 +132,21 @@ def test_pairwise_driver_recovers_known_transform(tmp_path):
                     assert float(t) < 1e-13 and float(r) < 3e-6, out      # README.md:148: 6.6e-15, 2.4e-6 deg (acos floor)
                 continue   # point-to-plane closed form = ONE linearised step from identity (icp-closedform.cpp:30-54): not exact for this P
             assert float(t) <= 1e-9 and float(r) <= 2e-6, out
+
+
+def test_pairwise_driver_prints_the_readme_lines(tmp_path):
+    """The literal drop-in on the reference's published vector: `pairwise` with the reference's defaults (loadXYZ's duplicated last row)
+    and the README run's noise stream (libc++ variate order, --noise_stream libc++) on cloudXYZ_0.xyz prints the README's own lines
+    (README.md:141-146, real Ceres): `ceres CeresAngleAxis diff_tra:7.76957e-11`, `ceres EigenQuaternion diff_tra:6.31278e-11` —
+    NN-free path: GPU linearize + the product's host LM."""
+    K = np.load(os.path.join(ROOT, "tests", "golden", "pairwise_kat.npz"))
+    cloud = tmp_path / "cloud.xyz"
+    np.savetxt(str(cloud), np.hstack([K["pts"], K["nor"]]), fmt="%.17g")
+    pfile = tmp_path / "P.txt"
+    out = subprocess.check_output([os.path.join(BIN, "pairwise"), "--cloud", str(cloud), "--noise_stream", "libc++", "--dump_P", str(pfile)]).decode()
+    assert np.allclose(np.loadtxt(str(pfile)), K["P_libcxx"], rtol=0, atol=1e-15)
+    vals = dict((m[0], m[1]) for m in re.findall(r"(ceres \w+)\s+diff_tra:([0-9.e+-]+)", out))
+    assert vals["ceres CeresAngleAxis"] == "7.76957e-11" and vals["ceres EigenQuaternion"] == "6.31278e-11", out
 
 
 # ---------------------------------------------------------------- the reference's DEFAULT workload (Bunny, 18 views) and cfg1, from committed data

@@ -334,6 +334,24 @@ def test_pairwise_known_answer_on_gpu(eng, orc, plane):
         assert dt < 1e-11 and dr < 1e-11, (param, plane, dt, dr)
 
 
+def test_pairwise_readme_vector_on_gpu(eng, orc):
+    """The reference's PUBLISHED numbers through the device path: README.md:141-146 (real Ceres, point-to-point) angle-axis diff_tra
+    7.76957e-11, quaternion 6.31278e-11, on the reference's own inputs (cloudXYZ_0 with loadXYZ's duplicated last row, P from the
+    libc++ noise stream; tests/test_oracle_lm.py::test_readme_known_answer_reproduced).  GPU linearize + host/lm.cpp."""
+    pts = np.vstack([KAT["pts"], KAT["pts"][-1:]])
+    P = KAT["P_libcxx"]
+    dstp = pts @ P[:3, :3].T + P[:3, 3]
+    ids = np.arange(len(pts), dtype=np.int32)
+    eng.set_frames([dstp, pts], None)
+    eng.set_graph([1], [0])
+    eng.set_correspondences(0, ids, ids, 0.0)
+    for param in (L.PARAM_ANGLE_AXIS, L.PARAM_EIGEN_QUATERNION):
+        Pout, sm = eng.optimize(np.array([np.eye(4), np.eye(4)]), [1, 0], param, 0, False, 50)
+        dt = orc.pose_diff(P, Pout[1])[0]
+        assert sm["termination"] == 2 and sm["iterations"] == 6, sm
+        assert abs(dt / KAT["readme_dt"][param] - 1) < 1e-4, (param, dt, KAT["readme_dt"][param])
+
+
 def test_point_to_point_block_against_kabsch(eng):
     """Row f4: the closed-form point-to-point solution (icp-closedform.cpp:9-26, here SVD in numpy AND the library's host solver)
     is the exact minimiser of sum |R p + t - q|^2, so it must be a stationary point of the GPU's point-to-point normal equations

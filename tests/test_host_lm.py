@@ -124,3 +124,22 @@ def test_random_pose_graphs(orc, seed):
     for k in range(K):
         dt, dr = synth.pose_diff(P[k], P_ref[k])
         assert dt < 1e-8 and dr < 1e-8, (seed, k, dt, dr)
+
+
+def test_product_lm_reproduces_the_readme_vector(orc):
+    """The PRODUCT's host solve (host/lm.cpp: analytic chain rule over canonical blocks, its own factorisation) on the reference's published
+    vector: README.md:141-146, real Ceres, angle-axis 7.76957e-11 / quaternion 6.31278e-11 (see test_oracle_lm.py::
+    test_readme_known_answer_reproduced for the inputs).  The evaluator is the oracle's (no GPU here); the GPU evaluator goes through the
+    same solve in tests/test_gpu_parity.py::test_pairwise_readme_vector_on_gpu."""
+    import os
+    K = np.load(os.path.join(os.path.dirname(__file__), "golden", "pairwise_kat.npz"))
+    pts = np.vstack([K["pts"], K["pts"][-1:]])
+    P = K["P_libcxx"]
+    dstp = pts @ P[:3, :3].T + P[:3, 3]
+    ids = np.arange(len(pts), dtype=np.int32)
+    for param in (orclib.PARAM_ANGLEAXIS, orclib.PARAM_QUAT):
+        ev = lambda poses: orc.edge_blocks([dstp, pts], None, [1], [0], [(ids, ids)], [0.0], poses, 0, 0)
+        Pout, sm = L.lm_solve_host(2, [1], [0], np.array([np.eye(4), np.eye(4)]), [1, 0], param, ev, 50)
+        dt = orc.pose_diff(P, Pout[1])[0]
+        assert sm["termination"] == 2 and sm["iterations"] == 6, sm
+        assert abs(dt / K["readme_dt"][param] - 1) < 1e-4, (param, dt)   # (1e-10-sized quantity out of 1e-16-relative arithmetic: 4+ digits)

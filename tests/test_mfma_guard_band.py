@@ -69,14 +69,17 @@ def tau_of(U, a2, s, amax, en):
          s * F32(2.0 * KACC * 1.002 / 16777216.0 + 1.0e-6)).astype(F32)
     tau = (-((U - a2).astype(F32) + E)).astype(F32)
     tau = (tau - np.abs(tau) * F32(2.4e-7)).astype(F32)
-    # a threshold too large for the pieces (-T beyond 60000 * 4096): the lane admits everything instead (tau_pieces' overflow guard)
-    tau = np.where(tau > F32(-2.4e8), tau, F32(-60000.0 * 4096.0)).astype(F32)
+    # a threshold too large for the pieces (-T beyond 2^27: t2 = f16(tau - 4096 t1) would overflow from |t1| = 2^15 on, where f16 spacing
+    # is 32): the lane admits everything instead (tau_pieces' overflow guard)
+    tau = np.where(tau > F32(-134217728.0), tau, F32(-60000.0 * 4096.0)).astype(F32)
     t1 = (tau * F32(1.0 / 4096.0)).astype(F16)
     r1 = (tau.astype(np.float64) - 4096.0 * t1.astype(np.float64)).astype(F32)     # fmaf(-4096, t1, tau): exact
     assert np.array_equal(r1.astype(np.float64), tau.astype(np.float64) - 4096.0 * t1.astype(np.float64))
     t2 = r1.astype(F16)
     r2 = (r1 - t2.astype(F32)).astype(F32)
     t3 = (r2 - np.abs(r2) * F32(1.0e-3) - F32(6.0e-8)).astype(F16)
+    for piece in (t1, t2, t3):   # a non-finite piece makes V NaN / -inf-free +inf: a silent miss
+        assert np.isfinite(piece.astype(np.float64)).all()
     return E, tau, t1, t2, t3
 
 
@@ -143,3 +146,29 @@ def test_out_of_range_and_unbounded_lanes_admit_everything():
     n_max = 3 * 128.0 ** 2
     assert n_max - 60000.0 * 4096.0 < 0
     assert 0.0 - 2.0 * 3 * 256.0 * 4096.0 * 1.001 + 60000.0 * 4096.0 > 0   # the most negative -2 a.b a finished in-range lane can reach
+
+
+def test_threshold_pieces_stay_finite_up_to_the_admit_everything_guard():
+    """for |tau| in [2^27, 2.4e8) the old guard (t1 only) let r1 = tau - 4096 t1 reach +-65536 and t2 round to +-inf (about
+    4e-4 of the band).  With the guard at 2^27 every tau the split ever sees gives finite pieces, and the split still stands for tau
+    (rounded down).  The band is reached when a lane's threshold radius is ~90-120 block half-extents (an unseeded first round with the
+    cutoff near the object size on a dense cloud)."""
+    rng = np.random.default_rng(0)
+    # tau values up to and across the guard, dense around the former failure band and its lower edge
+    mags = np.concatenate([10.0 ** rng.uniform(0, 8.4, 400000), rng.uniform(2.0 ** 26, 2.45e8, 400000), 2.0 ** 27 + rng.uniform(-70000, 70000, 200000)])
+    tau = (-mags).astype(F32)
+    zero = np.zeros_like(tau)
+    # drive tau_of with U - a2 + E == -tau: U = -tau, a2 = 0, s = 0, amax = 0, en = 0 leaves only the constant part of E
+    E, tau_c, t1, t2, t3 = tau_of((-tau).astype(F32), zero, zero, zero, F32(0.0))
+    clamped = tau_c <= F32(-60000.0 * 4096.0)
+    T = 4096.0 * t1.astype(np.float64) + t2.astype(np.float64) + t3.astype(np.float64)
+    assert clamped.any() and (~clamped).any()
+    assert (T[~clamped] <= tau_c.astype(np.float64)[~clamped] + 1e-12).all()
+    assert (tau_c.astype(np.float64)[~clamped] - T[~clamped] <= np.abs(tau_c.astype(np.float64)[~clamped]) * 2.0 ** -20 + 2e-7).all()
+    # the old guard really did overflow in the band (the case this test exists for)
+    band = (tau <= F32(-134217728.0)) & (tau > F32(-2.4e8))
+    tb = tau[band]
+    t1o = (tb * F32(1.0 / 4096.0)).astype(F16)
+    r1o = (tb.astype(np.float64) - 4096.0 * t1o.astype(np.float64)).astype(F32)
+    with np.errstate(over="ignore"):
+        assert not np.isfinite(r1o.astype(F16).astype(np.float64)).all()

@@ -169,6 +169,55 @@ def test_pairwise_known_answer_reference_inputs(orc, param, plane):
     assert dt <= 1.25 * K["reached_dt"][plane, param] + 1e-13 and sm["iterations"] == K["reached_iters"][plane, param], (param, plane, dt, sm)
 
 
+def readme_problem(orc, K, param, stdlib="libc++", phantom=True):
+    """The reference's own run of main_pairwise.cpp (point-to-point): cloudXYZ_0 as ITS loadXYZ delivers it (the last row twice,
+    common.h:233-238), P = addNoise(Pclean, 0.1, 0.1) from the default-seeded mt19937 through the given standard library's
+    std::normal_distribution, index-aligned pairs (dst[i], src[i]), frame 0 = dst fixed at identity, frame 1 = src from identity."""
+    pts = np.vstack([K["pts"], K["pts"][-1:]]) if phantom else K["pts"]
+    P = orc.add_noise(K["Pclean"], 0.1, 0.1, reset=True, stdlib=stdlib)
+    dstp = pts @ P[:3, :3].T + P[:3, 3]
+    ids = np.arange(len(pts), dtype=np.int32)
+    return orc.make_problem([dstp, pts], [None, None], [1, 0], [1], [0], [(ids, ids)], [0.0], param, 0, 0), P
+
+
+def test_readme_known_answer_reproduced(orc):
+    """THE PIN OF THE LM HALF.  README.md:141-146 prints what the reference itself — real Ceres — reached on its only
+    known-answer test:  `ceres CeresAngleAxis diff_tra:7.76957e-11`, `ceres EigenQuaternion diff_tra:6.31278e-11` (the third line
+    re-prints the quaternion result, main_pairwise.cpp:132).  The restated trust-region loop (oracle.cpp lm_solve, Ceres-default
+    schedule of icp-ceres.cpp:66-95) reproduces BOTH numbers to all six printed digits on the reference's inputs — once the inputs are
+    really the reference's: the libc++ variate order of std::normal_distribution (the README run was an OS X / clang build) and the
+    duplicated last row its loadXYZ appends.  diff_tra here is ~1e-6 of the last LM step, a smooth function of the whole trajectory
+    (functors, local parameterizations, damping, radius updates, the parameter-tolerance stop): six digits on two parameterizations
+    do not happen by accident — and the controls below show the vector tells details apart."""
+    K = kat()
+    assert np.array_equal(orc.add_noise(K["Pclean"], 0.1, 0.1, reset=True, stdlib="libc++"), K["P_libcxx"])
+    reached = {}
+    for param in PARAMS:
+        prob, P = readme_problem(orc, K, param)
+        Pout, sm = orc.optimize(prob, np.array([np.eye(4), np.eye(4)]), 50)
+        reached[param] = orc.pose_diff(P, Pout[1])[0]
+        assert sm["termination"] == 2 and sm["iterations"] == 6, sm
+        assert abs(reached[param] / K["readme_reached"][param] - 1) < 1e-6, (param, reached[param])
+    assert "%.5e" % reached[orclib.PARAM_ANGLEAXIS] == "7.76957e-11" and "%.5e" % reached[orclib.PARAM_QUAT] == "6.31278e-11", reached
+    assert K["readme_dt"][orclib.PARAM_ANGLEAXIS] == 7.76957e-11 and K["readme_dt"][orclib.PARAM_QUAT] == 6.31278e-11
+    # controls: what does NOT reproduce the README (each off in the 2nd-4th digit or by factors)
+    def run(param, **kw):
+        opts = {k: kw.pop(k) for k in list(kw) if k in orc.LM_OPTION_ORDER}
+        orc.set_lm_options(**opts)
+        try:
+            prob, P = readme_problem(orc, K, param, **kw)
+            Pout, _ = orc.optimize(prob, np.array([np.eye(4), np.eye(4)]), 50)
+        finally:
+            orc.set_lm_options()
+        return orc.pose_diff(P, Pout[1])[0] / K["readme_dt"][param]
+    for param in (orclib.PARAM_ANGLEAXIS, orclib.PARAM_QUAT):
+        assert abs(run(param, phantom=False) - 1) > 2e-4            # without the duplicated row: 7.77251e-11 / 6.31468e-11
+        assert run(param, stdlib="libstdc++") > 4                     # g++'s variate order = another P: 4.0e-10 / 3.2e-10
+        assert run(param, initial_radius=3e3) > 10 and run(param, initial_radius=1e5) > 3   # initial_trust_region_radius must be 1e4
+        assert run(param, radius_rule=1) < 0.3 and run(param, radius_rule=2) > 5              # the radius update must be Ceres' cubic rule
+        assert run(param, parameter_tolerance=1e-6) > 100            # the stopping rule must be 1e-8 (|x| + 1e-8)
+
+
 # ---------------------------------------------------------------- how much could an unpinned detail of Ceres' schedule matter?
 def _registration(orc, ref, pb, param, rounds=20):
     import cpupath
