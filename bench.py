@@ -47,7 +47,7 @@ WORKLOADS = {
 WORKLOAD_EXTRAS = {"cfg4_partial": {"cone_deg": 20.0, "sigma": 0.004, "sigmat": 0.002, "cutoff": 0.005}}
 ROUNDS_PER_REGISTRATION = 20   # main_multiview.cpp:150
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 
 def source_sha16():
@@ -103,7 +103,7 @@ def cpu_reference_legs(pb, plane, param, gpu_poses_after, gpu_iters, window_roun
         "lm_iterations_gpu": [p["lm_iterations_gpu"] for p in per_round], "lm_iterations_cpu": [p["lm_iterations_cpu"] for p in per_round],
         "note": ("GPU path vs the reference-equivalent CPU path (real nanoflann + oracle LM, all edges), each on its own trajectory from the same noisy initial "
                  "poses, compared after each of the first rounds of the registration; target 1e-5 m / rad.  The CPU path's LM is a restatement of Ceres "
-                 "(parity unpinned: Ceres is not installed), see DESIGN.md section 6")}
+                 "(pinned on the reference's published pairwise vector, README.md:141-146, to six digits: tests/test_oracle_lm.py), see DESIGN.md section 7")}
 
     def window_rate(sec_of_round):
         tot = 0.0
@@ -123,13 +123,21 @@ def cpu_reference_legs(pb, plane, param, gpu_poses_after, gpu_iters, window_roun
         "value": rate_all, "unit": "iterations/s", "cores": ncores, "s_per_round": spr_all, "edges": E, "sample": "ALL edges, rounds 1..%d measured one by one" % cpu_rounds,
         "per_round": per_round, "tree_build_s_once": tree_build_s}}
     # ---- (2) the reference's build and threading on a bounded sample
-    Ks = min(3, K)
-    keep = [e for e, (s_, d_) in enumerate(zip(pb["src"], pb["dst"])) if s_ < Ks and d_ < Ks]
-    scale = E / max(1, len(keep))
+    def sample_views(min_edges):
+        """smallest prefix of the views whose mutual edges number at least min_edges (all views if the graph is smaller)"""
+        for ks in range(2, K + 1):
+            kp = [e for e, (s_, d_) in enumerate(zip(pb["src"], pb["dst"])) if s_ < ks and d_ < ks]
+            if len(kp) >= min(min_edges, E):
+                return ks, kp
+        return K, list(range(E))
     r_mov = 2 if cpu_rounds >= 2 and per_round[1]["moved"] else 1
     r_fix = last_fixed["round"]
     starts = {"moving": (r_mov, pb["init"] if r_mov == 1 else gpu_poses_after[r_mov - 2]), "fixed_point": (r_fix, pb["init"] if r_fix == 1 else gpu_poses_after[r_fix - 2])}
-    for name, use_fast in (("O2_1thread", False),) + ((("O3_avx2_1thread", True),) if fast else ()):
+    # value (-O2, 1 thread = the reference's build and threading): at least 16 of the edges (VERDICT r4: 3 edges x 20.67 was an extrapolation);
+    # the -O3 single-thread variant stays on the 3-view sample (a side figure)
+    for name, use_fast, min_edges in (("O2_1thread", False, 16),) + ((("O3_avx2_1thread", True, 3),) if fast else ()):
+        Ks, keep = sample_views(min_edges)
+        scale = E / max(1, len(keep))
         c1 = cpupath.CpuPath(pb["pts"][:Ks], pb["nor"][:Ks], pb["src"][keep], pb["dst"][keep], pb["fixed"][:Ks], param, plane, cutoff=cutoff, fast=use_fast, threads=1)
         c1.correspond(np.ascontiguousarray(pb["init"][:Ks]))   # build the trees outside the timed rounds
         kinds = {}
@@ -142,9 +150,11 @@ def cpu_reference_legs(pb, plane, param, gpu_poses_after, gpu_iters, window_roun
         variants[name] = {"value": rate, "unit": "iterations/s", "cores": 1, "s_per_round": spr, "by_regime": kinds,
                           "sample": f"first {Ks} views ({len(keep)} of {E} edges), scaled x{scale:.2f}"}
     base = variants["O2_1thread"]
+    Ks, keep = sample_views(16)
+    scale = E / max(1, len(keep))
     out["cpu_baseline"] = {
         "value": base["value"], "unit": "iterations/s", "cores": 1, "kind": "port",
-        "sample": (f"reference-equivalent CPU path (real vendored nanoflann + oracle Jet/LM restatement of Ceres; Ceres is not installed).  value = -O2, 1 thread (the "
+        "sample": (f"reference-equivalent CPU path (real vendored nanoflann + oracle Jet/LM restatement of Ceres, pinned on README.md:141-146).  value = -O2, 1 thread (the "
                    f"reference's build and threading) on the first {Ks} views ({len(keep)} of {E} edges, N={len(pb['pts'][0])}): one moving round (round {r_mov}) and one "
                    f"fixed-point round (round {r_fix}) started from the GPU run's poses, scaled x{scale:.2f} by edge count and weighted over the rounds of the timed window.  "
                    f"variants.{'O3_avx2_allcores' if fast else 'O2_threadpool_nn'} = ALL {E} edges, rounds 1..{cpu_rounds} of the registration measured one by one on {ncores} cores"),
@@ -186,10 +196,12 @@ def main():
     ap.add_argument("--allow-host-exchange", action="store_true", help="N > 1 only: if the RCCL communicator cannot be created, fall back to a host-staged gloo all-reduce instead of failing")
     ap.add_argument("--grid-target", type=float, default=None)
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (mvicp_set_option), repeatable; tuning / A-B runs")
-    ap.add_argument("--windows", type=int, default=5, help="the timed window of --steps rounds is repeated this many times; value = the MEDIAN window (all in window_values)")
+    ap.add_argument("--windows", type=int, default=0, help="the timed window of --steps rounds is repeated this many times; value = the MEDIAN window (all in window_values).  "
+                    "0 (default) = at least 5 and as many as make the whole timed region >= 2 s (sized from the first window)")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in leg (bin/multiview on the same problem written to disk, with and without copy-back)")
     args = ap.parse_args()
-    if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or args.windows < 1:
-        print("[bench] --gpus, --steps and --windows must be >= 1 and --warmup >= 0", file=sys.stderr)
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or args.windows < 0:
+        print("[bench] --gpus and --steps must be >= 1, --windows and --warmup >= 0", file=sys.stderr)
         sys.exit(2)
 
     import torch
@@ -239,8 +251,14 @@ def main():
     for kv in args.opt:
         name, val = kv.split("=")
         eng.set_option(name, float(val))
+    t_setup = time.perf_counter()
     eng.set_frames(pb["pts"], pb["nor"])
+    t_frames = time.perf_counter()
     eng.set_graph(pb["src"], pb["dst"])
+    eng.sync()
+    setup_s = {"set_frames_s": t_frames - t_setup, "set_graph_s": time.perf_counter() - t_frames, "total_s": time.perf_counter() - t_setup,
+               "note": "one-off per registration problem: upload + per-cloud structures (k-d order, box hierarchy, matrix-pipe operands, hash) in mvicp_set_frame; "
+                       "buffers + the reference-equivalent trees (tie rule) in mvicp_set_graph.  The reference pays its lazy KD-tree build instead (cpu_baseline...tree_build_s_once)"}
     exchange = "none"
     if world > 1:
         rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
@@ -334,10 +352,10 @@ def main():
     eng.profile_reset()
     # R back-to-back windows of exactly --steps rounds, each bracketed by barrier + synchronize on both sides and reduced with MAX over
     # ranks; `value` is the MEDIAN window (a 20-round window is ~20 ms: one window alone is at the mercy of a single slow launch)
-    R = args.windows
-    NSTEPS = args.steps * R          # rounds under the live scopes (per-step averages below)
+    R = args.windows if args.windows > 0 else 5
     window_s, window_local_s = [], []
-    for w in range(R):
+    w = 0
+    while w < R:
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -350,6 +368,12 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         window_s.append(dt)
+        if w == 0 and args.windows == 0:
+            # size the timed region from the first window: >= 2 s in total (the driver's 5-second GPU-activity sampler then sees it), at most 400 windows;
+            # every rank takes the same decision (dt is the MAX over ranks)
+            R = int(min(400, max(5, np.ceil(2.0 / max(dt, 1e-6)))))
+        w += 1
+    NSTEPS = args.steps * R          # rounds under the live scopes (per-step averages below)
     med = int(np.argsort(window_s)[(R - 1) // 2])   # (lower median for an even count)
     elapsed = window_s[med]
     local_elapsed = window_local_s[med]
@@ -438,7 +462,7 @@ def main():
             return None
         try:
             j = json.load(open(path))
-            if j.get("source_sha16") != sha or j.get("warmup_skipped") != args.warmup or j.get("timed_rounds") != args.steps or j.get("windows", 1) != args.windows:
+            if j.get("source_sha16") != sha or j.get("warmup_skipped") != args.warmup or j.get("timed_rounds") != args.steps or j.get("windows", 1) != R:
                 return None
             sc = j["scopes"][name]
             return (sc["FETCH_SIZE_KiB"] * (2.0 if name == "linearize" else 1.0) + sc["WRITE_SIZE_KiB"]) * 1024.0
@@ -506,6 +530,8 @@ def main():
                          "note": "global round g (warm-up, then timed) = round g % 20 + 1 of registration g // 20 + 1 (main_multiview.cpp:150: 20 rounds); value = all timed "
                                  "rounds; `regimes` splits them by whether the LM solve took a step (moving) or ended without stepping (fixed point: the registration "
                                  "has converged and a round re-verifies it)"},
+            "value_moving_rounds": regime(lambda l: l["moved"]).get("iterations_per_s"), "value_fixed_point_rounds": regime(lambda l: not l["moved"]).get("iterations_per_s"),
+            "timed_region_s": float(sum(window_s)), "setup_s": setup_s,
             "regimes": {"moving_rounds": regime(lambda l: l["moved"]), "fixed_point_rounds": regime(lambda l: not l["moved"]),
                         "rounds_with_bit_identical_poses": int(sum(l["poses_bit_identical"] for l in log))},
             "round_ms": [round(l["nn_ms"] + l["lm_ms"], 4) for l in log], "round_index": window_rounds,
@@ -536,6 +562,15 @@ def main():
             out["comm_launches_per_step"] = timed["comm"][1] / NSTEPS
             out["rccl_nranks"] = eng.comm_nranks() if "rccl" in exchange else None
             out["per_rank"] = per_rank
+        if world == 1 and not args.no_dropin:
+            # the literal drop-in route (bin/multiview: Frame / Session / ICP_Ceres mirror over the C ABI) on the same problem, after the clock stopped
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import dropin_bench
+                eng.close()   # (one context at a time on the device: the driver builds its own)
+                out["dropin"] = dropin_bench.run(pb, param, plane, cutoff, ROUNDS_PER_REGISTRATION)
+            except Exception as ex:
+                out["dropin"] = {"error": repr(ex)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 moved_by_round = [bool(np.any(poses_after[r] != (pb["init"] if r == 1 else poses_after[r - 1]))) for r in sorted(poses_after)]

@@ -115,6 +115,15 @@ int mvicp_reset_history(mvicp_ctx* ctx);
  * RETURNS THE NUMBER OF TRIPLES WRITTEN (>= 0, = counts[e] of the last mvicp_correspond) or a negative mvicp_status;
  * cap is the capacity of the three output arrays (each may be NULL to skip that field). */
 int mvicp_get_correspondences(mvicp_ctx* ctx, int edge, int cap, int* first, int* second, double* dist);
+/* ALL lists of the last mvicp_correspond at once, as the reference lays them out: `struct Correspondance {int first; int second; double
+ * dist;}` (include/frame.h:18-22), ascending `first` within an edge (frame.cpp:129,156-160).  One device pass un-sorts every edge this
+ * rank owns, ONE asynchronous copy brings the triples into pinned host memory OWNED BY THE LIBRARY:
+ *   *triples            -> the buffer;   *offsets -> n_edges + 1 positions: edge e = (*triples)[(*offsets)[e] .. (*offsets)[e + 1])
+ * (zero width for edges of other ranks, edges whose source is fixed and edges that hold an explicit list).  Both pointers stay valid until
+ * the next mvicp_correspond / mvicp_set_correspondences / mvicp_set_graph / mvicp_reset_history / mvicp_destroy on this context.  The
+ * first call after a search does the work, later calls (and mvicp_get_correspondences, which slices the same buffer) are free. */
+typedef struct mvicp_corr { int first; int second; double dist; } mvicp_corr;
+int mvicp_map_correspondences(mvicp_ctx* ctx, const mvicp_corr** triples, const long long** offsets);
 /* Install an explicit list (pairwise known-correspondence case, main_pairwise.cpp:60-61; tests). */
 int mvicp_set_correspondences(mvicp_ctx* ctx, int edge, int n, const int* first, const int* second, float weight);
 

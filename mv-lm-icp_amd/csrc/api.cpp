@@ -149,6 +149,10 @@ void free_graph(mvicp_ctx* c) {
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   c->h_pin = nullptr; c->h_pin_doubles = 0; c->d_res_host = nullptr; c->d_blocks_host = nullptr; c->lin_out = nullptr;
   c->census_pending = false; c->spec_ready = false; c->spec_arm = false; c->d_spec_host = nullptr; c->d_adev_host = nullptr; c->d_res_target = nullptr; c->d_a_check = nullptr;
+  dev_free(c->d_xblock_cnt); c->export_valid = false;
+  if (c->d_export) (void)hipFree(c->d_export);
+  if (c->h_export) (void)hipHostFree(c->h_export);
+  c->d_export = nullptr; c->h_export = nullptr; c->export_cap = 0;
   c->E = 0; c->total_cap = 0; c->n_cblocks = 0; c->n_chunks = 0; c->have_corr = false;
 }
 
@@ -521,7 +525,7 @@ int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) t
   MV_CHECK(dev_alloc(&c->d_stream, 10 * cap));
   MV_CHECK(dev_alloc(&c->d_qpos, cap));
   MV_HIP(hipMemset(c->d_qpos, 0xff, sizeof(int) * std::max<size_t>(cap, 1)));
-  c->list_valid.assign(E, 0);
+  c->list_valid.assign(E, 0); c->explicit_list.assign(E, 0); c->export_valid = false; c->export_off.assign((size_t)E + 1, 0);
   c->dslot_off.assign(E + 1, 0);
   for (int e = 0; e < E; ++e) c->dslot_off[e + 1] = c->dslot_off[e] + (int)(((c->owned[e] ? c->frames[src[e]].n : 0) + 255) / 256);
   c->n_dslots = c->dslot_off[E];
@@ -600,6 +604,7 @@ int mvicp_reset_history(mvicp_ctx* c) try {
   c->auto_prev_dist = 0.0; c->auto_last_method = -1; c->last_rms = -1.0; c->prev_grid_kernel = false;
   c->corr_tie_seen = c->corr_far_seen = 1u;
   c->list_valid.assign(E, 0);                          // every list is re-compacted and re-gathered
+  c->export_valid = false;
   c->sel_med1.assign(E, -1.0); c->sel_med2.assign(E, -1.0);
   c->spec_ready = false; c->spec_arm = false; c->spec_flags_valid = false;
   c->have_corr = false;
@@ -794,7 +799,8 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   c->nn_cache_thresh = thresh;
   c->auto_last_method = handed_over ? MVICP_NN_GRID : method;   // (the policy's "already handed over" state)
   c->nn_cache_edge.assign(c->active.begin(), c->active.end());
-  for (int e = 0; e < E; ++e) c->list_valid[e] = c->active[e];
+  for (int e = 0; e < E; ++e) { c->list_valid[e] = c->active[e]; if (c->active[e]) c->explicit_list[e] = 0; }
+  c->export_valid = false;
 
   mark("host.corr.nn_launch");
   if (!nothing_can_change) {
@@ -891,6 +897,27 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   return MVICP_OK;
 } MVICP_GUARD_ABI
 
+// every exportable edge's list of the last search, un-sorted on the device into the reference's layout and copied once (export.hip)
+static int ensure_export(mvicp_ctx* c) {
+  if (c->export_valid) return MVICP_OK;
+  HostScope hs(c, "host.export");
+  MV_CHECK(launch_export(c));
+  MV_CHECK(stream_wait(c));
+  c->export_valid = true;
+  if (c->profile) prof_collect(c);
+  return MVICP_OK;
+}
+
+int mvicp_map_correspondences(mvicp_ctx* c, const mvicp_corr** triples, const long long** offsets) try {
+  MV_CHECK(bind(c));
+  if (!triples || !offsets) { set_error("null output"); return MVICP_ERR_ARG; }
+  if (!c->have_corr) { set_error("no correspondences yet"); return MVICP_ERR_STATE; }
+  MV_CHECK(ensure_export(c));
+  *triples = (const mvicp_corr*)c->h_export;
+  *offsets = c->export_off.data();
+  return MVICP_OK;
+} MVICP_GUARD_ABI
+
 int mvicp_get_correspondences(mvicp_ctx* c, int edge, int cap, int* first, int* second, double* dist) try {
   MV_CHECK(bind(c));
   if (edge < 0 || edge >= c->E) { set_error("edge %d out of range", edge); return MVICP_ERR_ARG; }
@@ -898,10 +925,22 @@ int mvicp_get_correspondences(mvicp_ctx* c, int edge, int cap, int* first, int* 
   if (!c->owned[edge]) { set_error("edge %d is owned by another rank", edge); return MVICP_ERR_STATE; }
   const int n = c->h_count[edge];
   if (cap < n) { set_error("capacity %d < count %d", cap, n); return MVICP_ERR_ARG; }
+  if (!c->explicit_list[edge]) {
+    // a list built by mvicp_correspond: slice of the one export of this search (first call after a search runs it for ALL edges)
+    if (n == 0) return 0;
+    MV_CHECK(ensure_export(c));
+    const mvicp_corr* t = (const mvicp_corr*)c->h_export + c->export_off[edge];
+    if (c->export_off[edge + 1] - c->export_off[edge] != n) { set_error("export of edge %d holds %lld triples, expected %d", edge, c->export_off[edge + 1] - c->export_off[edge], n); return MVICP_ERR_STATE; }
+    for (int i = 0; i < n; ++i) {
+      if (first) first[i] = t[i].first;
+      if (second) second[i] = t[i].second;
+      if (dist) dist[i] = t[i].dist;
+    }
+    return n;
+  }
+  // an explicit list (mvicp_set_correspondences: any order, repeats allowed) has no per-query positions: host-side un-sort
   const size_t off = (size_t)c->cap_off[edge];
   MV_HIP(hipStreamSynchronize(c->stream));
-  // the device lists hold SORTED positions (curve order of each cloud) in the source's sorted order; hand them back as
-  // the reference builds them: original indices, ascending `first` (frame.cpp:129,158)
   std::vector<int> a(n), b(n);
   std::vector<double> d(n);
   if (n) {
@@ -913,7 +952,7 @@ int mvicp_get_correspondences(mvicp_ctx* c, int edge, int cap, int* first, int* 
   const std::vector<int>& dorder = c->frames[c->edst[edge]].grid.h_order;
   std::vector<int> perm(n);
   for (int i = 0; i < n; ++i) { a[i] = so[a[i]]; b[i] = dorder[b[i]]; perm[i] = i; }
-  std::sort(perm.begin(), perm.end(), [&](int x, int y) { return a[x] < a[y]; });
+  std::stable_sort(perm.begin(), perm.end(), [&](int x, int y) { return a[x] < a[y]; });
   for (int i = 0; i < n; ++i) {
     const int k = perm[i];
     if (first) first[i] = a[k];
@@ -945,7 +984,7 @@ int mvicp_set_correspondences(mvicp_ctx* c, int edge, int n, const int* first, c
   }
   c->nn_cache_valid = false;
   c->spec_ready = false;
-  c->list_valid[edge] = 0;
+  c->list_valid[edge] = 0; c->explicit_list[edge] = 1; c->export_valid = false;
   c->sel_med1[edge] = c->sel_med2[edge] = -1.0;
   const double a = (double)weight;
   MV_HIP(hipMemcpy(c->d_count + edge, &n, sizeof(int), hipMemcpyHostToDevice));

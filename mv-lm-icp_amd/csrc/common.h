@@ -141,6 +141,12 @@ struct mvicp_ctx {
   int* d_dirty = nullptr;           // E: != 0 -> the edge's list (membership or a neighbour) changed this round: re-compact + re-gather
   int* d_dirty_slots = nullptr; int* d_dslot_off = nullptr; std::vector<int> dslot_off; int n_dslots = 0;  // one slot per 256 queries
   std::vector<char> list_valid;     // E: d_qpos / lists describe last round's result of this edge
+  std::vector<char> explicit_list;  // E: the edge's list was installed by mvicp_set_correspondences (arbitrary order / repeats: no d_qpos for it)
+  // the lists in the reference's layout (export.hip): {first, second, dist} triples, ascending first, all exportable edges of the last search
+  void* d_export = nullptr; void* h_export = nullptr; size_t export_cap = 0;   // device staging / pinned host copy (capacity in triples)
+  int* d_xblock_cnt = nullptr;
+  std::vector<long long> export_off; // E+1: edge e's triples = h_export[export_off[e] .. export_off[e + 1])
+  bool export_valid = false;         // h_export holds the lists as they are on the device now
   double* d_stream = nullptr;       // 10 x total_cap SoA: p (3) | n (3) | c = n . q | q (3)   (linearize.hip)
   // compaction scratch
   int n_cblocks = 0;                // total compaction blocks over owned edges
@@ -273,6 +279,7 @@ void free_tie(FrameDev& f);                                                     
 int launch_compact(mvicp_ctx* c, double d2_bound);                                    // corr.hip
 int launch_gather_stream(mvicp_ctx* c);
 int launch_select_median(mvicp_ctx* c);
+int launch_export(mvicp_ctx* c);           // export.hip: every exportable edge's list -> reference-order triples in pinned memory (async; caller waits)
 int launch_select_bracket(mvicp_ctx* c);   // one-pass select around last round's medians (d_sel_lohi); flags edges it cannot answer
 int launch_linearize(mvicp_ctx* c, int plane, int robust);                            // linearize.hip
 int launch_normals(mvicp_ctx* c, FrameDev& f, int k, int* d_knn);                      // normals.hip

@@ -62,14 +62,9 @@ struct VisitBuilder {
     return (int)lo;
   }
 
-  int divide(int first, int last, Box3& box) {
-    const int me = (int)nodes.size();
-    nodes.push_back(VisitNode{last, -1, -1, 0, 0.0, 0.0});
+  // The split of one range: picks axis / cut value, partitions the slots, returns the split position k (first < first + k < last).
+  int split_range(int first, int last, const Box3& box, int& axis_out, double& cut_out) {
     const int count = last - first;
-    if (count <= 1) {                                         // leaf (leaf_max_size = 1): its box is the point itself
-      for (int a = 0; a < 3; ++a) { box.lo[a] = box.hi[a] = count > 0 ? at(first, a) : 0.0; }
-      return me;
-    }
     // cut axis: among the axes whose box extent is within 1e-5 of the largest, the one with the largest spread of the points — where
     // the spread is measured along the axis chosen SO FAR (nanoflann.hpp:1109 passes `cutfeat`, not `i`); kept as it is
     double span_max = box.hi[0] - box.lo[0];
@@ -92,15 +87,57 @@ struct VisitBuilder {
     const int below = sweep(first, count, axis, 0, [cut](double v) { return v < cut; });
     const int upto = sweep(first, count, axis, below, [cut](double v) { return v <= cut; });
     const int half = count / 2;
-    const int k = below > half ? below : (upto < half ? upto : half);
-    Box3 lb = box, rb = box;
-    lb.hi[axis] = cut; rb.lo[axis] = cut;
-    divide(first, first + k, lb);
-    const int right = divide(first + k, last, rb);
-    VisitNode& nd = nodes[me];
-    nd.split = first + k; nd.right = right; nd.axis = axis; nd.lo_cut = lb.hi[axis]; nd.hi_cut = rb.lo[axis];
-    for (int a = 0; a < 3; ++a) { box.lo[a] = std::min(lb.lo[a], rb.lo[a]); box.hi[a] = std::max(lb.hi[a], rb.hi[a]); }
-    return me;
+    axis_out = axis; cut_out = cut;
+    return below > half ? below : (upto < half ? upto : half);
+  }
+
+  // divideTree (nanoflann.hpp:1034-1078) with an EXPLICIT stack: nanoflann recurses once per level, and a degenerate cloud (coordinates in
+  // geometric progression: every middle split peels off one point) is as deep as the exponent range allows — the reference would walk
+  // its call stack that deep; this builder does not depend on it.  Nodes are numbered in pre-order (left child = parent + 1), boxes are
+  // merged bottom-up when a node's right subtree completes, exactly as the recursive form did.
+  int divide(int first0, int last0, Box3& box0) {
+    struct Frame { int me, first, last, k, axis, stage; Box3 box, lb, rb; };   // stage 0: enter, 1: left done, 2: right done
+    std::vector<Frame> st;
+    Box3 ret = box0;      // box handed back by the subtree that has just completed
+    st.push_back(Frame{-1, first0, last0, 0, 0, 0, box0, box0, box0});
+    int root = -1;
+    while (!st.empty()) {
+      Frame& f = st.back();
+      if (f.stage == 0) {
+        f.me = (int)nodes.size();
+        if (root < 0) root = f.me;
+        nodes.push_back(VisitNode{f.last, -1, -1, 0, 0.0, 0.0});
+        const int count = f.last - f.first;
+        if (count <= 1) {                                       // leaf (leaf_max_size = 1): its box is the point itself
+          for (int a = 0; a < 3; ++a) ret.lo[a] = ret.hi[a] = count > 0 ? at(f.first, a) : 0.0;
+          st.pop_back();
+          continue;
+        }
+        double cut;
+        f.k = split_range(f.first, f.last, f.box, f.axis, cut);
+        f.lb = f.box; f.rb = f.box;
+        f.lb.hi[f.axis] = cut; f.rb.lo[f.axis] = cut;
+        f.stage = 1;
+        const Frame child{-1, f.first, f.first + f.k, 0, 0, 0, f.lb, f.lb, f.lb};
+        st.push_back(child);                                    // (f is dangling from here on: re-fetched at the top of the loop)
+        continue;
+      }
+      if (f.stage == 1) {
+        f.lb = ret;                                             // the left subtree's tightened box
+        f.stage = 2;
+        nodes[f.me].right = (int)nodes.size();                  // pre-order: the right child is the next node to be created
+        const Frame child{-1, f.first + f.k, f.last, 0, 0, 0, f.rb, f.rb, f.rb};
+        st.push_back(child);
+        continue;
+      }
+      f.rb = ret;
+      VisitNode& nd = nodes[f.me];
+      nd.split = f.first + f.k; nd.axis = f.axis; nd.lo_cut = f.lb.hi[f.axis]; nd.hi_cut = f.rb.lo[f.axis];
+      for (int a = 0; a < 3; ++a) { ret.lo[a] = std::min(f.lb.lo[a], f.rb.lo[a]); ret.hi[a] = std::max(f.lb.hi[a], f.rb.hi[a]); }
+      st.pop_back();
+    }
+    box0 = ret;
+    return root;
   }
 };
 

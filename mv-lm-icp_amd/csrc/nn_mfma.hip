@@ -163,39 +163,49 @@ __device__ __forceinline__ unsigned int screen(const h8 a, const BlockM& K, cons
   return m;
 }
 
-// fp64 re-evaluation (the reference's arithmetic) of the candidates in the lane's mask; true when the lane's best changed
+// fp64 re-evaluation (the reference's arithmetic) of the candidates in the lane's mask; true when the lane's best changed.
+// One candidate per lane per round, ~7 of 64 lanes busy in a converged round: the round is written WITHOUT control flow apart from the
+// exec-masked record load (round 5: the nested if / else form compiled to five saveexec regions and ~15 register copies per round — 49
+// VALU instructions; this form is selects only).
 template <bool BND, bool CEN>
 __device__ __forceinline__ bool confirm(const TileView& g, int tile, LaneM& L, unsigned int m, Census& C) {
   bool changed = false;
+  const double inf = __longlong_as_double(0x7ff0000000000000ll);
   while (__ballot(m != 0u) != 0ull) {
     MV_CEN(++C.rounds);
-    if (m != 0u) {
-      MV_CEN(++C.conf);
-      const int p = __ffs((int)m) - 1;
-      m &= m - 1u;
-      const int r = p & 15;
-      const int k = tile * LEAF + (r & 3) + 8 * (r >> 2) + 4 * (p >> 4);
-      if (k < g.n) {
-        const double2* pr = reinterpret_cast<const double2*>(g.srec + k);
-        const double2 u = pr[0], v = pr[1];
-        const double d0 = __dsub_rn(L.qx, u.x), d1 = __dsub_rn(L.qy, u.y), d2 = __dsub_rn(L.qz, v.x);
-        const double d = __dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2));
-        const int oi = (int)__double_as_longlong(v.y);
-        // strictly nearer: the new best.  EXACTLY as near as the best (rare): the lower original index keeps the place for now and the query
-        // is reported, so that nn_tie.hip lets the reference's own tree decide (nanoflann keeps the target it visits first)
-        if (d < L.best) {
-          if (BND) L.second = fmin(L.second, L.best);   // the old best (or the cutoff bound: only lowers the bound) is now "another target"
-          L.best = d; L.bi = oi; L.bpos = k; changed = true;
-        } else if (d == L.best) {
-          if (oi != L.bi) {
-            if (BND) L.second = fmin(L.second, d); else L.tie = true;   // (BND builds read the tie off second == best at the end)
-            if (oi < L.bi) { L.bi = oi; L.bpos = k; changed = true; }
-          }
-        } else if (BND) {
-          L.second = fmin(L.second, d);
-        }
-      }
+    MV_CEN(C.conf += m != 0u ? 1u : 0u);
+    const bool has = m != 0u;
+    const int p = __ffs((int)m) - 1;   // (m == 0: -1, masked by `has`)
+    m &= m - 1u;
+    const int r = p & 15;
+    const int k = tile * LEAF + (r & 3) + 8 * (r >> 2) + 4 * ((p >> 4) & 1);
+    const bool valid = has && k < g.n;
+    double2 u = make_double2(0.0, 0.0), v = make_double2(0.0, 0.0);
+    if (valid) {
+      const double2* pr = reinterpret_cast<const double2*>(g.srec + k);
+      u = pr[0]; v = pr[1];
     }
+    const double d0 = __dsub_rn(L.qx, u.x), d1 = __dsub_rn(L.qy, u.y), d2 = __dsub_rn(L.qz, v.x);
+    const double d = __dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2));
+    const int oi = (int)__double_as_longlong(v.y);
+    // strictly nearer: the new best.  EXACTLY as near as the best (rare): the lower original index keeps the place for now and the query
+    // is reported, so that nn_tie.hip lets the reference's own tree decide (nanoflann keeps the target it visits first)
+    const bool lt = valid && d < L.best;
+    const bool other = valid && oi != L.bi;           // a target that is not the running best itself
+    const bool eq = other && d == L.best;
+    const bool take = lt || (eq && oi < L.bi);
+    if (BND) {
+      // second = smallest exact d2 among the evaluated targets other than the running best: the OLD best when it is displaced (or the
+      // cutoff bound: only lowers the bound), d itself otherwise (BND builds read the tie off second == best at the end)
+      const double s2 = lt ? L.best : (other ? d : inf);
+      L.second = fmin(L.second, s2);
+    } else {
+      L.tie = L.tie || eq;
+    }
+    L.best = lt ? d : L.best;
+    L.bi = take ? oi : L.bi;
+    L.bpos = take ? k : L.bpos;
+    changed = changed || take;
   }
   return changed;
 }
@@ -661,6 +671,7 @@ int launch_nn_mfma_edges(mvicp_ctx* c, double d2_bound, bool with_bounds, bool w
     for (const TileJob& j : jobs) if (j.seed) unseeded = false;
     if (unseeded && !with_bounds && top == 2 && !d_stats) MVICP_MFMA_L(5, 2, false, false, true);   // no seed anywhere: per-lane box test per tile (scan_block)
     else if (unseeded && !with_bounds && top == 2) MVICP_MFMA_L(5, 2, false, true, true);
+    else if (with_bounds && with_cache && top == 2 && c->mfma_lbt >= 2 && !d_stats) MVICP_MFMA_L(5, 2, true, false, true);   // cache-aware round (tile_mfma = 2): most lanes sit out, so the per-lane box test prunes nearly every tile
     else if (with_bounds) {
       if (top == 2) MVICP_MFMA_K(5, 2, true); else MVICP_MFMA_K(5, -1, true);
     }

@@ -23,9 +23,32 @@ namespace mvicp {
 // (Pinned, not guessed: with that duplicate the pairwise known-answer test reproduces README.md:141-146 to all six printed digits;
 // without it, or with a zeroed first field, the fourth digit differs — profiles/r05_lm_pin_sweep.txt.)  keep_phantom = true is the
 // reference's behaviour and the default; false (--drop_phantom_row) loads exactly the rows of the file.
+// Extension (benchmark datasets only): a file that starts with the 8 bytes "MVXYZB1\n" holds, after them, an int64 row count and the rows as raw
+// little-endian doubles (x y z nx ny nz) — a 32 x 200 k-point dataset loads in a second instead of a minute of text parsing.  The same
+// duplicated last row is appended, so a binary file stands for the text file with the same rows.
 inline bool loadXYZ(const std::string& filename, std::vector<Vector3d>& pts, std::vector<Vector3d>& nor, bool keep_phantom = true) {
-  std::ifstream file(filename.c_str());
+  std::ifstream file(filename.c_str(), std::ios::binary);
   if (file.fail()) { std::cerr << filename << " could not be opened" << std::endl; return false; }
+  {
+    char magic[8] = {0};
+    file.read(magic, 8);
+    if (file.gcount() == 8 && std::string(magic, 8) == "MVXYZB1\n") {
+      long long rows = 0;
+      file.read(reinterpret_cast<char*>(&rows), 8);
+      if (!file || rows < 0) { std::cerr << filename << ": bad binary header" << std::endl; return false; }
+      std::vector<double> raw(6 * (size_t)rows);
+      file.read(reinterpret_cast<char*>(raw.data()), (std::streamsize)(raw.size() * sizeof(double)));
+      if ((size_t)file.gcount() != raw.size() * sizeof(double)) { std::cerr << filename << ": truncated" << std::endl; return false; }
+      for (long long r = 0; r < rows; ++r) {
+        pts.push_back(Vector3d(raw[6 * r], raw[6 * r + 1], raw[6 * r + 2]));
+        nor.push_back(Vector3d(raw[6 * r + 3], raw[6 * r + 4], raw[6 * r + 5]));
+      }
+      if (keep_phantom && !pts.empty()) { pts.push_back(pts.back()); nor.push_back(nor.back()); }
+      return true;
+    }
+    file.clear();
+    file.seekg(0);
+  }
   while (true) {
     double b[6];
     bool ok = true;

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <numeric>
 #include <stdexcept>
+#include <thread>
 
 namespace mvicp {
 
@@ -76,6 +77,9 @@ void Session::correspond(std::vector<std::shared_ptr<Frame>>& frames, float thre
   last_poses = P;
   last_thresh = thresh;
   last_fixed = fx;
+  corr = nullptr; corr_off = nullptr;
+  // the literal drop-in contract: every list in the reference's layout, un-sorted on the device, ONE copy per round for all edges
+  if (copy_back) check(mvicp_map_correspondences(ctx, &corr, &corr_off));
 }
 
 void Session::optimize(std::vector<std::shared_ptr<Frame>>& frames, int param, bool pointToPlane, bool robust, mvicp_summary* out) {
@@ -107,6 +111,24 @@ void Frame::computePoseNeighboursKnn(std::vector<std::shared_ptr<Frame>>* frames
   }
 }
 
+// dst[i] <- src[i] for a few (destination, source, bytes) pieces on up to `threads` host threads (a frame's lists are a few megabytes
+// each: one thread copies at ~5 GB/s, the memory system takes eight such streams)
+static void parallel_copy(const std::vector<std::pair<std::pair<char*, const char*>, size_t>>& pieces, int threads) {
+  size_t total = 0;
+  for (const auto& p : pieces) total += p.second;
+  const size_t chunk = 512 << 10;
+  struct Job { char* d; const char* s; size_t n; };
+  std::vector<Job> jobs;
+  for (const auto& p : pieces)
+    for (size_t o = 0; o < p.second; o += chunk) jobs.push_back(Job{p.first.first + o, p.first.second + o, std::min(chunk, p.second - o)});
+  const int nt = (int)std::min<size_t>((size_t)std::max(1, threads), jobs.size());
+  if (nt <= 1 || total < (2u << 20)) { for (const Job& j : jobs) std::memcpy(j.d, j.s, j.n); return; }
+  std::vector<std::thread> pool;
+  for (int t = 1; t < nt; ++t) pool.emplace_back([&, t]() { for (size_t k = t; k < jobs.size(); k += nt) std::memcpy(jobs[k].d, jobs[k].s, jobs[k].n); });
+  for (size_t k = 0; k < jobs.size(); k += nt) std::memcpy(jobs[k].d, jobs[k].s, jobs[k].n);
+  for (auto& th : pool) th.join();
+}
+
 void Frame::computeClosestPointsToNeighbours(std::vector<std::shared_ptr<Frame>>* frames, float thresh) {
   if (fixed) return;  // frame.cpp:93
   Session& S = Session::get();
@@ -115,19 +137,16 @@ void Frame::computeClosestPointsToNeighbours(std::vector<std::shared_ptr<Frame>>
   for (size_t i = 0; i < frames->size(); ++i) {
     Frame& f = *(*frames)[i];
     if (&f != this) { e += f.neighbours.size(); continue; }
+    std::vector<std::pair<std::pair<char*, const char*>, size_t>> pieces;
     for (OutgoingEdge& edge : f.neighbours) {
       edge.weight = S.weights[e];
-      edge.correspondances.clear();
-      if (S.copy_back && S.counts[e] > 0) {
-        const int n = S.counts[e];
-        std::vector<int> a(n), b(n);
-        std::vector<double> d(n);
-        check(mvicp_get_correspondences(S.ctx, (int)e, n, a.data(), b.data(), d.data()));
-        edge.correspondances.resize(n);
-        for (int k = 0; k < n; ++k) edge.correspondances[k] = Correspondance{a[k], b[k], d[k]};
-      }
+      const size_t n = S.copy_back && S.corr ? (size_t)(S.corr_off[e + 1] - S.corr_off[e]) : 0;
+      // frame.cpp:110,158: clear(), then one push_back per kept pair — here the finished slice of the mapped triples (same layout)
+      edge.correspondances.resize(n);
+      if (n) pieces.push_back(std::make_pair(std::make_pair((char*)edge.correspondances.data(), (const char*)(S.corr + S.corr_off[e])), n * sizeof(Correspondance)));
       ++e;
     }
+    parallel_copy(pieces, S.copy_threads);
     break;
   }
 }

@@ -18,6 +18,7 @@
 namespace mvicp {
 
 struct Correspondance { int first; int second; double dist; };
+static_assert(sizeof(Correspondance) == sizeof(mvicp_corr), "mvicp_corr is the reference's Correspondance (include/frame.h:18-22)");
 
 struct OutgoingEdge {
   int neighbourIdx;
@@ -57,6 +58,8 @@ struct Session {
   mvicp_ctx* ctx = nullptr;
   int device = 0;
   bool copy_back = true;  // fill Frame::neighbours[].correspondances after the search (off: device-only, faster)
+  int copy_threads = 8;   // host threads that slice the mapped triples into a frame's vectors (1 = the calling thread alone)
+  const mvicp_corr* corr = nullptr; const long long* corr_off = nullptr;   // mvicp_map_correspondences of the current search (library-owned, pinned)
   int nn_method = MVICP_NN_AUTO;
   const void* frames_key = nullptr;
   // what the device copy was built from: per frame {Frame*, pts data, size, nor data, normals version}; any difference

@@ -1,7 +1,8 @@
 // Headless counterpart of the reference's src/main_multiview.cpp (same flags, same loop, no viewer):
 //   loadFrames (:53-100) -> frames[0]->fixed = true (:141) -> computePoseNeighbours (:104-117, once) ->
 //   20 x { computeClosestPoints (:119-127) ; ceresOptimizer* (:158-161) }
-// Extra flags: --rounds (20), --out DIR (write final poses as pose_<i>.txt, 4x4 row-major), --device, --copyback,
+// Extra flags: --rounds (20), --out DIR (write final poses as pose_<i>.txt, 4x4 row-major), --device, --copyback (default on: fill
+// Frame::neighbours[].correspondances every round — one device un-sort + one pinned copy for all edges, sliced by --copy_threads (8) host threads),
 // --drop_phantom_row (load exactly the files' rows; default: the reference's loadXYZ, which appends a duplicate of the last row),
 // --noise_stream libstdc++|libc++ (std::normal_distribution's variate order for addNoise; default = this build's libstdc++), --quiet, --dump_corr DIR (after the LAST round's search
 // write every Frame::neighbours[j] as corr_<src>_<j>.txt: a header line `dst weight count`, then `first second dist` rows),
@@ -52,6 +53,7 @@ int main(int argc, char** argv) {
   const std::string dir = F.s("dir", "../samples/Bunny_RealData"), out = F.s("out", "");
   Session::get().device = F.i("device", 0);
   Session::get().copy_back = F.b("copyback", true);
+  Session::get().copy_threads = F.i("copy_threads", 8);
   noiseStream() = F.s("noise_stream", "libstdc++") == "libc++" ? 1 : 0;
 
   std::vector<std::shared_ptr<Frame>> frames;
@@ -68,6 +70,7 @@ int main(int argc, char** argv) {
       std::cout << std::endl;
     }
   }
+  double wall_search = 0.0, wall_solve = 0.0;
   std::ofstream trace;
   if (!F.s("trace", "").empty()) { trace.open(F.s("trace", "").c_str()); trace.precision(17); }
   try {
@@ -131,6 +134,8 @@ int main(int argc, char** argv) {
           for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) trace << " " << frames[i]->pose.m[a + 4 * b];
           trace << "\n";
         }
+      wall_search += std::chrono::duration<double, std::milli>(t1 - t0).count();
+      wall_solve += std::chrono::duration<double, std::milli>(t2 - t1).count();
       if (!quiet)
         std::cout << "round: " << r << "  closest pts " << std::chrono::duration<double, std::milli>(t1 - t0).count() << " ms  global "
                   << std::chrono::duration<double, std::milli>(t2 - t1).count() << " ms" << std::endl;
@@ -139,6 +144,9 @@ int main(int argc, char** argv) {
     std::cerr << ex.what() << std::endl;
     return 2;
   }
+  // whole-loop wall clock of the drop-in route (Frame API + session + copy-back): parsed by bench.py / tools/dropin_bench.py
+  std::cout << "loop: rounds " << rounds << " copyback " << (Session::get().copy_back ? 1 : 0) << " closest_pts_ms " << wall_search << " global_ms " << wall_solve
+            << " it_per_s " << (rounds > 0 ? 1e3 * rounds / (wall_search + wall_solve) : 0.0) << std::endl;
   for (size_t i = 0; i < frames.size(); ++i) {
     if (!quiet) std::cout << "frame " << i << poseDiff(frames[i]->pose, frames[i]->poseGroundTruth);
     if (!out.empty()) saveMatrix4d(out + "/pose_" + std::to_string(i) + ".txt", frames[i]->pose);

@@ -14,7 +14,7 @@ EDGE_BLOCK = 91
 SYMBOLS = [
     "mvicp_last_error", "mvicp_version", "mvicp_create", "mvicp_destroy", "mvicp_set_num_frames", "mvicp_set_frame",
     "mvicp_recompute_normals", "mvicp_set_graph", "mvicp_set_shard", "mvicp_edge_owner", "mvicp_comm_unique_id", "mvicp_comm_init", "mvicp_comm_nranks", "mvicp_comm_set_callback", "mvicp_correspond",
-    "mvicp_get_correspondences", "mvicp_set_correspondences", "mvicp_nn_query", "mvicp_linearize", "mvicp_optimize",
+    "mvicp_get_correspondences", "mvicp_map_correspondences", "mvicp_set_correspondences", "mvicp_nn_query", "mvicp_linearize", "mvicp_optimize",
     "mvicp_lm_solve", "mvicp_set_option", "mvicp_nn_census", "mvicp_nn_census_ex", "mvicp_reset_history", "mvicp_profile_enable", "mvicp_profile_reset", "mvicp_profile_get", "mvicp_profile_get_ex", "mvicp_stream", "mvicp_sync",
     "mvicp_closedform_point_to_point", "mvicp_closedform_point_to_plane",
 ]
@@ -64,6 +64,7 @@ def load_library(path=None):
     lib.mvicp_comm_nranks.argtypes = [vp]
     lib.mvicp_correspond.argtypes = [vp, dp, u8p, C.c_float, C.c_int, ip, fp]
     lib.mvicp_get_correspondences.argtypes = [vp, C.c_int, C.c_int, ip, ip, dp]
+    lib.mvicp_map_correspondences.argtypes = [vp, C.POINTER(vp), C.POINTER(C.POINTER(C.c_longlong))]
     lib.mvicp_set_correspondences.argtypes = [vp, C.c_int, C.c_int, ip, ip, C.c_float]
     lib.mvicp_nn_query.argtypes = [vp, C.c_int, dp, C.c_int, C.c_int, ip, dp]
     lib.mvicp_linearize.argtypes = [vp, dp, C.c_int, C.c_int, dp]
@@ -294,6 +295,22 @@ class Engine:
         dist = np.zeros(cap, dtype=np.float64)
         n = _check(self.lib, self.lib.mvicp_get_correspondences(self.h, edge, cap, _ip(first), _ip(second), _dp(dist)))
         return first[:n].copy(), second[:n].copy(), dist[:n].copy()
+
+    CORR_DTYPE = np.dtype([("first", np.int32), ("second", np.int32), ("dist", np.float64)])   # struct Correspondance (include/frame.h:18-22)
+
+    def map_correspondences(self, copy=True):
+        """ALL lists of the last correspond() in the reference's layout: (triples, offsets) — a structured array of {first, second, dist}
+        and E + 1 positions; edge e = triples[offsets[e]:offsets[e + 1]], ascending `first`.  copy=False returns a VIEW of the library's
+        pinned buffer, valid until the next correspond() / set_correspondences() on this engine."""
+        tp, op = C.c_void_p(), C.POINTER(C.c_longlong)()
+        _check(self.lib, self.lib.mvicp_map_correspondences(self.h, C.byref(tp), C.byref(op)))
+        off = np.ctypeslib.as_array(op, shape=(self.E + 1,)).copy()
+        total = int(off[-1])
+        if total == 0:
+            return np.zeros(0, dtype=self.CORR_DTYPE), off
+        buf = (C.c_char * (16 * total)).from_address(tp.value)
+        t = np.frombuffer(buf, dtype=self.CORR_DTYPE, count=total)
+        return (t.copy() if copy else t), off
 
     def set_correspondences(self, edge, first, second, weight=0.0):
         first = np.ascontiguousarray(first, dtype=np.int32)

@@ -1105,3 +1105,80 @@ def test_far_queries_and_unbounded_search(orc, factor, mfma):
                     assert np.array_equal(gf, f) and np.array_equal(gs, sec) and np.array_equal(gd, dist), (factor, mfma, float(thresh), r, k)
     finally:
         e.close()
+
+
+# ---------------------------------------------------------------- the lists in the reference's layout, all edges at once (export.hip)
+@pytest.mark.parametrize("thresh", [0.05, 0.006])
+def test_map_correspondences_is_the_reference_layout(eng, orc, thresh):
+    """mvicp_map_correspondences = Frame::neighbours[j].correspondances of every edge (frame.cpp:129,156-160; frame.h:18-22): triples
+    {first, second, dist} in ascending first — device un-sort + one copy — against the oracle's own loop, bit for bit (dist = the IEEE
+    sqrt of d2, frame.cpp:139), over a registration: moving rounds (lists re-compacted), cache-aware rounds (entries patched in place)
+    and fixed-point rounds (nothing rewritten); with a loose cutoff (every query kept) and a tight one (a third rejected, membership changes)."""
+    pb = synth.make_problem(5, 6000, cone_deg=40.0 if thresh < 0.01 else 100.0, sigma=0.004 if thresh < 0.01 else 0.02, sigmat=0.002 if thresh < 0.01 else 0.01)
+    eng.set_frames(pb["pts"], pb["nor"]); eng.set_graph(pb["src"], pb["dst"])
+    eng.reset_history()
+    poses = pb["init"].copy()
+    for rnd in range(9):
+        counts, weights = eng.correspond(poses, pb["fixed"], thresh)
+        trip, off = eng.map_correspondences()
+        assert off[0] == 0 and np.array_equal(np.diff(off), counts)
+        if rnd in (0, 1, 4, 8):
+            for e, (s, d) in enumerate(zip(pb["src"], pb["dst"])):
+                f, sec, dist, w, _, _ = orc.correspond_edge(pb["pts"][s], poses[s], pb["pts"][d], poses[d], thresh)
+                t = trip[off[e]:off[e + 1]]
+                assert np.array_equal(t["first"], f) and np.array_equal(t["second"], sec), (rnd, e)
+                assert t["dist"].tobytes() == dist.tobytes(), (rnd, e)
+                gf, gs, gd = eng.get_correspondences(e)     # the per-edge call slices the same export
+                assert np.array_equal(gf, f) and np.array_equal(gs, sec) and gd.tobytes() == dist.tobytes()
+            if thresh < 0.01 and rnd == 0:
+                assert counts.sum() < 0.95 * sum(len(pb["pts"][s]) for s in pb["src"])   # the cutoff does reject queries here
+        poses, sm = eng.optimize(poses, pb["fixed"], L.PARAM_SOPHUS_SE3, 1, True, 50)
+    # a second map call without a search in between is the same buffer (no work), also as a zero-copy view
+    v, off2 = eng.map_correspondences(copy=False)
+    assert np.array_equal(off, off2) and np.array_equal(v, trip)
+
+
+def test_map_correspondences_skips_explicit_and_fixed_edges(eng, orc):
+    """Edges whose source is fixed are never searched (frame.cpp:93) and an edge that holds an explicit list (mvicp_set_correspondences: any
+    order, repeats) has no per-query positions: both have zero width in the map; mvicp_get_correspondences still returns the explicit list
+    in ascending-first order; the next search puts the edge back."""
+    pb = synth.make_problem(3, 3000)
+    src, dst = synth.pose_graph_knn(pb["init"], 2, skip_fixed0=False)   # frame 0's own edges included
+    eng.set_frames(pb["pts"], pb["nor"]); eng.set_graph(src, dst)
+    counts, _ = eng.correspond(pb["init"], pb["fixed"], 0.05)
+    trip, off = eng.map_correspondences()
+    assert np.array_equal(np.diff(off), counts) and np.all(counts[src == 0] == 0) and np.all(counts[src != 0] > 0)
+    e = int(np.flatnonzero(src != 0)[0])
+    rng = np.random.default_rng(5)
+    fi = rng.integers(0, len(pb["pts"][src[e]]), 500).astype(np.int32); se = rng.integers(0, len(pb["pts"][dst[e]]), 500).astype(np.int32)
+    eng.set_correspondences(e, fi, se, 0.01)
+    trip2, off2 = eng.map_correspondences()
+    assert off2[e + 1] == off2[e]
+    others = [k for k in range(len(src)) if k != e]
+    for k in others:
+        assert np.array_equal(trip2[off2[k]:off2[k + 1]], trip[off[k]:off[k + 1]])
+    gf, gs, gd = eng.get_correspondences(e)
+    order = np.argsort(fi, kind="stable")
+    assert np.array_equal(gf, fi[order]) and np.array_equal(gs, se[order]) and np.all(gd == 0)
+    counts3, _ = eng.correspond(pb["init"], pb["fixed"], 0.05)
+    trip3, off3 = eng.map_correspondences()
+    assert np.array_equal(counts3, counts) and np.array_equal(trip3, trip) and np.array_equal(off3, off)
+
+
+def test_device_sqrt_is_the_ieee_sqrt(eng):
+    """export.hip hands back dist = __dsqrt_rn(d2): must equal the host's correctly rounded sqrt (frame.cpp:139) for every d2 — checked through
+    the product path on a cloud whose query distances cover twelve decades (explicit targets at random distances from the queries)."""
+    rng = np.random.default_rng(11)
+    n = 200000
+    dst = rng.uniform(-1, 1, (n, 3))
+    r = 10.0 ** rng.uniform(-9, 0, n)
+    u = rng.normal(0, 1, (n, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    srcp = dst + u * r[:, None] * 1e-3
+    eng.set_frames([dst, srcp], None); eng.set_graph([1], [0])
+    P = np.array([np.eye(4), np.eye(4)])
+    counts, _ = eng.correspond(P, [1, 0], 0.05)
+    trip, off = eng.map_correspondences()
+    idx, d2 = eng.nn_query(0, srcp[trip["first"]])
+    assert counts[0] > 0.99 * n and np.array_equal(idx, trip["second"])
+    assert np.sqrt(d2).tobytes() == trip["dist"].tobytes()
+    assert trip["dist"].min() < 1e-11 and trip["dist"].max() > 1e-4

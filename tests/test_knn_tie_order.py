@@ -53,3 +53,18 @@ def test_tie_order_on_a_lattice_with_duplicate_points(harness, refnn):
     gi, _ = refnn.knn_self(pts, 10)
     got, _ = knn(harness, pts, 10)
     assert np.array_equal(got, gi)
+
+
+def test_degenerate_depth_is_not_a_recursion_depth(harness, refnn):
+    """A cloud whose coordinates form a geometric progression: every middle split (nanoflann.hpp:1034-1078) peels ONE point off, so the
+    tree is as deep as it has points (900 levels here; the exponent range of a double allows ~2000).  The product's builder walks it with an explicit
+    stack (kdvisit.h divide) and must still agree with the real nanoflann (which recurses that deep), ties and all."""
+    if refnn is None:
+        pytest.skip("oracle/_ref not built")
+    x = 2.0 ** np.arange(-450, 450, dtype=np.float64)                     # (squared distances stay finite)
+    pts = np.stack([x, np.zeros_like(x), np.zeros_like(x)], 1)
+    pts = np.vstack([pts, pts[::7]])                                    # + duplicates
+    gi, _ = refnn.knn_self(pts, 10)
+    got, nodes = knn(harness, pts, 10)
+    assert nodes == 2 * len(pts) - 1
+    assert np.array_equal(got, gi)

@@ -1,0 +1,89 @@
+"""Wall-clock rate of the LITERAL drop-in route: mv-lm-icp_amd/bin/multiview (host mirror of the reference's main_multiview.cpp:
+Frame / Session / ICP_Ceres over the C ABI) on a dataset written in the reference's on-disk layout, with the reference's contract
+`Frame::neighbours[j].correspondances` filled every round (--copyback, default on) and without it.
+
+    python tools/dropin_bench.py [--workload cfg4] [--rounds 20]
+
+One JSON object on stdout (bench.py embeds the same dict as its `dropin` key).  The clouds are written in the binary variant of the
+.xyz rows (host/common_io.h: same rows, no text parsing) with --drop_phantom_row so that the driver registers exactly the problem of
+bench.py's workload; load + structure-build time is reported separately (`setup_s`), the rate is the driver's own clock over its
+round loop (computeClosestPointsToNeighbours for every frame + ceresOptimizer_*), as the reference's CPUTimer brackets it."""
+import argparse
+import json
+import os
+import re
+import shutil
+import struct
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mv-lm-icp_amd"))
+
+import numpy as np  # noqa: E402
+
+BIN = os.path.join(ROOT, "mv-lm-icp_amd", "bin", "multiview")
+
+
+def write_binary_dataset(d, pb):
+    for i, (p, n) in enumerate(zip(pb["pts"], pb["nor"])):
+        with open(os.path.join(d, f"cloud_{i}.xyz"), "wb") as f:
+            f.write(b"MVXYZB1\n")
+            f.write(struct.pack("<q", len(p)))
+            np.ascontiguousarray(np.hstack([p, n]), dtype="<f8").tofile(f)
+        np.savetxt(os.path.join(d, f"pose_{i}.txt"), pb["init"][i], fmt="%.17g")
+        np.savetxt(os.path.join(d, f"groundtruth_{i}.txt"), pb["gt"][i], fmt="%.17g")
+
+
+def run(pb, param, plane, cutoff, rounds=20, tmp_root=None, timeout=600):
+    """-> dict: per mode {it_per_s, closest_pts_ms_per_round, global_ms_per_round, per_round}; needs a GPU."""
+    d = tempfile.mkdtemp(prefix="mvicp_dropin_", dir=tmp_root)
+    try:
+        write_binary_dataset(d, pb)
+        flags = ["--dir", d, "--step", "1", "--limit", str(len(pb["pts"])), "--rounds", str(rounds), "--norecomputeNormals", "--drop_phantom_row",
+                 "--cutoff", repr(float(cutoff))]
+        flags += {0: ["--nosophusSE3"], 1: ["--nosophusSE3", "--angleAxis"], 2: []}[param]
+        if not plane:
+            flags += ["--nopointToPlane"]
+        out = {"driver": "mv-lm-icp_amd/bin/multiview", "rounds": rounds, "views": len(pb["pts"]), "pts_per_view": len(pb["pts"][0])}
+        for mode, extra in (("copyback", ["--copyback"]), ("device_only", ["--nocopyback"])):
+            t0 = time.perf_counter()
+            txt = subprocess.check_output([BIN] + flags + extra, timeout=timeout).decode()
+            wall = time.perf_counter() - t0
+            m = re.search(r"loop: rounds (\d+) copyback (\d) closest_pts_ms ([0-9.e+-]+) global_ms ([0-9.e+-]+) it_per_s ([0-9.e+-]+)", txt)
+            per = [(float(a), float(b)) for a, b in re.findall(r"round: \d+\s+closest pts ([0-9.e+-]+) ms\s+global ([0-9.e+-]+) ms", txt)]
+            n = int(m.group(1))
+            out[mode] = {"it_per_s": float(m.group(5)), "closest_pts_ms_per_round": float(m.group(3)) / n, "global_ms_per_round": float(m.group(4)) / n,
+                         "process_wall_s": wall, "setup_s": wall - (float(m.group(3)) + float(m.group(4))) * 1e-3,
+                         "round_ms": [round(a + b, 3) for a, b in per]}
+        nt = sum(len(p) for p in pb["pts"][1:]) * 2
+        out["copyback"]["triples_per_round_upper_bound"] = nt
+        out["note"] = ("whole-loop wall clock of the driver (its own steady_clock around the 20 rounds: Frame::computeClosestPointsToNeighbours for every frame + "
+                       "ICP_Ceres::ceresOptimizer_*), first round included (it allocates the vectors and the pinned buffer); copyback = the reference's contract "
+                       "(Frame::neighbours[j].correspondances filled every round: one device un-sort + one pinned copy + host slicing), device_only = lists stay on the GPU")
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="cfg4")
+    ap.add_argument("--rounds", type=int, default=20)
+    args = ap.parse_args()
+    sys.path.insert(0, ROOT)
+    import bench
+    from mvicp import synth
+    K, N, plane, param, desc = bench.WORKLOADS[args.workload]
+    extra = dict(bench.WORKLOAD_EXTRAS.get(args.workload, {}))
+    cutoff = extra.pop("cutoff", 0.05)
+    pb = synth.make_problem(K, N, **extra)
+    res = run(pb, param, plane, cutoff, args.rounds)
+    res["workload"] = desc
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

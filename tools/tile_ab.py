@@ -39,5 +39,7 @@ for v in variants:
         ref = trace
     else:
         same = all(np.array_equal(a[0], b[0]) and a[1].tobytes() == b[1].tobytes() and np.array_equal(a[2], b[2]) for a, b in zip(ref, trace))
-    print(f"[{v or 'defaults'}] nn_ms per round: {rows}  sum {sum(x if not isinstance(x, tuple) else x[0] for x in rows):.3f}  identical_to_first: {same}", flush=True)
+    import hashlib
+    dg = hashlib.sha256(b"".join(a[0].tobytes() + a[1].tobytes() + a[2].tobytes() for a in trace)).hexdigest()[:12]   # compare across processes (MVICP_LIB builds)
+    print(f"[{v or 'defaults'}] nn_ms per round: {rows}  sum {sum(x if not isinstance(x, tuple) else x[0] for x in rows):.3f}  identical_to_first: {same}  digest {dg}", flush=True)
     eng.close()
