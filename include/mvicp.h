@@ -62,7 +62,10 @@ int mvicp_destroy(mvicp_ctx* ctx);
 /* ---- data upload (once; clouds are static in their local frame) ------------------------------- */
 /* Replaces Frame::pts / Frame::nor as the kernel-visible copy (include/frame.h:38-39) and the lazy
  * KD-tree build of Frame::getClosestPoint (src/internal/frame.cpp:188-193): the per-cloud NN
- * structure is built here, once.  nrm may be NULL (point-to-point only). */
+ * structure is built here, once.  nrm may be NULL (point-to-point only).  The call returns when the cloud is on the device; the
+ * structures themselves (k-d order, box hierarchy, matrix-pipe operands, hash) are built behind it on a host thread from a private copy
+ * of the cloud, so that the clouds of an upload loop are built side by side (option "async_build", default 1); the first entry point that
+ * needs a structure (mvicp_set_graph, mvicp_nn_query, mvicp_recompute_normals) waits for the pending builds and reports a failed one. */
 int mvicp_set_num_frames(mvicp_ctx* ctx, int n_frames);
 int mvicp_set_frame(mvicp_ctx* ctx, int frame, const double* xyz, const double* nrm, int n);
 

@@ -5,8 +5,11 @@
 #include <cmath>
 #include <cstring>
 #include <ctime>
+#include <condition_variable>
 #include <exception>
+#include <mutex>
 #include <new>
+#include <thread>
 
 #include "common.h"
 #include "comm.h"
@@ -269,6 +272,48 @@ void census_resolve(mvicp_ctx* c) {
   }
 }
 
+// ---- background structure builds (mvicp_set_frame) ---------------------------------------------------------------------------------------
+namespace {
+// at most one build per hardware thread at a time (each build forks a few threads of its own for the k-d order)
+struct BuildSlots {
+  std::mutex m; std::condition_variable cv; int free_slots;
+  BuildSlots() : free_slots((int)std::max(2u, std::min(32u, std::thread::hardware_concurrency()))) {}
+  void acquire() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [this]() { return free_slots > 0; }); --free_slots; }
+  void release() { { std::lock_guard<std::mutex> lk(m); ++free_slots; } cv.notify_one(); }
+};
+BuildSlots& build_slots() { static BuildSlots s; return s; }
+}  // namespace
+
+// upload of the normals in the cloud's sorted order (needs the order the build produced)
+static int upload_sorted_normals(FrameDev& f, const double* nrm) {
+  const int n = f.n;
+  std::vector<double> sn(3 * (size_t)n);
+  for (int i = 0; i < n; ++i) std::memcpy(&sn[3 * (size_t)i], nrm + 3 * (size_t)f.grid.h_order[i], 24);
+  MV_HIP(hipMalloc((void**)&f.grid.snor, sizeof(double) * 3 * (size_t)std::max(n, 1)));
+  MV_HIP(hipMemcpy(f.grid.snor, sn.data(), sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice));
+  return MVICP_OK;
+}
+
+static int build_frame_structures(mvicp_ctx* c, FrameDev& f, const double* xyz, const double* nrm) {
+  MV_CHECK(build_grid(c, f, xyz));
+  if (nrm) MV_CHECK(upload_sorted_normals(f, nrm));
+  return MVICP_OK;
+}
+
+int finish_builds(mvicp_ctx* c) {
+  int st = MVICP_OK;
+  std::string msg;
+  for (FrameDev& f : c->frames) {
+    if (!f.job) continue;
+    int s1 = MVICP_ERR_INTERNAL;
+    try { s1 = f.job->fut.get(); } catch (...) { f.job->err = "structure build threw"; }
+    if (s1 != MVICP_OK && st == MVICP_OK) { st = s1; msg = f.job->err; }
+    f.job.reset();
+  }
+  if (st != MVICP_OK) set_error("%s", msg.c_str());
+  return st;
+}
+
 // One device evaluation of all per-edge blocks at `poses` -> host `out` (E x 91), all-reduced over ranks.
 int evaluate_blocks(mvicp_ctx* c, const double* poses, int plane, int robust, double* out) {
   if (!c->have_corr) { set_error("no correspondences: call mvicp_correspond or mvicp_set_correspondences first"); return MVICP_ERR_STATE; }
@@ -291,14 +336,34 @@ int evaluate_blocks(mvicp_ctx* c, const double* poses, int plane, int robust, do
       return MVICP_OK;
     }
   }
-  MV_CHECK(upload_rel(c, poses));
   double* h = c->h_pin + c->pin_blocks_off;
   if (c->comm || c->ar_fn) {
+    // One collective per evaluation: [E x 91 blocks | poison slot].  The slot right behind the blocks (the buffer's tail region, rewritten
+    // by every search) is zeroed, or — if this rank's upload / launch failed — poisoned with a NaN, so that a local failure reaches every
+    // rank through the collective instead of leaving the peers blocked in it (see mvicp_correspond).
     c->lin_out = c->d_out;
-    MV_CHECK(launch_linearize(c, plane, robust));
-    { ProfScope pc(c, "comm", 8.0 * (double)n); MV_CHECK(comm_allreduce_sum(c, c->d_out, n)); }
-    MV_HIP(hipMemcpyAsync(h, c->d_out, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    int st_l = upload_rel(c, poses);
+    if (st_l == MVICP_OK && c->fault_inject_eval > 0 && --c->fault_inject_eval == 0) { set_error("injected launch failure (option fault_inject_eval)"); st_l = MVICP_ERR_HIP; }
+    if (st_l == MVICP_OK) st_l = launch_linearize(c, plane, robust);
+    char local_msg[sizeof(g_err)] = "";
+    if (st_l != MVICP_OK) std::memcpy(local_msg, g_err, sizeof(local_msg));
+    if (hipMemsetAsync(c->d_out + n, st_l == MVICP_OK ? 0 : 0xFF, sizeof(double), c->stream) != hipSuccess) {
+      if (st_l != MVICP_OK) return st_l;
+      set_error("hipMemsetAsync of the poison slot failed"); return MVICP_ERR_HIP;
+    }
+    { ProfScope pc(c, "comm", 8.0 * (double)(n + 1)); MV_CHECK(comm_allreduce_sum(c, c->d_out, n + 1)); }
+    double* hx = c->h_pin + c->pin_spec_off;   // (the spec region holds E x 94 + 2 doubles: room for the slot; the queued blocks in it were consumed or dropped above)
+    MV_HIP(hipMemcpyAsync(hx, c->d_out, sizeof(double) * (n + 1), hipMemcpyDeviceToHost, c->stream));
+    MV_CHECK(stream_wait(c));
+    if (std::isnan(hx[n])) {
+      if (st_l != MVICP_OK) { set_error("%s", local_msg); return st_l; }
+      set_error("a peer rank failed before the exchange of this evaluation (poisoned exchange buffer)");
+      return MVICP_ERR_COMM;
+    }
+    std::memcpy(out, hx, sizeof(double) * n);
+    return MVICP_OK;
   } else {
+    MV_CHECK(upload_rel(c, poses));
     c->lin_out = c->d_blocks_host;   // 8 * 91 * E bytes: the reduce kernel stores them straight into mapped host memory
     MV_CHECK(launch_linearize(c, plane, robust));
   }
@@ -337,6 +402,7 @@ int mvicp_create(int device, mvicp_ctx** out) try {
 int mvicp_destroy(mvicp_ctx* c) try {
   if (!c) return MVICP_OK;
   (void)hipSetDevice(c->device);
+  (void)finish_builds(c);
   (void)hipStreamSynchronize(c->stream);
   comm_destroy(c);
   free_graph(c);
@@ -363,6 +429,7 @@ int mvicp_destroy(mvicp_ctx* c) try {
 int mvicp_set_num_frames(mvicp_ctx* c, int n_frames) try {
   MV_CHECK(bind(c));
   if (n_frames < 0) { set_error("n_frames < 0"); return MVICP_ERR_ARG; }
+  (void)finish_builds(c);   // (builds of clouds that are dropped right here: their outcome no longer matters)
   if (c->E) free_graph(c);
   for (FrameDev& f : c->frames) { dev_free(f.pts); dev_free(f.nor); free_grid(f.grid); free_tie(f); }
   c->frames.assign(n_frames, FrameDev());
@@ -376,6 +443,7 @@ int mvicp_set_frame(mvicp_ctx* c, int frame, const double* xyz, const double* nr
   if (n < 0 || (n > 0 && !xyz)) { set_error("bad cloud (n=%d)", n); return MVICP_ERR_ARG; }
   if (c->E) { set_error("set frames before mvicp_set_graph"); return MVICP_ERR_STATE; }
   FrameDev& f = c->frames[frame];
+  if (f.job) { try { (void)f.job->fut.get(); } catch (...) {} f.job.reset(); }   // a build of the cloud this call replaces
   dev_free(f.pts); dev_free(f.nor); free_grid(f.grid); free_tie(f);
   f.has_grid = false;
   f.n = n;
@@ -388,21 +456,39 @@ int mvicp_set_frame(mvicp_ctx* c, int frame, const double* xyz, const double* nr
   f.max_norm = 0.0;
   for (int i = 0; i < n; ++i) {
     const double* p = xyz + 3 * (size_t)i;
+    if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) { set_error("non-finite coordinate in cloud"); return MVICP_ERR_ARG; }   // (reported by this call, not by a later one)
     f.max_norm = std::max(f.max_norm, std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]));
   }
-  if (n > 0) MV_CHECK(build_grid(c, f, xyz));
-  if (n > 0 && nrm) {
-    std::vector<double> sn(3 * (size_t)n);
-    for (int i = 0; i < n; ++i) std::memcpy(&sn[3 * (size_t)i], nrm + 3 * (size_t)f.grid.h_order[i], 24);
-    MV_CHECK(dev_alloc(&f.grid.snor, 3 * (size_t)n));
-    MV_HIP(hipMemcpy(f.grid.snor, sn.data(), sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice));
-  }
+  if (n == 0) return MVICP_OK;
+  if (!c->async_build) return build_frame_structures(c, f, xyz, nrm);
+  // The per-cloud structures (k-d order, box hierarchy, matrix-pipe operands, hash: ~0.1 s of host work per 200 k points) are built on a
+  // thread of their own from a private copy of the cloud, so that a driver's upload loop builds its clouds side by side (cfg4: 32 clouds,
+  // 2.9 s one after the other); whoever needs a structure first waits for the pending builds (finish_builds).
+  std::shared_ptr<BuildJob> job = std::make_shared<BuildJob>();
+  job->xyz.assign(xyz, xyz + 3 * (size_t)n);
+  if (nrm) job->nrm.assign(nrm, nrm + 3 * (size_t)n);
+  FrameDev* fp = &f;   // (stable: mvicp_set_num_frames, the only call that moves the frames, waits for the builds first)
+  BuildJob* jp = job.get();
+  job->fut = std::async(std::launch::async, [c, fp, jp]() -> int {
+    build_slots().acquire();
+    int st = MVICP_ERR_INTERNAL;
+    try {
+      st = hipSetDevice(c->device) == hipSuccess ? build_frame_structures(c, *fp, jp->xyz.data(), jp->nrm.empty() ? nullptr : jp->nrm.data()) : MVICP_ERR_HIP;
+      if (st != MVICP_OK) jp->err = g_err;   // (this worker's thread-local message)
+    } catch (const std::exception& e) { jp->err = std::string("structure build: ") + e.what(); }
+    catch (...) { jp->err = "structure build threw"; }
+    std::vector<double>().swap(jp->xyz); std::vector<double>().swap(jp->nrm);
+    build_slots().release();
+    return st;
+  });
+  f.job = job;
   return MVICP_OK;
 } MVICP_GUARD_ABI
 
 int mvicp_recompute_normals(mvicp_ctx* c, int frame, int k, double* nrm_out, int* knn_out) try {
   MV_CHECK(bind(c));
   if (frame < 0 || frame >= c->n_frames) { set_error("frame %d out of range", frame); return MVICP_ERR_ARG; }
+  MV_CHECK(finish_builds(c));
   FrameDev& f = c->frames[frame];
   if (f.n < k) { set_error("frame %d has %d points < k = %d (common.h:333 asserts >= 3)", frame, f.n, k); return MVICP_ERR_STATE; }
   if (!f.nor) MV_CHECK(dev_alloc(&f.nor, 3 * (size_t)f.n));
@@ -465,6 +551,7 @@ int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) t
       set_error("edge %d (%d->%d) invalid", e, src[e], dst[e]);
       return MVICP_ERR_ARG;
     }
+  MV_CHECK(finish_builds(c));   // every cloud's structures are needed from here on
   free_graph(c);
   const int E = n_edges;
   c->E = E;
@@ -594,10 +681,9 @@ int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) t
   return MVICP_OK;
 } MVICP_GUARD_ABI
 
-int mvicp_reset_history(mvicp_ctx* c) try {
-  MV_CHECK(bind(c));
+// everything earlier searches left behind (host-side bookkeeping only)
+static void forget_history(mvicp_ctx* c) {
   const int E = c->E;
-  MV_HIP(hipStreamSynchronize(c->stream));
   c->nn_cache_valid = false; c->nn_cache_thresh = -1.f;
   c->prev_q.assign((size_t)E * 12, 0.0); c->prev_xf.assign((size_t)E * 24, 0.0);
   c->nn_cache_edge.assign(E, 0);                      // no seeds, no temporal cache: d_nn_idx / d_nn_lb are dead until the next search rewrites them
@@ -609,6 +695,12 @@ int mvicp_reset_history(mvicp_ctx* c) try {
   c->spec_ready = false; c->spec_arm = false; c->spec_flags_valid = false;
   c->have_corr = false;
   std::fill(c->h_count.begin(), c->h_count.end(), 0); std::fill(c->h_weight.begin(), c->h_weight.end(), 0.f);
+}
+
+int mvicp_reset_history(mvicp_ctx* c) try {
+  MV_CHECK(bind(c));
+  MV_HIP(hipStreamSynchronize(c->stream));
+  forget_history(c);
   return MVICP_OK;
 } MVICP_GUARD_ABI
 
@@ -664,10 +756,17 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   int* hd = hn + E;
   std::memcpy(hn, nsrc.data(), sizeof(int) * E);
 
+  // Failure semantics with N > 1 ranks.  A search has ONE collective; a rank that failed locally before it (an allocation,
+  // an upload, a launch) used to return at once — and its peers blocked in the collective forever.  Now every local step up to the exchange
+  // only records its status (st_local); a rank whose share cannot be delivered still ENTERS the collective, with the "armed" slot of the
+  // exchanged buffer poisoned (NaN): the sum is NaN on every rank, every rank sees it after its own wait, drops its cross-round state and
+  // returns an error from this same call — the failing rank its own status, the others MVICP_ERR_COMM.  (A device that no longer executes
+  // anything cannot poison or exchange: that stays fatal for the job, as any collective library has it.)
+  int st_local = MVICP_OK;
   if (c->tie_rule) {   // a cloud uploaded after mvicp_set_graph has no tree yet (the reference builds its index lazily as well, frame.cpp:188-193)
     std::vector<int> need;
     for (int e = 0; e < E; ++e) if (c->active[e] && !c->frames[c->edst[e]].has_tie) need.push_back(c->edst[e]);
-    if (!need.empty()) MV_CHECK(ensure_tie_trees(c, need));
+    if (!need.empty()) st_local = ensure_tie_trees(c, need);
   }
   const double bound = sqrt_bound((double)thresh);
   double t_mark = now_ms();
@@ -784,12 +883,14 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
     c->spec_q_plane = c->spec_plane; c->spec_q_robust = c->spec_robust;
     upload_doubles = c->ctl_r2_off + (size_t)E * kEdgeRel;
   }
+  if (method != MVICP_NN_BRUTE && method != MVICP_NN_GRID && method != MVICP_NN_TILE) { set_error("unknown nn_method %d", nn_method); return MVICP_ERR_ARG; }   // (an argument error: the same on every rank)
+  auto local_search = [&]() -> int {
   MV_HIP(hipMemcpyAsync(c->d_ctl, hx, sizeof(double) * upload_doubles, hipMemcpyHostToDevice, c->stream));
   c->far_narrow = nn_method == MVICP_NN_AUTO && method == MVICP_NN_GRID && c->nn_cache_valid && c->nn_cache_enable && all_same;   // the fixed point: (almost) every query is a cache hit
+  if (c->fault_inject > 0 && --c->fault_inject == 0) { set_error("injected launch failure (option fault_inject)"); return MVICP_ERR_HIP; }   // tests: a local failure before the exchange
   if (method == MVICP_NN_BRUTE) MV_CHECK(launch_nn_brute_edges(c));
   else if (method == MVICP_NN_GRID) MV_CHECK(launch_nn_grid_edges(c, bound));
-  else if (method == MVICP_NN_TILE) MV_CHECK(launch_nn_tile_edges(c, bound, tile_lb, tile_cached, c->list_reuse));
-  else { set_error("unknown nn_method %d", nn_method); return MVICP_ERR_ARG; }
+  else MV_CHECK(launch_nn_tile_edges(c, bound, tile_lb, tile_cached, c->list_reuse));
   c->tie_skip = false; c->far_skip = false;
   c->prev_grid_kernel = method == MVICP_NN_GRID;
   // only the grid kernel and the tile kernel's BND build leave the per-query lower bounds the temporal cache needs; the cutoff must
@@ -807,21 +908,35 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
     MV_CHECK(launch_compact(c, bound));
     MV_CHECK(launch_gather_stream(c));
   }
-  int st_sel = use_bracket ? launch_select_bracket(c) : launch_select_median(c);
-  if (st_sel != MVICP_OK) { c->spec_flags_valid = false; return st_sel; }
+  return use_bracket ? launch_select_bracket(c) : launch_select_median(c);
+  };   // local_search
+  if (st_local == MVICP_OK) st_local = local_search();
+  if (st_local != MVICP_OK && !exchange) { c->spec_flags_valid = false; return st_local; }
   // the queued first evaluation (its relative transforms went up with the control block).  With N > 1 ranks: ONE collective per
   // search — [E x 91 blocks | (count, median d2) x E | armed | a x E], always the full buffer — and ONE wait.
   int st_q = MVICP_OK;
+  char local_msg[sizeof(g_err)] = "";
   if (exchange) {
     c->lin_out = c->d_out;
-    if (c->spec_arm) st_q = launch_linearize(c, c->spec_q_plane, c->spec_q_robust);
-    else {
-      // this rank queued no evaluation: its share of the block region and of the scale slots is ZERO, not whatever the last exchange left
-      // there (already-summed values would be summed again round after round).  Every rank sends the same buffer size whatever it decided.
-      if (hipMemsetAsync(c->d_out, 0, sizeof(double) * nb, c->stream) != hipSuccess ||
-          hipMemsetAsync(c->d_out + nb + 2 * (size_t)E + 1, 0, sizeof(double) * (size_t)E, c->stream) != hipSuccess) { set_error("hipMemsetAsync of the exchange buffer failed"); st_q = MVICP_ERR_HIP; }
+    if (st_local == MVICP_OK) {
+      if (c->spec_arm) st_local = launch_linearize(c, c->spec_q_plane, c->spec_q_robust);
+      else {
+        // this rank queued no evaluation: its share of the block region and of the scale slots is ZERO, not whatever the last exchange left
+        // there (already-summed values would be summed again round after round).  Every rank sends the same buffer size whatever it decided.
+        if (hipMemsetAsync(c->d_out, 0, sizeof(double) * nb, c->stream) != hipSuccess ||
+            hipMemsetAsync(c->d_out + nb + 2 * (size_t)E + 1, 0, sizeof(double) * (size_t)E, c->stream) != hipSuccess) { set_error("hipMemsetAsync of the exchange buffer failed"); st_local = MVICP_ERR_HIP; }
+      }
     }
-    if (st_q == MVICP_OK) { ProfScope pc(c, "comm", 8.0 * (double)(nb + ntail)); st_q = comm_allreduce_sum(c, c->d_out, nb + ntail); }
+    if (st_local != MVICP_OK) {
+      // this rank's share cannot be delivered: enter the collective all the same, with the armed slot poisoned (eight 0xFF bytes = a NaN)
+      std::memcpy(local_msg, g_err, sizeof(local_msg));
+      if (hipMemsetAsync(c->d_out + nb + 2 * (size_t)E, 0xFF, sizeof(double), c->stream) != hipSuccess) {
+        set_error("%s — and the exchange buffer could not be poisoned: the peers of this rank will block in the collective", local_msg);
+        c->spec_flags_valid = false; c->spec_arm = false;
+        return st_local;
+      }
+    }
+    { ProfScope pc(c, "comm", 8.0 * (double)(nb + ntail)); st_q = comm_allreduce_sum(c, c->d_out, nb + ntail); }
     if (st_q == MVICP_OK && hipMemcpyAsync(c->h_pin + c->pin_spec_off, c->d_out, sizeof(double) * (nb + ntail), hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
       set_error("hipMemcpyAsync of the exchanged buffer failed"); st_q = MVICP_ERR_HIP;
     }
@@ -834,6 +949,15 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   // behind the blocks; weight = (float)(1.5 * sqrt(median d2))  (frame.cpp:168-176)
   if (st_q == MVICP_OK) st_q = stream_wait(c);
   if (st_q != MVICP_OK) { c->spec_flags_valid = false; c->spec_arm = false; return st_q; }
+  if (exchange && std::isnan(c->h_pin[c->pin_spec_off + nb + 2 * (size_t)E])) {
+    // some rank (this one if st_local says so) entered the collective without its share: nothing of this search is usable anywhere.  Every
+    // rank forgets what earlier searches left behind — the next search is a first search on all of them, so their states agree again.
+    forget_history(c);
+    c->census_pending = false;
+    if (st_local != MVICP_OK) { set_error("%s", local_msg); return st_local; }
+    set_error("a peer rank failed before the exchange of this search (poisoned exchange buffer); nothing was updated, cross-round state dropped on every rank");
+    return MVICP_ERR_COMM;
+  }
   census_resolve(c);
   // what THIS search's tie fix-up / far launch reported (a skipped launch keeps last search's zero): the next search's skip decisions
   if (tie_launched) c->corr_tie_seen = c->h_tie_seen ? *c->h_tie_seen : 1u;
@@ -850,15 +974,28 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
     if (redo) {
       spec_bad = true;   // the queued evaluation used the scales of the failed select
       int st_r = launch_select_median(c);
-      if (st_r == MVICP_OK && exchange) {
-        ProfScope pc(c, "comm", 8.0 * (double)ntail);
-        st_r = comm_allreduce_sum(c, c->d_out + nb, ntail);
-        if (st_r == MVICP_OK && hipMemcpyAsync(c->h_pin + c->pin_spec_off + nb, c->d_out + nb, sizeof(double) * ntail, hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
-          set_error("hipMemcpyAsync of the exchanged tail failed"); st_r = MVICP_ERR_HIP;
+      if (exchange) {
+        int st_x = MVICP_OK;
+        if (st_r != MVICP_OK) {   // same protocol as above: the second (tail-only) collective is entered with a poisoned armed slot
+          std::memcpy(local_msg, g_err, sizeof(local_msg));
+          if (hipMemsetAsync(c->d_out + nb + 2 * (size_t)E, 0xFF, sizeof(double), c->stream) != hipSuccess) { c->spec_flags_valid = false; c->spec_arm = false; return st_r; }
         }
+        { ProfScope pc(c, "comm", 8.0 * (double)ntail); st_x = comm_allreduce_sum(c, c->d_out + nb, ntail); }
+        if (st_x == MVICP_OK && hipMemcpyAsync(c->h_pin + c->pin_spec_off + nb, c->d_out + nb, sizeof(double) * ntail, hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
+          set_error("hipMemcpyAsync of the exchanged tail failed"); st_x = MVICP_ERR_HIP;
+        }
+        if (st_x == MVICP_OK) st_x = stream_wait(c);
+        if (st_x != MVICP_OK) { c->spec_flags_valid = false; c->spec_arm = false; return st_x; }
+        if (std::isnan(hr[2 * (size_t)E])) {
+          forget_history(c);
+          if (st_r != MVICP_OK) { set_error("%s", local_msg); return st_r; }
+          set_error("a peer rank failed before the second exchange of this search (poisoned exchange buffer); cross-round state dropped on every rank");
+          return MVICP_ERR_COMM;
+        }
+      } else {
+        if (st_r == MVICP_OK) st_r = stream_wait(c);
+        if (st_r != MVICP_OK) { c->spec_flags_valid = false; c->spec_arm = false; return st_r; }
       }
-      if (st_r == MVICP_OK) st_r = stream_wait(c);
-      if (st_r != MVICP_OK) { c->spec_flags_valid = false; c->spec_arm = false; return st_r; }
     }
   }
   for (int e = 0; e < E; ++e) {
@@ -1008,6 +1145,7 @@ int mvicp_nn_query(mvicp_ctx* c, int frame, const double* queries, int n, int nn
   MV_CHECK(bind(c));
   if (frame < 0 || frame >= c->n_frames) { set_error("frame %d out of range", frame); return MVICP_ERR_ARG; }
   if (n < 0 || (n && (!queries || !idx || !d2))) { set_error("bad query buffers"); return MVICP_ERR_ARG; }
+  MV_CHECK(finish_builds(c));
   const FrameDev& f = c->frames[frame];
   if (f.n == 0) { set_error("frame %d is empty (nanoflann throws here: nanoflann.hpp:904)", frame); return MVICP_ERR_STATE; }
   if (n == 0) return MVICP_OK;
@@ -1046,6 +1184,8 @@ int mvicp_linearize(mvicp_ctx* c, const double* poses, int point_to_plane, int r
 int mvicp_set_option(mvicp_ctx* c, const char* name, double value) try {
   MV_CHECK(bind(c));
   if (!name) { set_error("null option name"); return MVICP_ERR_ARG; }
+  if (std::strcmp(name, "async_build") == 0) { c->async_build = value != 0.0; return MVICP_OK; }
+  if (std::strcmp(name, "grid_target") == 0 || std::strcmp(name, "grid_curve") == 0) MV_CHECK(finish_builds(c));   // (pending builds read them)
   if (std::strcmp(name, "nn_tree_only") == 0) { c->nn_tree_only = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "nn_cache") == 0) { c->nn_cache_enable = value != 0.0; c->nn_cache_valid = false; return MVICP_OK; }
   if (std::strcmp(name, "lin_chunk") == 0) { c->lin_chunk_override = (int)value; return MVICP_OK; }  // takes effect at the next mvicp_set_graph
@@ -1071,6 +1211,8 @@ int mvicp_set_option(mvicp_ctx* c, const char* name, double value) try {
   if (std::strcmp(name, "tile_waves") == 0) { c->tile_waves = (int)value; return MVICP_OK; }
   if (std::strcmp(name, "tile_cache") == 0) { c->tile_cache = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "spin_wait") == 0) { c->spin_wait = value != 0.0; return MVICP_OK; }
+  if (std::strcmp(name, "fault_inject") == 0) { c->fault_inject = (int)value; return MVICP_OK; }            // tests: the value-th mvicp_correspond from now fails locally before its exchange
+  if (std::strcmp(name, "fault_inject_eval") == 0) { c->fault_inject_eval = (int)value; return MVICP_OK; }  // tests: the value-th exchanged LM evaluation from now fails locally
   if (std::strcmp(name, "spec_eval") == 0) { c->spec_enable = value != 0.0; c->spec_ready = false; return MVICP_OK; }
   if (std::strcmp(name, "grid_target") == 0) {
     if (!(value >= 0.5 && value <= 64.0)) { set_error("grid_target out of range"); return MVICP_ERR_ARG; }

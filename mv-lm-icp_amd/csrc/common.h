@@ -4,7 +4,9 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <future>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -74,7 +76,13 @@ struct GridDev {
 
 struct PointRec { double x, y, z; long long idx; };  // 32-B aligned sorted point + original index
 
+// The per-cloud structure build of one mvicp_set_frame, running on a host thread of its own (api.cpp): the call returns once the cloud is
+// on the device, the k-d order / box hierarchy / matrix-pipe operands / hash are built behind it, one cloud beside the other, and every
+// entry point that needs a structure waits for the pending builds first (finish_builds).
+struct BuildJob { std::future<int> fut; std::string err; std::vector<double> xyz, nrm; };
+
 struct FrameDev {
+  std::shared_ptr<BuildJob> job;   // pending structure build (null: none)
   int n = 0;
   double* pts = nullptr;  // n x 3 AoS, original order
   double* nor = nullptr;  // n x 3 or null
@@ -206,6 +214,8 @@ struct mvicp_ctx {
   mvicp_allreduce_fn ar_fn = nullptr; void* ar_user = nullptr;   // host-staged all-reduce supplied by the launcher (no RCCL)
   std::vector<double> ar_host;
 
+  bool async_build = true;          // option "async_build": mvicp_set_frame builds the per-cloud structures on a background host thread
+  int fault_inject = 0, fault_inject_eval = 0;   // tests only: make the n-th search / exchanged evaluation from now fail locally before its collective
   // options / NN census (profiling only)
   bool list_reuse = true;          // skip compaction + gather for edges whose list did not change
   bool nn_tree_only = false;
@@ -274,6 +284,7 @@ int warm_nn_tile(mvicp_ctx* c); int warm_nn_grid(mvicp_ctx* c);                 
 int build_wide(FrameDev& f, const double* sorted_pts);                                 // nn_tile.hip (host, called by build_grid)
 int launch_nn_grid_queries(mvicp_ctx* c, const FrameDev& f, const double* d_q, int n, int* d_idx, double* d_d2);
 int build_grid(mvicp_ctx* c, FrameDev& f, const double* h_xyz);
+int finish_builds(mvicp_ctx* c);   // api.cpp: wait for every pending structure build of this context; first failure wins
 void free_grid(GridDev& g);
 void free_tie(FrameDev& f);                                                            // nn_tie.hip
 int launch_compact(mvicp_ctx* c, double d2_bound);                                    // corr.hip

@@ -27,6 +27,7 @@
 // the point distance, and every rounding is monotone, so lb <= d2 for every point in the box; nodes are
 // skipped only when lb > best (ties are still visited for the index rule).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -914,10 +915,12 @@ void kd_split(KdItem* a, long long lo, long long hi, int par) noexcept {   // pa
     else { kd_split(a, mid, hi, 0); hi = mid; }
   }
 }
+std::atomic<int> g_builds_running{0};   // builds of several clouds run side by side (api.cpp, mvicp_set_frame): the fewer threads each forks
 void kd_order(const double* xyz, int n, std::vector<int>& order) {
   std::vector<KdItem> a((size_t)n);
   for (int i = 0; i < n; ++i) a[i] = KdItem{xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], i, 0};
-  kd_split(a.data(), 0, n, 3);
+  const int busy = g_builds_running.load();
+  kd_split(a.data(), 0, n, busy > 4 ? 0 : busy > 1 ? 1 : 3);   // (the order does not depend on how the work was split)
   order.resize(n);
   for (int i = 0; i < n; ++i) order[i] = a[i].idx;
 }
@@ -925,6 +928,7 @@ void kd_order(const double* xyz, int n, std::vector<int>& order) {
 }  // namespace
 
 int build_grid(mvicp_ctx* c, FrameDev& f, const double* xyz) {
+  struct Running { Running() { ++g_builds_running; } ~Running() { --g_builds_running; } } running;
   const int n = f.n;
   GridDev& G = f.grid;
   double lo[3] = {xyz[0], xyz[1], xyz[2]}, hi[3] = {xyz[0], xyz[1], xyz[2]};

@@ -5,6 +5,9 @@
 #include <cmath>
 #include <cstring>
 #include <numeric>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <stdexcept>
 #include <thread>
 
@@ -111,22 +114,70 @@ void Frame::computePoseNeighboursKnn(std::vector<std::shared_ptr<Frame>>* frames
   }
 }
 
-// dst[i] <- src[i] for a few (destination, source, bytes) pieces on up to `threads` host threads (a frame's lists are a few megabytes
-// each: one thread copies at ~5 GB/s, the memory system takes eight such streams)
+// dst[i] <- src[i] for a few (destination, source, bytes) pieces on up to `threads` host threads: a frame's lists are a few megabytes
+// each; one thread copies at ~5 GB/s, the memory system takes eight such streams.  The workers are PERSISTENT (created on first use, parked
+// on a condition variable): a driver calls this once per frame per round, and creating eight threads per call cost more than the copy.
+namespace {
+struct CopyJob { char* d; const char* s; size_t n; };
+class CopyPool {
+ public:
+  static CopyPool& get() { static CopyPool p; return p; }
+  void run(const std::vector<CopyJob>& jobs, int threads) {
+    const int nt = (int)std::min<size_t>((size_t)std::max(1, threads), jobs.size());
+    if (nt <= 1) { for (const CopyJob& j : jobs) std::memcpy(j.d, j.s, j.n); return; }
+    std::unique_lock<std::mutex> lk(m_);
+    while ((int)workers_.size() < nt - 1) workers_.emplace_back([this]() { loop(); });
+    jobs_ = &jobs; next_.store(0); pending_ = (int)workers_.size(); ++epoch_;
+    cv_.notify_all();
+    lk.unlock();
+    drain();                                   // the caller is a worker too
+    lk.lock();
+    done_.wait(lk, [this]() { return pending_ == 0; });
+    jobs_ = nullptr;
+  }
+  ~CopyPool() {
+    { std::lock_guard<std::mutex> lk(m_); stop_ = true; ++epoch_; }
+    cv_.notify_all();
+    for (std::thread& t : workers_) t.join();
+  }
+ private:
+  void drain() {
+    for (;;) {
+      const size_t k = next_.fetch_add(1);
+      if (k >= jobs_->size()) return;
+      const CopyJob& j = (*jobs_)[k];
+      std::memcpy(j.d, j.s, j.n);
+    }
+  }
+  void loop() {
+    unsigned long long seen = 0;
+    for (;;) {
+      std::unique_lock<std::mutex> lk(m_);
+      cv_.wait(lk, [&]() { return epoch_ != seen; });
+      seen = epoch_;
+      if (stop_) return;
+      lk.unlock();
+      drain();
+      lk.lock();
+      if (--pending_ == 0) done_.notify_one();
+    }
+  }
+  std::mutex m_; std::condition_variable cv_, done_;
+  std::vector<std::thread> workers_;
+  const std::vector<CopyJob>* jobs_ = nullptr;
+  std::atomic<size_t> next_{0};
+  int pending_ = 0; unsigned long long epoch_ = 0; bool stop_ = false;
+};
+}  // namespace
+
 static void parallel_copy(const std::vector<std::pair<std::pair<char*, const char*>, size_t>>& pieces, int threads) {
   size_t total = 0;
   for (const auto& p : pieces) total += p.second;
-  const size_t chunk = 512 << 10;
-  struct Job { char* d; const char* s; size_t n; };
-  std::vector<Job> jobs;
+  const size_t chunk = 256 << 10;
+  std::vector<CopyJob> jobs;
   for (const auto& p : pieces)
-    for (size_t o = 0; o < p.second; o += chunk) jobs.push_back(Job{p.first.first + o, p.first.second + o, std::min(chunk, p.second - o)});
-  const int nt = (int)std::min<size_t>((size_t)std::max(1, threads), jobs.size());
-  if (nt <= 1 || total < (2u << 20)) { for (const Job& j : jobs) std::memcpy(j.d, j.s, j.n); return; }
-  std::vector<std::thread> pool;
-  for (int t = 1; t < nt; ++t) pool.emplace_back([&, t]() { for (size_t k = t; k < jobs.size(); k += nt) std::memcpy(jobs[k].d, jobs[k].s, jobs[k].n); });
-  for (size_t k = 0; k < jobs.size(); k += nt) std::memcpy(jobs[k].d, jobs[k].s, jobs[k].n);
-  for (auto& th : pool) th.join();
+    for (size_t o = 0; o < p.second; o += chunk) jobs.push_back(CopyJob{p.first.first + o, p.first.second + o, std::min(chunk, p.second - o)});
+  CopyPool::get().run(jobs, total < (1u << 20) ? 1 : threads);
 }
 
 void Frame::computeClosestPointsToNeighbours(std::vector<std::shared_ptr<Frame>>* frames, float thresh) {

@@ -1182,3 +1182,62 @@ def test_device_sqrt_is_the_ieee_sqrt(eng):
     assert counts[0] > 0.99 * n and np.array_equal(idx, trip["second"])
     assert np.sqrt(d2).tobytes() == trip["dist"].tobytes()
     assert trip["dist"].min() < 1e-11 and trip["dist"].max() > 1e-4
+
+
+# ---------------------------------------------------------------- regime transitions of mvicp_correspond
+@pytest.mark.parametrize("seed", range(8))
+def test_correspond_regime_transitions_match_a_fresh_context(orc, seed):
+    """mvicp_correspond carries a dozen cross-round flags (temporal cache, seeds, reusable lists, settled medians, bracket select, AUTO state,
+    tie / far skips, the queued evaluation).  Whatever happened before, a search is a pure function of (clouds, graph, poses, fixed mask,
+    cutoff): after EVERY round of a randomly perturbed registration — cutoff changes, fixed-mask changes, mvicp_reset_history, forced kernel
+    methods, option flips, rounds without a solve (bit-identical poses), an explicit list installed on an edge — the persistent context's
+    counts, float weights and reference-order triples must equal those of a FRESH context asked once at the same poses (and the oracle's
+    on a sampled edge)."""
+    rng = np.random.default_rng(9000 + seed)
+    K = int(rng.integers(3, 6))
+    pb = synth.make_problem(K, int(rng.integers(2500, 5000)), cone_deg=float(rng.choice([100.0, 45.0])), pose_seed=int(700 + seed))
+    src, dst = pb["src"], pb["dst"]
+    A = mvicp.Engine(0)
+    A.set_frames(pb["pts"], pb["nor"]); A.set_graph(src, dst)
+    poses = pb["init"].copy()
+    fixed = pb["fixed"].copy()
+    cutoff = 0.05
+    method = L.NN_AUTO
+    events = []
+    for rnd in range(14):
+        ev = rng.choice(["none", "none", "cutoff", "fixed", "reset", "method", "option", "hold", "explicit"]) if rnd > 0 else "none"
+        events.append(ev)
+        if ev == "cutoff":
+            cutoff = float(rng.choice([0.05, 0.02, 0.008, 0.004]))
+        elif ev == "fixed":
+            k = int(rng.integers(1, K)); fixed[k] = 1 - fixed[k]
+        elif ev == "reset":
+            A.reset_history()
+        elif ev == "method":
+            method = int(rng.choice([L.NN_AUTO, L.NN_AUTO, L.NN_BRUTE, L.NN_GRID, L.NN_TILE]))
+        elif ev == "option":
+            name = str(rng.choice(["list_reuse", "nn_cache", "sel_bracket", "spec_eval", "tile_cache", "tile_seed"]))
+            A.set_option(name, float(rng.integers(0, 2)))
+            if rng.random() < 0.5:
+                A.set_option("tile_mfma", float(rng.integers(0, 3)))
+        elif ev == "explicit":
+            e = int(rng.integers(0, len(src)))
+            n = int(rng.integers(1, 200))
+            A.set_correspondences(e, rng.integers(0, len(pb["pts"][src[e]]), n).astype(np.int32), rng.integers(0, len(pb["pts"][dst[e]]), n).astype(np.int32), 0.01)
+        counts, weights = A.correspond(poses, fixed, cutoff, method)
+        trip, off = A.map_correspondences()
+        B = mvicp.Engine(0)
+        B.set_frames(pb["pts"], pb["nor"]); B.set_graph(src, dst)
+        cb, wb = B.correspond(poses, fixed, cutoff, L.NN_BRUTE if rnd % 3 == 0 else L.NN_AUTO)
+        tb, ob = B.map_correspondences()
+        B.close()
+        assert np.array_equal(counts, cb) and weights.tobytes() == wb.tobytes(), (seed, rnd, events)
+        assert np.array_equal(off, ob) and np.array_equal(trip, tb), (seed, rnd, events)
+        e = int(rng.integers(0, len(src)))
+        if not fixed[src[e]]:
+            f, sec, dist, w, _, _ = orc.correspond_edge(pb["pts"][src[e]], poses[src[e]], pb["pts"][dst[e]], poses[dst[e]], cutoff)
+            t = trip[off[e]:off[e + 1]]
+            assert np.array_equal(t["first"], f) and np.array_equal(t["second"], sec) and t["dist"].tobytes() == dist.tobytes() and weights[e] == w, (seed, rnd, e, events)
+        if ev != "hold" and counts.sum() > 0:
+            poses, sm = A.optimize(poses, fixed, int(rng.integers(0, 3)), int(rng.integers(0, 2)), bool(rng.integers(0, 2)), 50)
+    A.close()

@@ -55,13 +55,18 @@ def run(pb, param, plane, cutoff, rounds=20, tmp_root=None, timeout=600):
             m = re.search(r"loop: rounds (\d+) copyback (\d) closest_pts_ms ([0-9.e+-]+) global_ms ([0-9.e+-]+) it_per_s ([0-9.e+-]+)", txt)
             per = [(float(a), float(b)) for a, b in re.findall(r"round: \d+\s+closest pts ([0-9.e+-]+) ms\s+global ([0-9.e+-]+) ms", txt)]
             n = int(m.group(1))
+            rms = [a + b for a, b in per]
             out[mode] = {"it_per_s": float(m.group(5)), "closest_pts_ms_per_round": float(m.group(3)) / n, "global_ms_per_round": float(m.group(4)) / n,
-                         "process_wall_s": wall, "setup_s": wall - (float(m.group(3)) + float(m.group(4))) * 1e-3,
-                         "round_ms": [round(a + b, 3) for a, b in per]}
+                         "first_round_ms": rms[0] if rms else None,
+                         "it_per_s_after_first_round": (1e3 * (len(rms) - 1) / sum(rms[1:])) if len(rms) > 1 else None,
+                         "closest_pts_ms_after_first_round": [round(a, 3) for a, _ in per[1:]],
+                         "process_wall_s": wall, "load_and_exit_s": wall - (float(m.group(3)) + float(m.group(4))) * 1e-3,
+                         "round_ms": [round(x, 3) for x in rms]}
         nt = sum(len(p) for p in pb["pts"][1:]) * 2
         out["copyback"]["triples_per_round_upper_bound"] = nt
         out["note"] = ("whole-loop wall clock of the driver (its own steady_clock around the 20 rounds: Frame::computeClosestPointsToNeighbours for every frame + "
-                       "ICP_Ceres::ceresOptimizer_*), first round included (it allocates the vectors and the pinned buffer); copyback = the reference's contract "
+                       "ICP_Ceres::ceresOptimizer_*).  it_per_s = all rounds, first round included — the first computeClosestPointsToNeighbours uploads the clouds and builds their "
+                       "structures (the reference builds its KD-trees there too, frame.cpp:188-193); it_per_s_after_first_round = rounds 2..N; copyback = the reference's contract "
                        "(Frame::neighbours[j].correspondances filled every round: one device un-sort + one pinned copy + host slicing), device_only = lists stay on the GPU")
         return out
     finally:
