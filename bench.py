@@ -452,7 +452,12 @@ def main():
 
     sha = source_sha16()
 
-    def pmc_traffic(name):
+    # FETCH_SIZE correction per scope (profiles/r05_pmc_calibration.txt: counter / known bytes in this library's own access patterns, tools/pmc_calib.hip):
+    # coalesced streams of 8 and 16 B per lane read 1/2 (linearize's SoA stream, the fixed-point verify pass); the NN traversal kernels mix 16-B
+    # fragment streams (1/2) with 32-B record gathers and 4-B box loads — their factor is the measured mix, see DESIGN.md
+    FETCH_FACTOR = {"linearize": 2.0}
+
+    def pmc_traffic(name, what="traffic"):
         """HBM bytes per launch of THIS command from a committed rocprofv3 PMC summary (tools/profile.sh -> profiles/), used only if
         that summary was taken with the same workload / warm-up / steps / NN method AND the same device sources (hash) — otherwise null.
         FETCH_SIZE is doubled for the 16-B/lane coalesced linearize stream as MI355X_MICROARCH.md §HBM prescribes for gfx950; the NN
@@ -462,10 +467,12 @@ def main():
             return None
         try:
             j = json.load(open(path))
-            if j.get("source_sha16") != sha or j.get("warmup_skipped") != args.warmup or j.get("timed_rounds") != args.steps or j.get("windows", 1) != R:
+            if j.get("source_sha16") != sha or j.get("warmup_skipped") != args.warmup or j.get("timed_rounds") != args.steps:   # (per-launch averages: the number of windows does not matter)
                 return None
             sc = j["scopes"][name]
-            return (sc["FETCH_SIZE_KiB"] * (2.0 if name == "linearize" else 1.0) + sc["WRITE_SIZE_KiB"]) * 1024.0
+            if what == "valu_busy":
+                return sc.get("valu_busy")
+            return (sc["FETCH_SIZE_KiB"] * FETCH_FACTOR.get(name, 1.0) + sc["WRITE_SIZE_KiB"]) * 1024.0
         except Exception:
             return None
 
@@ -480,7 +487,7 @@ def main():
             return None
         ach = (b / n) / (ms / n * 1e-3) / 1e9
         r = {"kernel": name, "device_function": KERNEL_OF.get(name), "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-             "traffic": pmc_traffic(name), "launches": n, "avg_us": ms / n * 1e3, "total_ms": ms, "alg_bytes_per_launch": b / n}
+             "traffic": pmc_traffic(name), "valu_busy": pmc_traffic(name, "valu_busy"), "launches": n, "avg_us": ms / n * 1e3, "total_ms": ms, "alg_bytes_per_launch": b / n}
         if name.startswith("nn"):
             r["compulsory_bytes_per_launch"] = comp / n
             r["compulsory_frac"] = comp / n / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS

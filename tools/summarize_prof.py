@@ -101,9 +101,25 @@ if tr:
     for k, v in sorted(scopes.items()):
         if v:
             lines.append(f"{k:12s} calls {v['calls']:5d}  avg_us {v['avg_us']:10.2f}" + (f"  total_us {v['total_us']:12.1f}" if "total_us" in v else ""))
-for sub, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+for sub, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"), ("pmc_sq", "SQ_ACTIVE_INST_VALU"), ("pmc_sq", "SQ_INSTS_VALU"), ("pmc_sq", "SQ_WAVE_CYCLES")):
     cc = find(sub, "*counter_collection.csv")
     if not cc:
+        continue
+    if sub == "pmc_sq":
+        # instruction-issue counters (own pass): per scope, and VALU busy = SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / 1024 SIMDs / (avg_us x 2400 cycles per us)
+        rows = sorted((r for r in csv.DictReader(open(cc)) if r.get("Counter_Name") == ctr), key=lambda r: int(r["Dispatch_Id"]))
+        nn_calls, lin, by_scope = scope_calls(rows, lambda r: float(r["Counter_Value"]))
+        if lin:
+            scopes["linearize"][ctr] = sum(lin) / len(lin)
+        for k, t in by_scope.items():
+            scopes[k][ctr] = sum(t) / len(t)
+        if ctr == "SQ_ACTIVE_INST_VALU":
+            lines.append("")
+            lines.append("# rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES (own pass): per timed launch; valu_busy = ACTIVE_INST_VALU x 4 / 1024 SIMDs / (avg_us x 2400)")
+            for k, v in sorted(scopes.items()):
+                if ctr in v and v.get("avg_us"):
+                    v["valu_busy"] = v[ctr] * 4.0 / 1024.0 / (v["avg_us"] * 2400.0)
+                    lines.append(f"{k:12s} SQ_ACTIVE_INST_VALU {v[ctr]:.4g}  avg_us {v['avg_us']:.1f}  valu_busy {v['valu_busy']:.3f}")
         continue
     rows = sorted((r for r in csv.DictReader(open(cc)) if r.get("Counter_Name") == ctr), key=lambda r: int(r["Dispatch_Id"]))
     agg = defaultdict(lambda: [0, 0.0])
