@@ -452,16 +452,17 @@ def main():
 
     sha = source_sha16()
 
-    # FETCH_SIZE correction per scope (profiles/r05_pmc_calibration.txt: counter / known bytes in this library's own access patterns, tools/pmc_calib.hip):
-    # coalesced streams of 8 and 16 B per lane read 1/2 (linearize's SoA stream, the fixed-point verify pass); the NN traversal kernels mix 16-B
-    # fragment streams (1/2) with 32-B record gathers and 4-B box loads — their factor is the measured mix, see DESIGN.md
-    FETCH_FACTOR = {"linearize": 2.0}
+    # FETCH_SIZE correction (profiles/r05_pmc_calibration.txt: tools/pmc_calib.hip under rocprofv3 --pmc, 1-GiB known-byte kernels in this library's own
+    # access patterns): every coalesced read stream — 4, 8, 16 B per lane, 1-KiB tile fragments in random order — reads 0.500 of its bytes, and random 32-B
+    # record gathers read 2.03x their USEFUL bytes = 0.5 of the 128-B lines they pull: the counter tallies each 128-B fabric request as 64 B in every
+    # pattern, so HBM-side read traffic = 2 x FETCH_SIZE for every kernel; WRITE_SIZE reads 1.000 of 4 / 8 / 16-B coalesced stores
+    FETCH_FACTOR_ALL = 2.0
 
     def pmc_traffic(name, what="traffic"):
         """HBM bytes per launch of THIS command from a committed rocprofv3 PMC summary (tools/profile.sh -> profiles/), used only if
         that summary was taken with the same workload / warm-up / steps / NN method AND the same device sources (hash) — otherwise null.
-        FETCH_SIZE is doubled for the 16-B/lane coalesced linearize stream as MI355X_MICROARCH.md §HBM prescribes for gfx950; the NN
-        kernels mix access widths (uncalibrated there), so their raw counters are used as they are."""
+        FETCH_SIZE is doubled for every kernel: MI355X_MICROARCH.md §HBM prescribes it for wide coalesced streams on gfx950, and the calibration
+        run in this library's own access patterns (profiles/r05_pmc_calibration.txt) found the same factor for every pattern the kernels use."""
         path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{args.workload}_w{args.warmup}s{args.steps}_kernels.json")
         if world != 1 or args.nn != "auto" or args.opt or not os.path.exists(path):
             return None
@@ -472,7 +473,7 @@ def main():
             sc = j["scopes"][name]
             if what == "valu_busy":
                 return sc.get("valu_busy")
-            return (sc["FETCH_SIZE_KiB"] * FETCH_FACTOR.get(name, 1.0) + sc["WRITE_SIZE_KiB"]) * 1024.0
+            return (sc["FETCH_SIZE_KiB"] * FETCH_FACTOR_ALL + sc["WRITE_SIZE_KiB"]) * 1024.0
         except Exception:
             return None
 
@@ -487,7 +488,9 @@ def main():
             return None
         ach = (b / n) / (ms / n * 1e-3) / 1e9
         r = {"kernel": name, "device_function": KERNEL_OF.get(name), "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-             "traffic": pmc_traffic(name), "valu_busy": pmc_traffic(name, "valu_busy"), "launches": n, "avg_us": ms / n * 1e3, "total_ms": ms, "alg_bytes_per_launch": b / n}
+             "traffic": pmc_traffic(name), "valu_busy": pmc_traffic(name, "valu_busy"), "launches": n,
+             "traffic_note": "HBM-side bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE of profiles/%s_%s_w%ds%d_kernels.json (same command, same device sources; factor 2: profiles/r05_pmc_calibration.txt); "
+                             "valu_busy = SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / kernel cycles from the same summary" % (PROFILE_ROUND, args.workload, args.warmup, args.steps), "avg_us": ms / n * 1e3, "total_ms": ms, "alg_bytes_per_launch": b / n}
         if name.startswith("nn"):
             r["compulsory_bytes_per_launch"] = comp / n
             r["compulsory_frac"] = comp / n / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS
@@ -569,7 +572,7 @@ def main():
             out["comm_launches_per_step"] = timed["comm"][1] / NSTEPS
             out["rccl_nranks"] = eng.comm_nranks() if "rccl" in exchange else None
             out["per_rank"] = per_rank
-        if world == 1 and not args.no_dropin:
+        if world == 1 and not args.no_dropin and float(K) * N <= 8e6:   # (the leg writes the clouds to a temporary directory: not for the 64 x 1 M problem)
             # the literal drop-in route (bin/multiview: Frame / Session / ICP_Ceres mirror over the C ABI) on the same problem, after the clock stopped
             try:
                 sys.path.insert(0, os.path.join(ROOT, "tools"))

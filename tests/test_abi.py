@@ -53,3 +53,14 @@ def test_edge_owner_partition_is_contiguous_and_balanced():
         assert max(counts) - min(counts) <= 1, counts
     own = L.edge_owner([10, 1000, 10, 10], 2)
     assert list(own) == [0, 0, 1, 1] or list(own) == [0, 1, 1, 1]
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/mvicp.h is the drop-in boundary: it must compile as C (C99, pedantic) — no C++-isms, no torch / HIP types in any signature —
+    and mvicp_corr must be the reference's 16-byte Correspondance (include/frame.h:18-22)."""
+    import subprocess
+    src = tmp_path / "abi_c.c"
+    src.write_text('#include "mvicp.h"\n#include <stddef.h>\n'
+                   'typedef char corr_is_16_bytes[(sizeof(mvicp_corr) == 16 && offsetof(mvicp_corr, second) == 4 && offsetof(mvicp_corr, dist) == 8) ? 1 : -1];\n'
+                   'int use(mvicp_ctx* c) { const mvicp_corr* t; const long long* o; return mvicp_map_correspondences(c, &t, &o); }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src), "-o", str(tmp_path / "abi_c.o")])
