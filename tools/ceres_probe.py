@@ -44,7 +44,8 @@ def probe():
     }
     res["ceres_usable"] = bool(res["ceres_header"] and res["ceres_lib"] and res["eigen_header"])
     res["verdict"] = ("real Ceres present: a Ceres-linked harness could pin the LM half" if res["ceres_usable"]
-                      else "Ceres unavailable: pose parity is vs the fp64 CPU restatement (oracle/), LM half unpinned beyond the reference's known-answer test")
+                      else "Ceres unavailable here: pose parity is vs the fp64 CPU restatement (oracle/), which reproduces the reference's published Ceres result "
+                           "(README.md:141-146) to six digits — see the README-vector line of smoke()")
     return res
 
 
