@@ -212,7 +212,7 @@ int mvicp_set_option(mvicp_ctx* ctx, const char* name, double value);
  * examined, tree boxes / grid cells looked up, queries that needed the tree fallback, queries answered by the temporal cache,
  * candidate points fetched from memory (a wave-cooperative kernel fetches a point once and examines it from LDS many times). */
 int mvicp_nn_census(mvicp_ctx* ctx, double* out5);              /* the first five counters (the 0.1 contract) */
-/* All counters the build has, at most `cap` of them; returns how many were written (6 in version 0.3) or a negative status. */
+/* All counters the build has, at most `cap` of them; returns how many were written (10 since version 0.4) or a negative status. */
 int mvicp_nn_census_ex(mvicp_ctx* ctx, double* out, int cap);
 
 /* ---- profiling (HIP events on the library's own stream) ------------------------------------------ */

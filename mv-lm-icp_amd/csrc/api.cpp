@@ -379,7 +379,7 @@ using namespace mvicp;
 extern "C" {
 
 const char* mvicp_last_error(void) { return g_err; }
-const char* mvicp_version(void) { return "mvicp_hip 0.3 (gfx950)"; }
+const char* mvicp_version(void) { return "mvicp_hip 0.5 (gfx950)"; }
 
 int mvicp_create(int device, mvicp_ctx** out) try {
   if (!out) { set_error("out is null"); return MVICP_ERR_ARG; }
@@ -704,6 +704,23 @@ int mvicp_reset_history(mvicp_ctx* c) try {
   return MVICP_OK;
 } MVICP_GUARD_ABI
 
+// mvicp_correspond — cross-round state at a glance.  A search is a PURE FUNCTION of (clouds, graph, poses, fixed mask, cutoff): every field below
+// only decides HOW FAST the same answer is found, and tests/test_gpu_parity.py::test_correspond_regime_transitions_match_a_fresh_context checks
+// after every round of randomly perturbed registrations that the answer equals a fresh context's.  mvicp_reset_history / a poisoned exchange
+// (forget_history) drop all of it.
+//   field (common.h)              written by                               read by / meaning                                    invalidated by
+//   nn_cache_valid, _thresh       this call's end (grid / BND tile round)  temporal cache may be consulted next search          cutoff change, set_correspondences, options, reset
+//   nn_cache_edge[e]              this call's end (= active mask)          edge e was searched last time: seeds + bounds usable   fixed-mask change (per edge), reset
+//   prev_q / prev_xf[e]           the per-edge loop below                  dM, dv of the temporal cache; bit-identical transform  every search rewrites them
+//   list_valid[e], explicit_list  end of the NN stage / set_correspondences  the edge's compacted list may be maintained in place  set_correspondences, recompute_normals (dst), reset
+//   sel_med1/2[e]                 after the wait below                     one-pass bracket select once the median has settled   inactive edge, set_correspondences, reset
+//   auto_prev_dist, auto_last_method   the AUTO policy block               hand-over tile -> grid, "already handed over"          set_graph, reset
+//   corr_tie_seen, corr_far_seen  after the wait below (own launches only) tie fix-up / far launch may be skipped at a fixed point  any search that is not bit-identical; reset
+//   prev_grid_kernel              end of the NN stage                      corr_far_seen describes the last search                every search rewrites it
+//   spec_flags_valid, spec_param/plane/robust   mvicp_optimize             arm the queued first evaluation of the NEXT solve      failed solve / search, spec_eval option, reset
+//   spec_ready, spec_poses        end of this call                         evaluate_blocks may serve the first evaluation from it  consumed by the next evaluation, any list change
+//   last_rms                      mvicp_optimize                           nn_cell policy only                                    consumed here
+//   export_valid                  ensure_export                            h_export holds the lists as they are on the device     every search, set_correspondences, reset
 int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fixed, float thresh, int nn_method, int* counts, float* weights) try {
   MV_CHECK(bind(c));
   if (!poses) { set_error("poses is null"); return MVICP_ERR_ARG; }
