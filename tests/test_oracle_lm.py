@@ -1,6 +1,6 @@
-"""Anchors the 'parity unpinned' half of the oracle (oracle/oracle.cpp part (b): Jets, functors, local
-parameterizations, LM): finite differences, cross-parameterization agreement, and the reference's only
-known-answer test (src/main_pairwise.cpp:44-61,117-133; README.md:141-146)."""
+"""Anchors the LM half of the oracle (oracle/oracle.cpp part (b): Jets, functors, local parameterizations, LM): finite differences,
+cross-parameterization agreement, and the reference's only known-answer test (src/main_pairwise.cpp:44-61,117-133) — whose published
+result for real Ceres (README.md:141-146) is reproduced to six digits (test_readme_known_answer_reproduced: the pin of this half)."""
 import numpy as np
 import pytest
 
@@ -218,7 +218,7 @@ def test_readme_known_answer_reproduced(orc):
         assert run(param, parameter_tolerance=1e-6) > 100            # the stopping rule must be 1e-8 (|x| + 1e-8)
 
 
-# ---------------------------------------------------------------- how much could an unpinned detail of Ceres' schedule matter?
+# ---------------------------------------------------------------- how much could a detail of Ceres' schedule that the README vector does not reach matter?
 def _registration(orc, ref, pb, param, rounds=20):
     import cpupath
     cp = cpupath.CpuPath(pb["pts"], pb["nor"], pb["src"], pb["dst"], pb["fixed"], param, 1, orc=orc, ref=ref)
