@@ -72,9 +72,9 @@ def cpu_reference_legs(pb, plane, param, gpu_poses_after, gpu_iters, window_roun
         1..cpu_rounds of the SAME registration from the same noisy initial poses on ALL edges (its own trajectory: its own
         correspondences, its own solves), -O3 AVX2 + OpenMP on every usable core; after every round its poses are compared with the
         GPU run's poses after the same round, and its LM iteration count is listed next to the GPU's.
-    (2) `cpu_baseline.value` = the reference's own build and threading (-O2, 1 thread; CMakeLists.txt:14-22, Ceres num_threads 1):
-        too slow for all edges inside a bench run, so a bounded sample — the first 3 views' edges, one moving round (round 2, started
-        from the GPU run's poses) and one fixed-point round (the last compared round) — scaled by edge count.
+    (2) `cpu_baseline.value` = the reference's own build and threading (-O2, 1 thread; CMakeLists.txt:14-22, Ceres num_threads 1): one moving
+        round (round 2, started from the GPU run's poses) and one fixed-point round (the last compared round), on ALL edges up to cfg4's size
+        (about 110 s), on a 16-edge sample scaled by edge count beyond it (`sampled: true`).
     Both are weighted over the rounds of the timed window: a window round r <= cpu_rounds uses the measured round r, later rounds (all
     fixed-point rounds) use the last measured fixed-point round."""
     import cpupath
@@ -122,7 +122,9 @@ def cpu_reference_legs(pb, plane, param, gpu_poses_after, gpu_iters, window_roun
     variants = {("O3_avx2_allcores" if fast else "O2_threadpool_nn"): {
         "value": rate_all, "unit": "iterations/s", "cores": ncores, "s_per_round": spr_all, "edges": E, "sample": "ALL edges, rounds 1..%d measured one by one" % cpu_rounds,
         "per_round": per_round, "tree_build_s_once": tree_build_s}}
-    # ---- (2) the reference's build and threading on a bounded sample
+    # ---- (2) the reference's build and threading (-O2, one thread): ONE moving and ONE fixed-point round, started from the GPU run's poses, on ALL edges
+    #      while that stays a bounded job (E x N <= 1.3e7: cfg4 = 62 x 200 k is about 110 s); beyond that on the smallest prefix of the views with >= 16
+    #      edges, scaled by edge count — and then the line says `sampled: true` (a scaled sample must not pass for a measurement)
     def sample_views(min_edges):
         """smallest prefix of the views whose mutual edges number at least min_edges (all views if the graph is smaller)"""
         for ks in range(2, K + 1):
@@ -133,35 +135,104 @@ def cpu_reference_legs(pb, plane, param, gpu_poses_after, gpu_iters, window_roun
     r_mov = 2 if cpu_rounds >= 2 and per_round[1]["moved"] else 1
     r_fix = last_fixed["round"]
     starts = {"moving": (r_mov, pb["init"] if r_mov == 1 else gpu_poses_after[r_mov - 2]), "fixed_point": (r_fix, pb["init"] if r_fix == 1 else gpu_poses_after[r_fix - 2])}
-    # value (-O2, 1 thread = the reference's build and threading): at least 16 of the edges (3 edges x 20.67 was an extrapolation);
-    # the -O3 single-thread variant stays on the 3-view sample (a side figure)
-    for name, use_fast, min_edges in (("O2_1thread", False, 16),) + ((("O3_avx2_1thread", True, 3),) if fast else ()):
-        Ks, keep = sample_views(min_edges)
-        scale = E / max(1, len(keep))
-        c1 = cpupath.CpuPath(pb["pts"][:Ks], pb["nor"][:Ks], pb["src"][keep], pb["dst"][keep], pb["fixed"][:Ks], param, plane, cutoff=cutoff, fast=use_fast, threads=1)
-        c1.correspond(np.ascontiguousarray(pb["init"][:Ks]))   # build the trees outside the timed rounds
-        kinds = {}
-        for kind, (r, P0) in starts.items():
-            _, sm = c1.round(np.ascontiguousarray(P0[:Ks]))
-            kinds[kind] = {"round": r, "nn_s_sample": c1.last["nn_s"], "lm_s_sample": c1.last["lm_s"], "lm_iterations": sm["iterations"],
-                           "s_per_round_full": (c1.last["nn_s"] + c1.last["lm_s"]) * scale}
-        c1.close()
-        rate, spr = window_rate(lambda r: kinds["moving" if (r <= len(moved_by_round) and moved_by_round[r - 1]) else "fixed_point"]["s_per_round_full"])
-        variants[name] = {"value": rate, "unit": "iterations/s", "cores": 1, "s_per_round": spr, "by_regime": kinds,
-                          "sample": f"first {Ks} views ({len(keep)} of {E} edges), scaled x{scale:.2f}"}
-    base = variants["O2_1thread"]
-    Ks, keep = sample_views(16)
+    whole = float(E) * len(pb["pts"][0]) <= 1.3e7
+    Ks, keep = (K, list(range(E))) if whole else sample_views(16)
     scale = E / max(1, len(keep))
+    c1 = cpupath.CpuPath(pb["pts"][:Ks], pb["nor"][:Ks], pb["src"][keep], pb["dst"][keep], pb["fixed"][:Ks], param, plane, cutoff=cutoff, fast=False, threads=1)
+    c1.correspond(np.ascontiguousarray(pb["init"][:Ks]))   # build the trees outside the timed rounds
+    kinds = {}
+    for kind, (r, P0) in starts.items():
+        _, sm = c1.round(np.ascontiguousarray(P0[:Ks]))
+        kinds[kind] = {"round": r, "nn_s": c1.last["nn_s"], "lm_s": c1.last["lm_s"], "lm_iterations": sm["iterations"], "edges_measured": len(keep),
+                       "s_per_round_full": (c1.last["nn_s"] + c1.last["lm_s"]) * scale}
+    tree_build_o2 = c1.tree_build_s
+    c1.close()
+    rate, spr = window_rate(lambda r: kinds["moving" if (r <= len(moved_by_round) and moved_by_round[r - 1]) else "fixed_point"]["s_per_round_full"])
+    variants["O2_1thread"] = {"value": rate, "unit": "iterations/s", "cores": 1, "s_per_round": spr, "by_regime": kinds, "sampled": not whole, "tree_build_s_once": tree_build_o2,
+                              "sample": (f"all {E} edges" if whole else f"first {Ks} views ({len(keep)} of {E} edges), scaled x{scale:.2f}")}
+    what = f"ALL {E} edges" if whole else f"the first {Ks} views ({len(keep)} of {E} edges, scaled x{scale:.2f} by edge count)"
     out["cpu_baseline"] = {
-        "value": base["value"], "unit": "iterations/s", "cores": 1, "kind": "port",
+        "value": rate, "unit": "iterations/s", "cores": 1, "kind": "port", "sampled": not whole,
+        "sample_short": (f"real nanoflann + oracle LM (restated Ceres), -O2, 1 thread, {what}, N={len(pb['pts'][0])}: one moving round (round {r_mov}: "
+                         f"{kinds['moving']['s_per_round_full']:.1f} s) + one fixed-point round (round {r_fix}: {kinds['fixed_point']['s_per_round_full']:.1f} s) from the GPU run's poses, "
+                         f"weighted over the timed window's rounds"),
         "sample": (f"reference-equivalent CPU path (real vendored nanoflann + oracle Jet/LM restatement of Ceres, pinned on README.md:141-146).  value = -O2, 1 thread (the "
-                   f"reference's build and threading) on the first {Ks} views ({len(keep)} of {E} edges, N={len(pb['pts'][0])}): one moving round (round {r_mov}) and one "
-                   f"fixed-point round (round {r_fix}) started from the GPU run's poses, scaled x{scale:.2f} by edge count and weighted over the rounds of the timed window.  "
+                   f"reference's build and threading) on {what}, N={len(pb['pts'][0])}: one moving round (round {r_mov}) and one "
+                   f"fixed-point round (round {r_fix}) started from the GPU run's poses, weighted over the rounds of the timed window.  "
                    f"variants.{'O3_avx2_allcores' if fast else 'O2_threadpool_nn'} = ALL {E} edges, rounds 1..{cpu_rounds} of the registration measured one by one on {ncores} cores"),
         "variants": variants, "host_cores": ncores,
         "fast_build_note": "-O3 -march=x86-64-v3 (AVX2/FMA, portable stand-in for -march=native: the .so is built off-box), -ffp-contract=off; all-cores = OpenMP over correspondences / queries",
     }
     return out
+
+
+COMPACT_LIMIT = 4000   # bytes: the driver keeps an 8-KB tail of stdout+stderr, and the line has to sit inside it whole (round 5's 20-KB line did not: BENCH_r05.parsed = null)
+
+
+def _sig(x, n=6):
+    """numbers of the compact line: n significant digits (the detail file keeps full precision)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        return float(f"{x:.{n}g}") if np.isfinite(x) else None
+    if isinstance(x, dict):
+        return {k: _sig(v, n) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, n) for v in x]
+    return x
+
+
+def compact_line(out, detail_file=None):
+    """The ONE JSON line rank 0 prints last: the contract's keys + `roofline` + `cpu_baseline` in at most COMPACT_LIMIT bytes.  Everything else
+    the run worked out (window arrays, regimes, per-kernel rooflines, the drop-in leg, the per-round CPU table) is in `detail_file`."""
+    def pick(d, keys):
+        return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+    line = pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
+    line["config"] = pick(out.get("config", {}), ("workload", "views", "pts_per_view", "edges", "cutoff", "parallelism", "nn"))
+    line.update(pick(out, ("value_moving_rounds", "value_fixed_point_rounds", "timed_region_s", "windows")))
+    rf = out.get("roofline")
+    line["roofline"] = None if not rf else pick(rf, ("kernel", "device_function", "bound", "achieved", "peak", "unit", "frac", "traffic", "valu_busy", "launches", "avg_us",
+                                                     "alg_bytes_per_launch", "compulsory_frac"))
+    others = {}
+    for k, r in out.items():
+        if k.startswith("roofline_") and r and k != "roofline_nn" and r.get("kernel") != (rf or {}).get("kernel"):
+            others[r["kernel"]] = pick(r, ("frac", "avg_us", "launches", "traffic"))
+    if others:
+        line["roofline_other_kernels"] = others
+    cb = out.get("cpu_baseline")
+    if cb is not None:
+        c = pick(cb, ("value", "unit", "cores", "kind", "sampled", "host_cores", "error"))
+        if "sample" in cb:
+            c["sample"] = cb.get("sample_short", cb["sample"][:300])
+        allc = [v for k, v in cb.get("variants", {}).items() if "allcores" in k or "threadpool" in k]
+        if allc:
+            c["all_cores_value"] = allc[0]["value"]
+        line["cpu_baseline"] = c
+    if "speedup_vs_cpu_baseline" in out:
+        line["speedup_vs_cpu_baseline"] = pick(out["speedup_vs_cpu_baseline"], ("value", "vs_all_cores"))
+    if "pose_diff_vs_cpu_path" in out:
+        line["pose_diff_vs_cpu_path"] = pick(out["pose_diff_vs_cpu_path"], ("rounds_compared", "max_translation_m", "max_rotation_rad"))
+    if "pose_error_vs_gt" in out:
+        line["pose_error_vs_gt"] = out["pose_error_vs_gt"]
+    dp = out.get("dropin")
+    if isinstance(dp, dict):
+        line["dropin"] = {k: pick(dp[k], ("it_per_s_after_first_round", "first_round_ms")) for k in ("copyback", "device_only") if isinstance(dp.get(k), dict)} or pick(dp, ("error",))
+        if "fixed_point_note" in dp:
+            line["dropin"]["note"] = dp["fixed_point_note"]
+    if "setup_s" in out:
+        line["setup_s"] = out["setup_s"].get("total_s") if isinstance(out["setup_s"], dict) else out["setup_s"]
+    line.update(pick(out, ("comm_ms_per_step", "rccl_nranks")))
+    line["source_sha16"] = out.get("source_sha16")
+    line["detail_file"] = detail_file
+    line = _sig(line)
+    s = json.dumps(line, separators=(",", ":"))
+    for drop in ("roofline_other_kernels", "dropin", "pose_error_vs_gt", "speedup_vs_cpu_baseline"):   # (never needed at today's sizes; a guard, not a plan)
+        if len(s) <= COMPACT_LIMIT:
+            break
+        line.pop(drop, None)
+        s = json.dumps(line, separators=(",", ":"))
+    assert len(s) <= COMPACT_LIMIT, len(s)
+    return s
 
 
 def free_port():
@@ -198,6 +269,8 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (mvicp_set_option), repeatable; tuning / A-B runs")
     ap.add_argument("--windows", type=int, default=0, help="the timed window of --steps rounds is repeated this many times; value = the MEDIAN window (all in window_values).  "
                     "0 (default) = at least 5 and as many as make the whole timed region >= 2 s (sized from the first window)")
+    ap.add_argument("--detail-file", default=os.path.join(ROOT, "bench_detail.json"), help="where rank 0 writes the full record (windows, regimes, every kernel's roofline, the drop-in "
+                    "and CPU legs); the printed line stays compact and names this file")
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in leg (bin/multiview on the same problem written to disk, with and without copy-back)")
     args = ap.parse_args()
     if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or args.windows < 0:
@@ -592,7 +665,18 @@ def main():
                                                   "note": "GPU whole-job rate / CPU path rate over the same timed rounds (1 thread -O2 sampled and scaled; all cores measured on all edges); a reported baseline, not a kernel-quality figure"}
             except Exception as ex:  # the baseline is a reported extra, never the measurement
                 out["cpu_baseline"] = {"error": repr(ex)}
-        print(json.dumps(out))
+        detail = args.detail_file
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(detail)), exist_ok=True)
+            with open(detail, "w") as f:
+                json.dump(out, f)
+                f.write("\n")
+            detail = os.path.relpath(detail, ROOT)
+        except OSError as ex:   # a read-only checkout still gets its line
+            detail = None
+            print(f"[bench] could not write {args.detail_file}: {ex}", file=sys.stderr)
+        sys.stdout.flush()
+        print(compact_line(out, detail), flush=True)
     eng.close()
     if world > 1:
         dist.destroy_process_group()

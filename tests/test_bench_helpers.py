@@ -77,3 +77,33 @@ def test_gpus_more_than_visible_devices_is_an_error_not_a_smaller_job():
     env.update(RANK="0", WORLD_SIZE="4", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and r.stdout.strip() == "" and "WORLD_SIZE=4 but --gpus 2" in r.stderr
+
+
+def test_compact_line_fits_the_driver_tail_and_round_trips():
+    """BENCH_r05.parsed was null because the printed line had grown to 20 KB and the driver keeps an 8-KB tail.  The printed line is now built by
+    bench.compact_line from the full record (which goes to --detail-file): it must stay under 4 KB, parse, and carry the contract's keys with
+    `roofline` and `cpu_baseline` — checked on the recorded full records of earlier rounds (20 KB / 12 KB / 9 KB)."""
+    must = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+            "roofline", "cpu_baseline", "source_sha16", "detail_file"}
+    seen = 0
+    for name in ("r05_cfg4_w5s20_bench_line.json", "r05_cfg4_bench_line.json", "r04_cfg4_w5s20_bench_line.json", "r05_cfg5_bench_line.json", "r05_shard8_bench_line.json"):
+        p = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(p):
+            continue
+        full = json.loads([l for l in open(p).read().splitlines() if l.startswith("{")][-1])
+        line = bench.compact_line(full, "bench_detail.json")
+        assert len(line) <= bench.COMPACT_LIMIT < 6000 and "\n" not in line, (name, len(line))
+        d = json.loads(line)
+        need = must - ({"cpu_baseline"} if "cpu_baseline" not in full else set())
+        assert need <= set(d), (name, need - set(d))
+        assert d["value"] == float("%.6g" % full["value"]) and d["config"]["workload"] == full["config"]["workload"] and "model" not in d["config"]
+        assert abs(d["ms_per_step"] * d["steps"] / 1e3 * d["value"] / d["steps"] - 1.0) < 1e-4          # value x ms_per_step consistent after rounding
+        r = d["roofline"]
+        assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_us"} <= set(r) and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-5
+        if "cpu_baseline" in full:
+            assert {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"]) and len(d["cpu_baseline"]["sample"]) <= 300
+        seen += 1
+    assert seen >= 1
+    # a pathological record (long strings everywhere) still fits: optional blocks are dropped before the limit is broken
+    full["dropin"] = {"copyback": {"it_per_s_after_first_round": 1.0, "first_round_ms": 2.0}, "device_only": {"it_per_s_after_first_round": 1.0, "first_round_ms": 2.0}, "fixed_point_note": "x" * 5000}
+    assert len(bench.compact_line(full, "d.json")) <= bench.COMPACT_LIMIT

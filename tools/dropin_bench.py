@@ -68,6 +68,8 @@ def run(pb, param, plane, cutoff, rounds=20, tmp_root=None, timeout=600):
                        "ICP_Ceres::ceresOptimizer_*).  it_per_s = all rounds, first round included — the first computeClosestPointsToNeighbours uploads the clouds and builds their "
                        "structures (the reference builds its KD-trees there too, frame.cpp:188-193); it_per_s_after_first_round = rounds 2..N; copyback = the reference's contract "
                        "(Frame::neighbours[j].correspondances filled every round: one device un-sort + one pinned copy + host slicing), device_only = lists stay on the GPU")
+        out["fixed_point_note"] = ("device_only memoises a search whose poses are bit-identical to the last one's (host/frame.cpp Session::correspond): its fixed-point rounds "
+                                   "do no search, unlike `value`, which runs the verify pass every round; never comparable to `value`")
         return out
     finally:
         shutil.rmtree(d, ignore_errors=True)
