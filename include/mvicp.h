@@ -123,10 +123,19 @@ int mvicp_get_correspondences(mvicp_ctx* ctx, int edge, int cap, int* first, int
  * rank owns, ONE asynchronous copy brings the triples into pinned host memory OWNED BY THE LIBRARY:
  *   *triples            -> the buffer;   *offsets -> n_edges + 1 positions: edge e = (*triples)[(*offsets)[e] .. (*offsets)[e + 1])
  * (zero width for edges of other ranks, edges whose source is fixed and edges that hold an explicit list).  Both pointers stay valid until
- * the next mvicp_correspond / mvicp_set_correspondences / mvicp_set_graph / mvicp_reset_history / mvicp_destroy on this context.  The
+ * the next mvicp_correspond that changes a list (see mvicp_correspondence_epochs) / mvicp_set_correspondences / mvicp_set_graph /
+ * mvicp_reset_history / mvicp_destroy on this context.  The
  * first call after a search does the work, later calls (and mvicp_get_correspondences, which slices the same buffer) are free. */
 typedef struct mvicp_corr { int first; int second; double dist; } mvicp_corr;
 int mvicp_map_correspondences(mvicp_ctx* ctx, const mvicp_corr** triples, const long long** offsets);
+/* Per-edge change counters of the lists, for callers that keep their own copy (the Frame mirror's `neighbours[j].correspondances`,
+ * frame.cpp:110,156-160: the reference clears and refills every list every round; a caller that holds edge e's list with epoch x may skip the
+ * refill while (*epochs)[e] == x).  An edge keeps its epoch across an mvicp_correspond iff its list is PROVABLY last search's bit for bit — same
+ * cutoff, both poses bit-identical, searched then and now (a search is a pure function of these) — e.g. every edge in the rounds after the
+ * registration has converged; then mvicp_map_correspondences returns the buffer it already holds without any device work.  Every other event
+ * (a search with different inputs, mvicp_set_correspondences, mvicp_reset_history, a failed search) gives the edge a new, never repeated epoch.
+ * *epochs -> n_edges counters owned by the library, valid until mvicp_set_graph / mvicp_destroy. */
+int mvicp_correspondence_epochs(mvicp_ctx* ctx, const unsigned long long** epochs);
 /* Install an explicit list (pairwise known-correspondence case, main_pairwise.cpp:60-61; tests). */
 int mvicp_set_correspondences(mvicp_ctx* ctx, int edge, int n, const int* first, const int* second, float weight);
 

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstring>
 #include <ctime>
+#include <chrono>
 #include <condition_variable>
 #include <exception>
 #include <mutex>
@@ -295,23 +296,46 @@ static int upload_sorted_normals(FrameDev& f, const double* nrm) {
 }
 
 static int build_frame_structures(mvicp_ctx* c, FrameDev& f, const double* xyz, const double* nrm) {
+  if (c->fault_inject_build.load() > 0 && c->fault_inject_build.fetch_sub(1) == 1) { set_error("injected structure-build failure (option fault_inject_build)"); return MVICP_ERR_INTERNAL; }
   MV_CHECK(build_grid(c, f, xyz));
   if (nrm) MV_CHECK(upload_sorted_normals(f, nrm));
   return MVICP_OK;
 }
 
 int finish_builds(mvicp_ctx* c) {
-  int st = MVICP_OK;
-  std::string msg;
   for (FrameDev& f : c->frames) {
     if (!f.job) continue;
     int s1 = MVICP_ERR_INTERNAL;
     try { s1 = f.job->fut.get(); } catch (...) { f.job->err = "structure build threw"; }
-    if (s1 != MVICP_OK && st == MVICP_OK) { st = s1; msg = f.job->err; }
+    if (s1 != MVICP_OK) {
+      // sticky: the frame stays unusable (and says why) until it is uploaded again; its half-built structures are released now
+      f.build_error = f.job->err.empty() ? std::string("structure build failed") : f.job->err;
+      (void)hipSetDevice(c->device);
+      free_grid(f.grid); f.has_grid = false;
+    }
     f.job.reset();
   }
-  if (st != MVICP_OK) set_error("%s", msg.c_str());
-  return st;
+  for (size_t i = 0; i < c->frames.size(); ++i)
+    if (!c->frames[i].build_error.empty()) {
+      set_error("frame %d: %s (upload the cloud again with mvicp_set_frame)", (int)i, c->frames[i].build_error.c_str());
+      return MVICP_ERR_STATE;
+    }
+  return MVICP_OK;
+}
+
+// Back-pressure of the background builds: each pending build holds a private copy of its cloud (48 B per point) and a parked thread; only the
+// builds themselves are throttled by the slots.  An upload loop over many large clouds (64 x 1 M points = 3 GB of copies) therefore waits here
+// for its oldest pending build once as many are pending as there are slots.  (The job's status is kept for finish_builds.)
+static void throttle_builds(mvicp_ctx* c) {
+  const int limit = std::max(2, (int)std::min(32u, std::thread::hardware_concurrency()));
+  for (;;) {
+    int pending = 0;
+    BuildJob* oldest = nullptr;
+    for (FrameDev& f : c->frames)
+      if (f.job && f.job->fut.valid() && f.job->fut.wait_for(std::chrono::seconds(0)) != std::future_status::ready) { if (!oldest) oldest = f.job.get(); ++pending; }
+    if (pending < limit || !oldest) return;
+    oldest->fut.wait();
+  }
 }
 
 // One device evaluation of all per-edge blocks at `poses` -> host `out` (E x 91), all-reduced over ranks.
@@ -445,7 +469,7 @@ int mvicp_set_frame(mvicp_ctx* c, int frame, const double* xyz, const double* nr
   FrameDev& f = c->frames[frame];
   if (f.job) { try { (void)f.job->fut.get(); } catch (...) {} f.job.reset(); }   // a build of the cloud this call replaces
   dev_free(f.pts); dev_free(f.nor); free_grid(f.grid); free_tie(f);
-  f.has_grid = false;
+  f.has_grid = false; f.build_error.clear();
   f.n = n;
   MV_CHECK(dev_alloc(&f.pts, 3 * (size_t)n));
   if (n) MV_HIP(hipMemcpy(f.pts, xyz, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice));
@@ -460,10 +484,15 @@ int mvicp_set_frame(mvicp_ctx* c, int frame, const double* xyz, const double* nr
     f.max_norm = std::max(f.max_norm, std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]));
   }
   if (n == 0) return MVICP_OK;
-  if (!c->async_build) return build_frame_structures(c, f, xyz, nrm);
+  if (!c->async_build) {
+    const int st = build_frame_structures(c, f, xyz, nrm);
+    if (st != MVICP_OK) { f.build_error = g_err; free_grid(f.grid); f.has_grid = false; }
+    return st;
+  }
   // The per-cloud structures (k-d order, box hierarchy, matrix-pipe operands, hash: ~0.1 s of host work per 200 k points) are built on a
   // thread of their own from a private copy of the cloud, so that a driver's upload loop builds its clouds side by side (cfg4: 32 clouds,
   // 2.9 s one after the other); whoever needs a structure first waits for the pending builds (finish_builds).
+  throttle_builds(c);
   std::shared_ptr<BuildJob> job = std::make_shared<BuildJob>();
   job->xyz.assign(xyz, xyz + 3 * (size_t)n);
   if (nrm) job->nrm.assign(nrm, nrm + 3 * (size_t)n);
@@ -613,6 +642,8 @@ int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) t
   MV_CHECK(dev_alloc(&c->d_qpos, cap));
   MV_HIP(hipMemset(c->d_qpos, 0xff, sizeof(int) * std::max<size_t>(cap, 1)));
   c->list_valid.assign(E, 0); c->explicit_list.assign(E, 0); c->export_valid = false; c->export_off.assign((size_t)E + 1, 0);
+  c->qpos_valid.assign(E, 0); c->corr_epoch.assign(E, 0);
+  for (int e = 0; e < E; ++e) c->corr_epoch[e] = ++c->epoch_counter;
   c->dslot_off.assign(E + 1, 0);
   for (int e = 0; e < E; ++e) c->dslot_off[e + 1] = c->dslot_off[e] + (int)(((c->owned[e] ? c->frames[src[e]].n : 0) + 255) / 256);
   c->n_dslots = c->dslot_off[E];
@@ -691,6 +722,8 @@ static void forget_history(mvicp_ctx* c) {
   c->corr_tie_seen = c->corr_far_seen = 1u;
   c->list_valid.assign(E, 0);                          // every list is re-compacted and re-gathered
   c->export_valid = false;
+  c->qpos_valid.assign(E, 0);
+  for (int e = 0; e < E; ++e) c->corr_epoch[e] = ++c->epoch_counter;
   c->sel_med1.assign(E, -1.0); c->sel_med2.assign(E, -1.0);
   c->spec_ready = false; c->spec_arm = false; c->spec_flags_valid = false;
   c->have_corr = false;
@@ -720,7 +753,9 @@ int mvicp_reset_history(mvicp_ctx* c) try {
 //   spec_flags_valid, spec_param/plane/robust   mvicp_optimize             arm the queued first evaluation of the NEXT solve      failed solve / search, spec_eval option, reset
 //   spec_ready, spec_poses        end of this call                         evaluate_blocks may serve the first evaluation from it  consumed by the next evaluation, any list change
 //   last_rms                      mvicp_optimize                           nn_cell policy only                                    consumed here
-//   export_valid                  ensure_export                            h_export holds the lists as they are on the device     every search, set_correspondences, reset
+//   export_valid                  ensure_export                            h_export holds the lists as they are on the device     every search that can change a list, set_correspondences, reset
+//   qpos_valid[e]                 end of the NN stage                      d_qpos / second / cd2 = the last search's result (export)  set_correspondences, failed search, reset
+//   corr_epoch[e]                 end of this call                         callers skip copying a list whose epoch they hold      bumped unless the edge's inputs are bit-identical to last search's
 int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fixed, float thresh, int nn_method, int* counts, float* weights) try {
   MV_CHECK(bind(c));
   if (!poses) { set_error("poses is null"); return MVICP_ERR_ARG; }
@@ -730,6 +765,10 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   // per-edge query transforms (frame.cpp:117-118,131,136) + active mask (frame.cpp:93)
   std::vector<int> nsrc(E, 0);
   std::vector<char> same_edge(E, 0);   // the edge's query transform is bit-identical to last search's (and the temporal cache is on for it)
+  // the edge's list after this search IS last search's, bit for bit: a search is a pure function of (clouds, transform, cutoff), and all three are
+  // last search's — whichever kernel runs.  Such an edge keeps its epoch (mvicp_correspondence_epochs), and if every edge does, the export too.
+  std::vector<char> unchanged(E, 0);
+  const bool hist_ok = c->have_corr && (int)c->nn_cache_edge.size() == E && c->nn_cache_thresh == thresh && (int)c->qpos_valid.size() == E;
   bool same_active_set = (int)c->nn_cache_edge.size() == E;   // the set of searched edges is last search's (a changed `fixed` mask changes it)
   double* hx = c->h_pin;
   for (int e = 0; e < E; ++e) {
@@ -761,6 +800,9 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
     // A transform that is BIT-IDENTICAL to last search's (a converged registration: the LM ends without stepping) reproduces every
     // query bit for bit: no allowance, and dM = dv = 0 below, so the kernel sees eps == 0 and re-verifies without rewriting anything.
     double* pxf = &c->prev_xf[(size_t)e * 24];
+    if (!c->owned[e]) unchanged[e] = 1;   // (another rank's edge: nothing of it lives here)
+    else if (c->active[e]) unchanged[e] = hist_ok && c->nn_cache_edge[e] && c->qpos_valid[e] && !c->explicit_list[e] && std::memcmp(pxf, x, sizeof(double) * 24) == 0;
+    else unchanged[e] = hist_ok && !c->nn_cache_edge[e] && !c->explicit_list[e] && c->h_count[e] == 0;   // not searched now, not searched then: stays empty
     const bool same_xf = cache_on && std::memcmp(pxf, x, sizeof(double) * 24) == 0;
     x[24] = cache_on ? (same_xf ? 0.0 : 1e-12 * (scale * (rmax + 1.0) + 1.0)) : -1.0;
     same_edge[e] = same_xf;
@@ -901,6 +943,8 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
     upload_doubles = c->ctl_r2_off + (size_t)E * kEdgeRel;
   }
   if (method != MVICP_NN_BRUTE && method != MVICP_NN_GRID && method != MVICP_NN_TILE) { set_error("unknown nn_method %d", nn_method); return MVICP_ERR_ARG; }   // (an argument error: the same on every rank)
+  bool all_unchanged = true;
+  for (int e = 0; e < E; ++e) { if (!unchanged[e]) all_unchanged = false; if (c->active[e]) c->qpos_valid[e] = 0; }   // (set again once the NN stage is queued)
   auto local_search = [&]() -> int {
   MV_HIP(hipMemcpyAsync(c->d_ctl, hx, sizeof(double) * upload_doubles, hipMemcpyHostToDevice, c->stream));
   c->far_narrow = nn_method == MVICP_NN_AUTO && method == MVICP_NN_GRID && c->nn_cache_valid && c->nn_cache_enable && all_same;   // the fixed point: (almost) every query is a cache hit
@@ -917,8 +961,8 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   c->nn_cache_thresh = thresh;
   c->auto_last_method = handed_over ? MVICP_NN_GRID : method;   // (the policy's "already handed over" state)
   c->nn_cache_edge.assign(c->active.begin(), c->active.end());
-  for (int e = 0; e < E; ++e) { c->list_valid[e] = c->active[e]; if (c->active[e]) c->explicit_list[e] = 0; }
-  c->export_valid = false;
+  for (int e = 0; e < E; ++e) { c->list_valid[e] = c->active[e]; if (c->owned[e]) c->qpos_valid[e] = c->active[e]; if (c->active[e]) c->explicit_list[e] = 0; }
+  if (!all_unchanged) c->export_valid = false;   // (a search that reproduces every list leaves the exported copy what it is)
 
   mark("host.corr.nn_launch");
   if (!nothing_can_change) {
@@ -1045,6 +1089,7 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
     if (counts) counts[e] = c->h_count[e];
     if (weights) weights[e] = c->h_weight[e];
   }
+  for (int e = 0; e < E; ++e) if (!unchanged[e]) c->corr_epoch[e] = ++c->epoch_counter;
   c->have_corr = true;
   mark("host.corr.finish");
   if (c->profile) prof_collect(c);
@@ -1069,6 +1114,14 @@ int mvicp_map_correspondences(mvicp_ctx* c, const mvicp_corr** triples, const lo
   MV_CHECK(ensure_export(c));
   *triples = (const mvicp_corr*)c->h_export;
   *offsets = c->export_off.data();
+  return MVICP_OK;
+} MVICP_GUARD_ABI
+
+int mvicp_correspondence_epochs(mvicp_ctx* c, const unsigned long long** epochs) try {
+  MV_CHECK(bind(c));
+  if (!epochs) { set_error("null output"); return MVICP_ERR_ARG; }
+  if (c->E == 0) { set_error("no graph"); return MVICP_ERR_STATE; }
+  *epochs = c->corr_epoch.data();
   return MVICP_OK;
 } MVICP_GUARD_ABI
 
@@ -1139,6 +1192,7 @@ int mvicp_set_correspondences(mvicp_ctx* c, int edge, int n, const int* first, c
   c->nn_cache_valid = false;
   c->spec_ready = false;
   c->list_valid[edge] = 0; c->explicit_list[edge] = 1; c->export_valid = false;
+  c->qpos_valid[edge] = 0; c->corr_epoch[edge] = ++c->epoch_counter;
   c->sel_med1[edge] = c->sel_med2[edge] = -1.0;
   const double a = (double)weight;
   MV_HIP(hipMemcpy(c->d_count + edge, &n, sizeof(int), hipMemcpyHostToDevice));
@@ -1229,6 +1283,7 @@ int mvicp_set_option(mvicp_ctx* c, const char* name, double value) try {
   if (std::strcmp(name, "tile_cache") == 0) { c->tile_cache = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "spin_wait") == 0) { c->spin_wait = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "fault_inject") == 0) { c->fault_inject = (int)value; return MVICP_OK; }            // tests: the value-th mvicp_correspond from now fails locally before its exchange
+  if (std::strcmp(name, "fault_inject_build") == 0) { c->fault_inject_build.store((int)value); return MVICP_OK; }      // tests: the value-th structure build from now fails
   if (std::strcmp(name, "fault_inject_eval") == 0) { c->fault_inject_eval = (int)value; return MVICP_OK; }  // tests: the value-th exchanged LM evaluation from now fails locally
   if (std::strcmp(name, "spec_eval") == 0) { c->spec_enable = value != 0.0; c->spec_ready = false; return MVICP_OK; }
   if (std::strcmp(name, "grid_target") == 0) {

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <future>
@@ -83,6 +84,8 @@ struct BuildJob { std::future<int> fut; std::string err; std::vector<double> xyz
 
 struct FrameDev {
   std::shared_ptr<BuildJob> job;   // pending structure build (null: none)
+  std::string build_error;         // sticky: this cloud's structure build failed (message); cleared only by a new mvicp_set_frame of this slot.  While it
+                                   // is set, every entry point that needs the structures fails — never a silent O(N^2) brute-force fallback
   int n = 0;
   double* pts = nullptr;  // n x 3 AoS, original order
   double* nor = nullptr;  // n x 3 or null
@@ -155,6 +158,10 @@ struct mvicp_ctx {
   int* d_xblock_cnt = nullptr;
   std::vector<long long> export_off; // E+1: edge e's triples = h_export[export_off[e] .. export_off[e + 1])
   bool export_valid = false;         // h_export holds the lists as they are on the device now
+  std::vector<char> qpos_valid;      // E: d_qpos / d_second / d_cd2 describe the LAST SEARCH's result of this edge (what the export reads).  Unlike list_valid
+                                     // (= the list may be maintained in place next round) it survives mvicp_recompute_normals, which only re-gathers operands
+  std::vector<unsigned long long> corr_epoch;   // E: changes whenever the edge's list (count, triples, weight) may differ from what it was (mvicp_correspondence_epochs)
+  unsigned long long epoch_counter = 0;
   double* d_stream = nullptr;       // 10 x total_cap SoA: p (3) | n (3) | c = n . q | q (3)   (linearize.hip)
   // compaction scratch
   int n_cblocks = 0;                // total compaction blocks over owned edges
@@ -215,6 +222,7 @@ struct mvicp_ctx {
   std::vector<double> ar_host;
 
   bool async_build = true;          // option "async_build": mvicp_set_frame builds the per-cloud structures on a background host thread
+  std::atomic<int> fault_inject_build{0};   // tests only: the n-th structure build from now fails (builds run on background threads)
   int fault_inject = 0, fault_inject_eval = 0;   // tests only: make the n-th search / exchanged evaluation from now fail locally before its collective
   // options / NN census (profiling only)
   bool list_reuse = true;          // skip compaction + gather for edges whose list did not change

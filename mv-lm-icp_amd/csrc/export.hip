@@ -148,7 +148,7 @@ int launch_export(mvicp_ctx* c) {
   std::vector<int> nexp(E, 0);
   long long total = 0;
   for (int e = 0; e < E; ++e) {
-    const bool ok = c->owned[e] && !c->explicit_list[e] && c->list_valid[e] && c->h_count[e] > 0;
+    const bool ok = c->owned[e] && !c->explicit_list[e] && c->qpos_valid[e] && c->h_count[e] > 0;   // (qpos_valid, not list_valid: mvicp_recompute_normals clears the latter — ADVICE r5)
     nexp[e] = ok ? c->frames[c->esrc[e]].n : 0;
     c->export_off[e + 1] = c->export_off[e] + (ok ? c->h_count[e] : 0);
   }

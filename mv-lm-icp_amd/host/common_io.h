@@ -36,6 +36,16 @@ inline bool loadXYZ(const std::string& filename, std::vector<Vector3d>& pts, std
       long long rows = 0;
       file.read(reinterpret_cast<char*>(&rows), 8);
       if (!file || rows < 0) { std::cerr << filename << ": bad binary header" << std::endl; return false; }
+      // the header is not trusted: the row count must fit the bytes the file really holds (a corrupt count would otherwise ask for a multi-GB
+      // allocation, or overflow 6 * rows, and throw out of a function that reports failure by return value — ADVICE r5)
+      const std::streamoff here = file.tellg();
+      file.seekg(0, std::ios::end);
+      const std::streamoff end = file.tellg();
+      file.seekg(here);
+      if (here < 0 || end < here || (unsigned long long)rows > (unsigned long long)(end - here) / 48ull) {
+        std::cerr << filename << ": binary header claims " << rows << " rows, the file holds " << (end >= here ? (long long)((end - here) / 48) : 0) << std::endl;
+        return false;
+      }
       std::vector<double> raw(6 * (size_t)rows);
       file.read(reinterpret_cast<char*>(raw.data()), (std::streamsize)(raw.size() * sizeof(double)));
       if ((size_t)file.gcount() != raw.size() * sizeof(double)) { std::cerr << filename << ": truncated" << std::endl; return false; }
@@ -81,9 +91,12 @@ inline void saveMatrix4d(const std::string& filename, const Isometry3d& P) {
 
 // common.h:36-67: file-scope default-seeded std::mt19937 + std::normal_distribution<double>(0,1); draw order w then t;
 // noisyPose = pose * Exp(sigma w) (rotation appended on the right), translation += sigmat t.
-// std::normal_distribution's algorithm is implementation-defined: libstdc++ (this build, and the reference on the README's Ubuntu)
-// and libc++ (the reference on OS X) run the same polar method on the same uniform stream but hand out a pair's variates in opposite
-// order.  noiseStream() = 1 (--noise_stream libc++) restates libc++'s order — the stream the numbers of README.md:141-146 come from.
+// std::normal_distribution's algorithm is implementation-defined: libstdc++ (this build) and libc++ (the reference on OS X) run the same
+// polar method on the same uniform stream but hand out a pair's variates in opposite order.  noiseStream() = 1 (--noise_stream libc++)
+// restates libc++'s order, filled left to right — the stream the numbers of README.md:141-146 come from, and the ONLY one that is pinned.
+// noiseStream() = 0 (default) = this build's libstdc++ variates filled left to right; noiseStream() = 2 (--noise_stream g++) = the same variates
+// with each triple reversed: the reference draws w and t as constructor ARGUMENTS (`Vector3d w(normal(g), normal(g), normal(g))`, common.h:43,52),
+// whose evaluation order is unspecified, and g++ usually evaluates arguments right to left — a model of an Ubuntu/g++ build, not a pinned fact.
 inline std::mt19937& noiseGenerator() { static std::mt19937 g; return g; }
 inline int& noiseStream() { static int s = 0; return s; }
 struct LibcxxNormal {   // libc++ <random> normal_distribution::operator(): first-drawn coordinate first, second kept for the next call
@@ -106,6 +119,7 @@ inline Isometry3d addNoise(const Isometry3d& pose, double sigma, double sigmat) 
   double z[6];
   if (noiseStream() == 1) { LibcxxNormal normal; for (double& x : z) x = normal(gen); }
   else { std::normal_distribution<double> normal(0.0, 1.0); for (double& x : z) x = normal(gen); }
+  if (noiseStream() == 2) { std::swap(z[0], z[2]); std::swap(z[3], z[5]); }
   double w[3] = {z[0] * sigma, z[1] * sigma, z[2] * sigma};
   double Rw[9];
   se3::aa_to_R(w, Rw);  // SO3::exp(w)

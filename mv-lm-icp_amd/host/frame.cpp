@@ -32,6 +32,7 @@ void Session::reset() {
 }
 
 void Session::invalidate() {
+  invalidate_lists();
   frames_key = nullptr;
   frame_keys.clear();
   last_poses.clear();
@@ -66,6 +67,8 @@ void Session::bind(std::vector<std::shared_ptr<Frame>>& frames) {
   frames_key = (const void*)&frames;
   frame_keys = keys;
   last_poses.clear();
+  held.assign(esrc.size(), Held());
+  epochs = nullptr;
 }
 
 void Session::correspond(std::vector<std::shared_ptr<Frame>>& frames, float thresh) {
@@ -82,7 +85,10 @@ void Session::correspond(std::vector<std::shared_ptr<Frame>>& frames, float thre
   last_fixed = fx;
   corr = nullptr; corr_off = nullptr;
   // the literal drop-in contract: every list in the reference's layout, un-sorted on the device, ONE copy per round for all edges
-  if (copy_back) check(mvicp_map_correspondences(ctx, &corr, &corr_off));
+  if (copy_back) {
+    check(mvicp_map_correspondences(ctx, &corr, &corr_off));   // (no device work when the search reproduced every list: mvicp.h)
+    check(mvicp_correspondence_epochs(ctx, &epochs));
+  }
 }
 
 void Session::optimize(std::vector<std::shared_ptr<Frame>>& frames, int param, bool pointToPlane, bool robust, mvicp_summary* out) {
@@ -192,9 +198,17 @@ void Frame::computeClosestPointsToNeighbours(std::vector<std::shared_ptr<Frame>>
     for (OutgoingEdge& edge : f.neighbours) {
       edge.weight = S.weights[e];
       const size_t n = S.copy_back && S.corr ? (size_t)(S.corr_off[e + 1] - S.corr_off[e]) : 0;
-      // frame.cpp:110,158: clear(), then one push_back per kept pair — here the finished slice of the mapped triples (same layout)
+      // frame.cpp:110,158: clear(), then one push_back per kept pair — here the finished slice of the mapped triples (same layout).  A list
+      // the vector already holds (same epoch of the library's list, same buffer, same length) is left as it is: after the registration
+      // has converged every round reproduces every list, and re-copying cfg4's 198 MB of unchanged triples was 2.3 ms per round
+      Session::Held* h = S.copy_back && S.corr && S.epochs && e < S.held.size() ? &S.held[e] : nullptr;
+      if (h && h->epoch == S.epochs[e] && h->epoch != 0 && h->n == n && edge.correspondances.size() == n && (const void*)edge.correspondances.data() == h->data) {
+        ++S.edges_skipped; ++e; continue;
+      }
       edge.correspondances.resize(n);
       if (n) pieces.push_back(std::make_pair(std::make_pair((char*)edge.correspondances.data(), (const char*)(S.corr + S.corr_off[e])), n * sizeof(Correspondance)));
+      if (h) { h->epoch = S.epochs[e]; h->data = (const void*)edge.correspondances.data(); h->n = n; }
+      ++S.edges_copied;
       ++e;
     }
     parallel_copy(pieces, S.copy_threads);

@@ -60,6 +60,15 @@ struct Session {
   bool copy_back = true;  // fill Frame::neighbours[].correspondances after the search (off: device-only, faster)
   int copy_threads = 8;   // host threads that slice the mapped triples into a frame's vectors (1 = the calling thread alone)
   const mvicp_corr* corr = nullptr; const long long* corr_off = nullptr;   // mvicp_map_correspondences of the current search (library-owned, pinned)
+  // Copy-back bookkeeping (frame.cpp:110,156-160 clears and refills every list every round; refilling a list with the bytes it already holds
+  // is skipped): per edge the library's change counter (mvicp_correspondence_epochs) of the list the Frame's vector was last filled from, and
+  // the vector's buffer and length at that time — a caller that resized, cleared or re-allocated the vector gets a fresh copy.  (A caller that
+  // overwrites ELEMENTS of a filled list in place and expects the next round to repair them must call Session::invalidate_lists().)
+  const unsigned long long* epochs = nullptr;
+  struct Held { unsigned long long epoch = 0; const void* data = nullptr; size_t n = 0; };
+  std::vector<Held> held;
+  unsigned long long edges_copied = 0, edges_skipped = 0;   // statistics of the copy-back (tests, bench)
+  void invalidate_lists() { held.assign(held.size(), Held()); }
   int nn_method = MVICP_NN_AUTO;
   const void* frames_key = nullptr;
   // what the device copy was built from: per frame {Frame*, pts data, size, nor data, normals version}; any difference

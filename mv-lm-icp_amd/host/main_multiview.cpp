@@ -8,7 +8,10 @@
 // write every Frame::neighbours[j] as corr_<src>_<j>.txt: a header line `dst weight count`, then `first second dist` rows),
 // --check_nn N (re-ask Frame::getClosestPoint for the first N correspondences of every edge and report disagreements),
 // --trace FILE (every round: one line `C round src j dst count weight-bits` per edge after the search and one line `P round frame m00 .. m33`
-// (4x4 row-major, 17 digits) per frame after the solve: the run's whole trajectory, for parity tests against a recorded one).
+// (4x4 row-major, 17 digits) per frame after the solve: the run's whole trajectory, for parity tests against a recorded one),
+// --freeze_from R (rounds >= R search but do not solve: the poses stay bit-identical), --perturb_frame K --perturb_round R (before round R's search
+// frame K's translation moves by 1e-4 m), --copy_stats (one line `copyback: round r copied X skipped Y` per round): the copy-back bookkeeping of
+// host/frame.h under test; --dump_corr also writes the poses of the last search (search_pose_<i>.txt).
 #include <chrono>
 #include <cstring>
 #include <fstream>
@@ -54,7 +57,7 @@ int main(int argc, char** argv) {
   Session::get().device = F.i("device", 0);
   Session::get().copy_back = F.b("copyback", true);
   Session::get().copy_threads = F.i("copy_threads", 8);
-  noiseStream() = F.s("noise_stream", "libstdc++") == "libc++" ? 1 : 0;
+  noiseStream() = F.s("noise_stream", "libstdc++") == "libc++" ? 1 : F.s("noise_stream", "libstdc++") == "g++" ? 2 : 0;
 
   std::vector<std::shared_ptr<Frame>> frames;
   loadFrames(F, frames, dir);
@@ -75,6 +78,9 @@ int main(int argc, char** argv) {
   if (!F.s("trace", "").empty()) { trace.open(F.s("trace", "").c_str()); trace.precision(17); }
   try {
     for (int r = 0; r < rounds; ++r) {
+      if (r == F.i("perturb_round", -1) && F.i("perturb_frame", -1) >= 0 && F.i("perturb_frame", -1) < (int)frames.size())
+        frames[F.i("perturb_frame", -1)]->pose.m[12] += 1e-4;
+      const unsigned long long c0 = Session::get().edges_copied, s0 = Session::get().edges_skipped;
       const auto t0 = std::chrono::steady_clock::now();
       for (auto& f : frames) f->computeClosestPointsToNeighbours(&frames, cutoff);
       const auto t1 = std::chrono::steady_clock::now();
@@ -86,7 +92,10 @@ int main(int argc, char** argv) {
             std::memcpy(&bits, &e.weight, 4);
             trace << "C " << r << " " << i << " " << j << " " << e.neighbourIdx << " " << e.correspondances.size() << " " << bits << "\n";
           }
+      if (F.b("copy_stats", false))
+        std::cout << "copyback: round " << r << " copied " << Session::get().edges_copied - c0 << " skipped " << Session::get().edges_skipped - s0 << std::endl;
       if (r == rounds - 1 && !F.s("dump_corr", "").empty()) {
+        for (size_t i = 0; i < frames.size(); ++i) saveMatrix4d(F.s("dump_corr", "") + "/search_pose_" + std::to_string(i) + ".txt", frames[i]->pose);
         for (size_t i = 0; i < frames.size(); ++i)
           for (size_t j = 0; j < frames[i]->neighbours.size(); ++j) {
             const OutgoingEdge& e = frames[i]->neighbours[j];
@@ -124,7 +133,8 @@ int main(int argc, char** argv) {
           }
         std::cout << "getClosestPoint check: " << checked << " queries, " << bad << " mismatches (" << single << " also asked one by one)" << std::endl;
       }
-      if (sophusSE3) ICP_Ceres::ceresOptimizer_sophusSE3(frames, pointToPlane, robust);
+      if (F.i("freeze_from", 1 << 30) <= r) {}   // (search only: the poses stay bit-identical)
+      else if (sophusSE3) ICP_Ceres::ceresOptimizer_sophusSE3(frames, pointToPlane, robust);
       else if (angleAxis) ICP_Ceres::ceresOptimizer_ceresAngleAxis(frames, pointToPlane, robust);
       else ICP_Ceres::ceresOptimizer(frames, pointToPlane, robust);
       const auto t2 = std::chrono::steady_clock::now();

@@ -20,7 +20,7 @@ int main(int argc, char** argv) {
   Session::get().device = F.i("device", 0);
   std::vector<Vector3d> pts, nor;
   if (!loadXYZ(F.s("cloud", "../samples/Bunny_RealData/cloudXYZ_0.xyz"), pts, nor, !F.b("drop_phantom_row", false)) || pts.empty()) return 1;
-  noiseStream() = F.s("noise_stream", "libstdc++") == "libc++" ? 1 : 0;
+  noiseStream() = F.s("noise_stream", "libstdc++") == "libc++" ? 1 : F.s("noise_stream", "libstdc++") == "g++" ? 2 : 0;
   // main_pairwise.cpp:44-56: q = Rx(pi/4) Ry(1) Rz(-0.2), t = (.01,-.01,-.005), P = addNoise(Pclean, 0.1, 0.1)
   auto rot = [](int axis, double a) {
     Isometry3d R;

@@ -14,7 +14,7 @@ EDGE_BLOCK = 91
 SYMBOLS = [
     "mvicp_last_error", "mvicp_version", "mvicp_create", "mvicp_destroy", "mvicp_set_num_frames", "mvicp_set_frame",
     "mvicp_recompute_normals", "mvicp_set_graph", "mvicp_set_shard", "mvicp_edge_owner", "mvicp_comm_unique_id", "mvicp_comm_init", "mvicp_comm_nranks", "mvicp_comm_set_callback", "mvicp_correspond",
-    "mvicp_get_correspondences", "mvicp_map_correspondences", "mvicp_set_correspondences", "mvicp_nn_query", "mvicp_linearize", "mvicp_optimize",
+    "mvicp_get_correspondences", "mvicp_map_correspondences", "mvicp_correspondence_epochs", "mvicp_set_correspondences", "mvicp_nn_query", "mvicp_linearize", "mvicp_optimize",
     "mvicp_lm_solve", "mvicp_set_option", "mvicp_nn_census", "mvicp_nn_census_ex", "mvicp_reset_history", "mvicp_profile_enable", "mvicp_profile_reset", "mvicp_profile_get", "mvicp_profile_get_ex", "mvicp_stream", "mvicp_sync",
     "mvicp_closedform_point_to_point", "mvicp_closedform_point_to_plane",
 ]
@@ -65,6 +65,7 @@ def load_library(path=None):
     lib.mvicp_correspond.argtypes = [vp, dp, u8p, C.c_float, C.c_int, ip, fp]
     lib.mvicp_get_correspondences.argtypes = [vp, C.c_int, C.c_int, ip, ip, dp]
     lib.mvicp_map_correspondences.argtypes = [vp, C.POINTER(vp), C.POINTER(C.POINTER(C.c_longlong))]
+    lib.mvicp_correspondence_epochs.argtypes = [vp, C.POINTER(C.POINTER(C.c_ulonglong))]
     lib.mvicp_set_correspondences.argtypes = [vp, C.c_int, C.c_int, ip, ip, C.c_float]
     lib.mvicp_nn_query.argtypes = [vp, C.c_int, dp, C.c_int, C.c_int, ip, dp]
     lib.mvicp_linearize.argtypes = [vp, dp, C.c_int, C.c_int, dp]
@@ -203,6 +204,13 @@ class Engine:
             _check(self.lib, self.lib.mvicp_set_frame(self.h, i, _dp(p), _dp(n) if n is not None else None, len(p)))
             self.npts.append(len(p))
 
+    def set_frame(self, frame, pts, nor=None):
+        """Re-upload ONE cloud (before set_graph): mvicp_set_frame."""
+        p = np.ascontiguousarray(pts, dtype=np.float64)
+        n = None if nor is None else np.ascontiguousarray(nor, dtype=np.float64)
+        _check(self.lib, self.lib.mvicp_set_frame(self.h, frame, _dp(p), _dp(n) if n is not None else None, len(p)))
+        self.npts[frame] = len(p)
+
     def recompute_normals(self, frame, k=10, want_knn=False):
         n = self.npts[frame]
         nrm = np.zeros((n, 3), dtype=np.float64)
@@ -311,6 +319,12 @@ class Engine:
         buf = (C.c_char * (16 * total)).from_address(tp.value)
         t = np.frombuffer(buf, dtype=self.CORR_DTYPE, count=total)
         return (t.copy() if copy else t), off
+
+    def correspondence_epochs(self):
+        """Per-edge change counters of the lists (mvicp_correspondence_epochs): an edge whose list is provably last search's keeps its epoch."""
+        ep = C.POINTER(C.c_ulonglong)()
+        _check(self.lib, self.lib.mvicp_correspondence_epochs(self.h, C.byref(ep)))
+        return np.ctypeslib.as_array(ep, shape=(self.E,)).copy()
 
     def set_correspondences(self, edge, first, second, weight=0.0):
         first = np.ascontiguousarray(first, dtype=np.int32)

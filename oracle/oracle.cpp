@@ -693,9 +693,12 @@ void orc_optimize(const orc_problem* p, double* poses, int max_iterations, orc_s
 
 // common.h:36-67 addNoise: file-scope DEFAULT-SEEDED std::mt19937 + std::normal_distribution<double>(0,1) (a fresh
 // distribution object per call, so no cached second variate survives a call); draw order w (3) then t (3);
-// noisyPose = pose * Exp(sigma w), translation += sigmat t.  The reference is built with libstdc++ (README targets
-// Ubuntu/g++), whose mt19937 is the standard-mandated sequence and whose normal_distribution is the Marsaglia polar
-// method: compiled here with the same g++ <random>, this IS the reference's pose noise.  reset != 0 re-seeds the generator to
+// noisyPose = pose * Exp(sigma w), translation += sigmat t.  stdlib = 0 uses this build's libstdc++ <random> (mt19937 is the
+// standard-mandated sequence, normal_distribution the Marsaglia polar method) and fills w and t LEFT TO RIGHT.  That is NOT
+// pinned as "the reference's noise on Ubuntu/g++": the reference draws the three variates as constructor ARGUMENTS
+// (`Vector3d w(normal(g), normal(g), normal(g))`, common.h:43,52), whose evaluation order is unspecified — g++ usually evaluates
+// right to left, so there w = (z2, z1, z0), t = (z5, z4, z3) (the host driver's `--noise_stream g++` models that order).
+// Only the clang / libc++ stream below (left to right, libc++'s variate order) is pinned — by the README vector.  reset != 0 re-seeds the generator to
 // its default state first (= a fresh process: main_pairwise.cpp calls addNoise exactly once, main_multiview.cpp once per
 // non-first frame in file order).
 //

@@ -92,6 +92,44 @@ def test_correspondence_copy_back_through_frame_api(tmp_path):
     eng.close()
 
 
+def test_copy_back_skips_unchanged_lists_and_refills_changed_ones(tmp_path):
+    """the Frame mirror refills `neighbours[j].correspondances` only when the library's list changed (mvicp_correspondence_epochs).
+    Driver run: round 0 search + solve, rounds 1.. search only (--freeze_from 1: bit-identical poses from round 2 on), before round 3 frame 2 moves.
+    Copy statistics per round, and after the last round EVERY list (refilled or kept) equals a fresh engine's at the driver's last poses."""
+    pb = synth.make_problem(4, 2500)
+    d = tmp_path / "data"; o = tmp_path / "out"
+    d.mkdir(); o.mkdir()
+    write_dataset(str(d), pb)
+    out = subprocess.check_output([os.path.join(BIN, "multiview"), "--dir", str(d), "--out", str(o), "--step", "1", "--rounds", "4", "--quiet", "--copyback", "--copy_stats",
+                                   "--norecomputeNormals", "--drop_phantom_row", "--freeze_from", "1", "--perturb_frame", "2", "--perturb_round", "3",
+                                   "--dump_corr", str(o)]).decode()
+    stats = {int(r): (int(c), int(s)) for r, c, s in re.findall(r"copyback: round (\d+) copied (\d+) skipped (\d+)", out)}
+    src, dst = synth.pose_graph_knn(pb["init"], 2, skip_fixed0=False)
+    searched = [e for e in range(len(src)) if src[e] != 0]          # frame 0 is fixed: never searched, never filled (frame.cpp:93)
+    touched = [e for e in searched if src[e] == 2 or dst[e] == 2]
+    assert stats[0] == (len(searched), 0) and stats[1] == (len(searched), 0), stats   # round 1: the solve moved the poses
+    assert stats[2] == (0, len(searched)), stats                                        # identical poses: nothing is re-copied
+    assert stats[3] == (len(touched), len(searched) - len(touched)) and 0 < len(touched) < len(searched), stats
+    P = np.array([np.loadtxt(os.path.join(str(o), f"search_pose_{i}.txt")) for i in range(4)])
+    eng = mvicp.Engine(0)
+    eng.set_frames(pb["pts"], pb["nor"]); eng.set_graph(src, dst)
+    counts, weights = eng.correspond(P, pb["fixed"], 0.05)
+    e = 0
+    for i in range(4):
+        for j in range(2):
+            path = os.path.join(str(o), f"corr_{i}_{j}.txt")
+            with open(path) as f:
+                hdr = f.readline().split()
+            if i != 0:
+                rows = np.loadtxt(path, skiprows=1).reshape(-1, 3)
+                gf, gs, gd = eng.get_correspondences(e)
+                assert int(hdr[2]) == counts[e] == len(rows)
+                assert np.array_equal(rows[:, 0].astype(np.int32), gf) and np.array_equal(rows[:, 1].astype(np.int32), gs) and np.array_equal(rows[:, 2], gd), (i, j)
+                assert np.float32(hdr[1]) == weights[e]
+            e += 1
+    eng.close()
+
+
 def test_multiview_driver_default_flags_recompute_normals(tmp_path):
     """Reference defaults (recomputeNormals on): the driver's PCA normals + loop equal the engine's."""
     pb = synth.make_problem(4, 3000)

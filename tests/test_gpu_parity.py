@@ -397,6 +397,94 @@ def test_recompute_normals_after_correspond_regathers(eng):
     assert np.array_equal(eng.linearize(pb["init"], 1, 1), want)
 
 
+def test_lists_survive_recompute_normals_and_epochs_track_changes(eng, orc):
+    """correspond -> recompute_normals -> get / map_correspondences used to fail ('export of edge holds 0 triples') because the export
+    keyed on list_valid, which recompute_normals clears.  The lists of the last search are still on the device: they must come back, equal to
+    the oracle's.  And mvicp_correspondence_epochs: an edge keeps its epoch exactly when its list is provably the same (bit-identical poses,
+    same cutoff); the mapped buffer then stays valid without device work, and still holds the right triples."""
+    pb = synth.make_problem(4, 3000)
+    eng.set_frames(pb["pts"], pb["nor"]); eng.set_graph(pb["src"], pb["dst"])
+    E = eng.E
+
+    def check_lists(P, cutoff=0.05):
+        t, off = eng.map_correspondences()
+        for e, (s_, d_) in enumerate(zip(pb["src"], pb["dst"])):
+            f, sec, dist, w, _, _ = orc.correspond_edge(pb["pts"][s_], P[s_], pb["pts"][d_], P[d_], cutoff)
+            seg = t[off[e]:off[e + 1]]
+            assert np.array_equal(seg["first"], f) and np.array_equal(seg["second"], sec) and np.array_equal(seg["dist"], dist), e
+            gf, gs, gd = eng.get_correspondences(e)
+            assert np.array_equal(gf, f) and np.array_equal(gs, sec) and np.array_equal(gd, dist), e
+
+    P = pb["init"].copy()
+    eng.correspond(P, pb["fixed"], 0.05)
+    ep0 = eng.correspondence_epochs()
+    assert len(set(ep0.tolist())) == E and (ep0 > 0).all()
+    for i in range(4):
+        eng.recompute_normals(i, 10)
+    check_lists(P)                                            # (export BEFORE any get: the failing sequence of ADVICE r5)
+    assert np.array_equal(eng.correspondence_epochs(), ep0)   # normals do not touch the triples
+    # identical poses: every list is provably the same -> epochs kept, lists still right (whatever kernel AUTO picks; three rounds cross its regimes)
+    for _ in range(3):
+        eng.correspond(P, pb["fixed"], 0.05)
+        assert np.array_equal(eng.correspondence_epochs(), ep0)
+        check_lists(P)
+    # one frame moves: exactly the edges that touch it get new epochs
+    P2 = P.copy(); P2[3, 0, 3] += 1e-4
+    eng.correspond(P2, pb["fixed"], 0.05)
+    ep1 = eng.correspondence_epochs()
+    touched = np.array([(s_ == 3 or d_ == 3) for s_, d_ in zip(pb["src"], pb["dst"])])
+    assert touched.any() and not touched.all()
+    assert (ep1[touched] > ep0.max()).all() and np.array_equal(ep1[~touched], ep0[~touched])
+    check_lists(P2)
+    # a different cutoff changes every list's inputs; so does reset_history and an explicit list
+    eng.correspond(P2, pb["fixed"], 0.04)
+    ep2 = eng.correspondence_epochs()
+    assert (ep2 > ep1.max()).all()
+    check_lists(P2, 0.04)
+    eng.reset_history()
+    eng.correspond(P2, pb["fixed"], 0.04)
+    ep3 = eng.correspondence_epochs()
+    assert (ep3 > ep2.max()).all()
+    check_lists(P2, 0.04)
+    f0, s0, _ = eng.get_correspondences(0)
+    eng.set_correspondences(0, f0[:10], s0[:10], 0.01)
+    ep4 = eng.correspondence_epochs()
+    assert ep4[0] > ep3.max() and np.array_equal(ep4[1:], ep3[1:])
+    eng.correspond(P2, pb["fixed"], 0.04)                      # the search replaces the explicit list: a new epoch again, the others stay
+    ep5 = eng.correspondence_epochs()
+    assert ep5[0] > ep4[0] and np.array_equal(ep5[1:], ep3[1:])
+    check_lists(P2, 0.04)
+
+
+def test_failed_structure_build_is_sticky_and_never_a_silent_brute_force(eng, orc):
+    """a failed background build used to be reported once and forgotten — a retried mvicp_set_graph succeeded and every edge touching
+    that frame silently fell back to the O(N^2) brute-force kernel.  Now the frame stays failed (with its message) until it is uploaded again."""
+    pb = synth.make_problem(3, 2000)
+    for async_build in (1, 0):
+        eng.set_option("async_build", async_build)
+        eng.set_option("fault_inject_build", 2)                    # the second build from now fails
+        if async_build:
+            eng.set_frames(pb["pts"], pb["nor"])                   # (the upload returns; the failure surfaces at the first call that needs the structures)
+        else:
+            with pytest.raises(mvicp.MvicpError, match="injected structure-build failure"):
+                eng.set_frames(pb["pts"], pb["nor"])
+            eng.npts = [len(p) for p in pb["pts"]]
+            eng.set_frame(2, pb["pts"][2], pb["nor"][2])           # (the loop stopped at frame 1: finish the upload)
+        for _ in range(2):                                         # sticky: the retry fails the same way
+            with pytest.raises(mvicp.MvicpError, match="frame 1: injected structure-build failure"):
+                eng.set_graph(pb["src"], pb["dst"])
+        with pytest.raises(mvicp.MvicpError, match="frame 1"):
+            eng.nn_query(0, pb["pts"][0][:8])
+        eng.set_frame(1, pb["pts"][1], pb["nor"][1])               # a new upload of that slot clears it
+        eng.set_graph(pb["src"], pb["dst"])
+        counts, weights = eng.correspond(pb["init"], pb["fixed"], 0.05)
+        for e, (s_, d_) in enumerate(zip(pb["src"], pb["dst"])):
+            f, sec, dist, w, _, _ = orc.correspond_edge(pb["pts"][s_], pb["init"][s_], pb["pts"][d_], pb["init"][d_], 0.05)
+            gf, gs, gd = eng.get_correspondences(e)
+            assert np.array_equal(gf, f) and np.array_equal(gs, sec) and np.array_equal(gd, dist) and weights[e] == w
+    eng.set_option("async_build", 1)
+
+
 def test_fixed_source_edges_are_excluded_from_the_solve(eng, orc):
     """ADVICE r1 / icp-ceres.cpp:255,351,426: correspond() with NO fixed mask fills the edges out of frame 0 too; the solve
     (which forces fixed[0]) must ignore them like the reference does."""
