@@ -229,6 +229,32 @@ void Frame::recomputeNormals() {
   ++version;   // a bound session re-uploads this cloud (new normals) at its next bind
 }
 
+const std::vector<int>& Frame::getNeighbourIndices(size_t num_results) {
+  if (pts.empty()) throw std::runtime_error("mvicp: getNeighbours on an empty cloud (nanoflann throws here: nanoflann.hpp:904)");
+  if (num_results < 3 || num_results > 16 || num_results > pts.size())
+    throw std::runtime_error("mvicp: getNeighbours supports 3 <= num_results <= 16 (and <= the cloud's size); the reference asks for 10 (frame.cpp:249)");
+  if (knn_k_ == num_results && knn_pts_ == (const void*)pts[0].data() && knn_n_ == pts.size()) return knn_table_;
+  mvicp_ctx* c = nullptr;
+  check(mvicp_create(Session::get().device, &c));
+  std::vector<int> table(pts.size() * num_results);
+  int st = mvicp_set_num_frames(c, 1);
+  if (st == MVICP_OK) st = mvicp_set_frame(c, 0, pts[0].data(), nullptr, (int)pts.size());
+  if (st == MVICP_OK) st = mvicp_recompute_normals(c, 0, (int)num_results, nullptr, table.data());
+  mvicp_destroy(c);
+  check(st);
+  knn_table_.swap(table); knn_k_ = num_results; knn_pts_ = (const void*)pts[0].data(); knn_n_ = pts.size();
+  return knn_table_;
+}
+
+std::vector<Vector3d> Frame::getNeighbours(int queryIdx, size_t num_results) {
+  if (queryIdx < 0 || (size_t)queryIdx >= pts.size()) throw std::runtime_error("mvicp: getNeighbours: queryIdx out of range");
+  const std::vector<int>& t = getNeighbourIndices(num_results);
+  std::vector<Vector3d> out;
+  out.reserve(num_results);
+  for (size_t i = 0; i < num_results; ++i) out.push_back(pts[t[(size_t)queryIdx * num_results + i]]);   // frame.cpp:222-226
+  return out;
+}
+
 mvicp_ctx* Session::query_context(Frame* f, int* slot) {
   // frame.cpp:187-206.  The reference builds the frame's KD-tree lazily on first use; here the frame's structure already lives in the
   // bound session (uploaded by computeClosestPointsToNeighbours / ceresOptimizer*), found by frame index.  A frame that is not part

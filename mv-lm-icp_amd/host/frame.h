@@ -49,6 +49,16 @@ class Frame {
   std::vector<double> getClosestPoints(const std::vector<Vector3d>& query_pts, std::vector<size_t>& ret_index);
   // frame.cpp:244-255: PCA normals from the 10 nearest points (self included), n_z <= 0; overwrites `nor`
   void recomputeNormals();
+  // frame.cpp:208-231: the num_results nearest points of pts[queryIdx] in this cloud — the point itself first — in the order nanoflann's
+  // knnSearch returns them (ascending distance, exact ties in the tree's visiting order).  The reference runs one tree query per call; here the
+  // first call for a given num_results answers ALL points of the cloud in one device launch (the k-NN kernel behind recomputeNormals, 3 <= k <= 16)
+  // and keeps the index table with the frame, so a loop over queryIdx — the reference's only use, frame.cpp:249 — costs one launch.
+  std::vector<Vector3d> getNeighbours(int queryIdx, size_t num_results);
+  // the table behind it: pts.size() x num_results original indices, row i = the neighbours of pts[i], nearest (i itself) first
+  const std::vector<int>& getNeighbourIndices(size_t num_results);
+
+ private:
+  std::vector<int> knn_table_; size_t knn_k_ = 0; const void* knn_pts_ = nullptr; size_t knn_n_ = 0;   // cache of getNeighbourIndices
 };
 
 // Process-wide device session behind the Frame / ICP_Ceres calls: uploads the (static) clouds once, mirrors the

@@ -11,7 +11,8 @@
 // (4x4 row-major, 17 digits) per frame after the solve: the run's whole trajectory, for parity tests against a recorded one),
 // --freeze_from R (rounds >= R search but do not solve: the poses stay bit-identical), --perturb_frame K --perturb_round R (before round R's search
 // frame K's translation moves by 1e-4 m), --copy_stats (one line `copyback: round r copied X skipped Y` per round): the copy-back bookkeeping of
-// host/frame.h under test; --dump_corr also writes the poses of the last search (search_pose_<i>.txt).
+// host/frame.h under test; --dump_corr also writes the poses of the last search (search_pose_<i>.txt); --dump_knn FILE [--knn_k 10]: Frame::getNeighbours
+// (frame.cpp:208-231) of EVERY point of frame 0, asked one by one like frame.cpp:249, as raw doubles (n x k x 3), then exit.
 #include <chrono>
 #include <cstring>
 #include <fstream>
@@ -62,6 +63,17 @@ int main(int argc, char** argv) {
   std::vector<std::shared_ptr<Frame>> frames;
   loadFrames(F, frames, dir);
   if (frames.empty()) { std::cerr << "no frames loaded from " << dir << std::endl; return 1; }
+  if (!F.s("dump_knn", "").empty()) {
+    try {
+      const size_t k = (size_t)F.i("knn_k", 10);
+      std::ofstream f(F.s("dump_knn", "").c_str(), std::ios::binary);
+      for (int i = 0; i < (int)frames[0]->pts.size(); ++i) {
+        const std::vector<Vector3d> nb = frames[0]->getNeighbours(i, k);
+        for (const Vector3d& p : nb) f.write(reinterpret_cast<const char*>(p.data()), 24);
+      }
+    } catch (const std::exception& ex) { std::cerr << ex.what() << std::endl; return 2; }
+    return 0;
+  }
   frames[0]->fixed = true;
   for (int i = 0; i < (int)frames.size(); ++i) frames[i]->computePoseNeighboursKnn(&frames, i, knn);
   if (!quiet) {

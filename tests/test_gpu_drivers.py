@@ -130,6 +130,40 @@ def test_copy_back_skips_unchanged_lists_and_refills_changed_ones(tmp_path):
     eng.close()
 
 
+@pytest.mark.parametrize("k", [10, 5])
+def test_frame_get_neighbours_equals_nanoflann_knnsearch(tmp_path, k):
+    """Frame::getNeighbours(int queryIdx, size_t num_results) (include/frame.h:48, src/internal/frame.cpp:208-231; VERDICT r5 item 5b) through the host
+    mirror, asked point by point like frame.cpp:249, on EVERY row of the reference's cloudXYZ_0.xyz: the returned points equal
+    pts[knnSearch indices] of the REAL nanoflann (golden tests/golden/bunny_knn_full.npz, generated from /root/reference/include/nanoflann.hpp) element for
+    element — including the 1185 points whose 10th place is an exact distance tie on this lattice-like scan (tie order = the tree's visiting order).
+    k = 5: a 5-list is the head of the 10-list wherever no exact tie spans the 5th place; those rows are compared."""
+    K = np.load(os.path.join(ROOT, "tests", "golden", "pairwise_kat.npz"))
+    G = np.load(os.path.join(ROOT, "tests", "golden", "bunny_knn_full.npz"))
+    pts = K["pts"]
+    d = tmp_path / "data"; d.mkdir()
+    np.savetxt(str(d / "cloud_0.xyz"), np.hstack([pts, K["nor"]]), fmt="%.17g")
+    np.savetxt(str(d / "pose_0.txt"), np.eye(4))
+    out = tmp_path / "knn.bin"
+    subprocess.check_call([os.path.join(BIN, "multiview"), "--dir", str(d), "--step", "1", "--norecomputeNormals", "--drop_phantom_row", "--quiet",
+                           "--dump_knn", str(out), "--knn_k", str(k)])
+    got = np.fromfile(str(out), dtype=np.float64).reshape(len(pts), k, 3)
+    want = pts[G["knn_idx"][:, :k]]
+    if k == 10:
+        assert G["tie_at_k"].sum() > 1000
+        assert np.array_equal(got, want)
+    else:
+        e = pts[:, None, :] - pts[G["knn_idx"]]
+        d2 = e[..., 0] * e[..., 0] + e[..., 1] * e[..., 1] + e[..., 2] * e[..., 2]     # frame.h:70-76, left to right, no FMA
+        clean = d2[:, k - 1] < d2[:, k]                      # no exact tie across the k-th place: the first k of the 10-list ARE the k-list
+        assert clean.sum() > 0.8 * len(pts)
+        assert np.array_equal(got[clean], want[clean])
+        assert np.array_equal(got[:, 0], pts)                 # self first, always
+    # out-of-range requests are errors, not garbage
+    r = subprocess.run([os.path.join(BIN, "multiview"), "--dir", str(d), "--step", "1", "--norecomputeNormals", "--quiet", "--dump_knn", str(out), "--knn_k", "40"],
+                       capture_output=True, text=True)
+    assert r.returncode == 2 and "3 <= num_results <= 16" in r.stderr
+
+
 def test_multiview_driver_default_flags_recompute_normals(tmp_path):
     """Reference defaults (recomputeNormals on): the driver's PCA normals + loop equal the engine's."""
     pb = synth.make_problem(4, 3000)

@@ -43,6 +43,40 @@ def assert_edge_equal(eng, e, counts, weights, want, tag):
     assert weights[e].tobytes() == np.float32(w).tobytes(), (tag, e, weights[e], w)
 
 
+# ------------------------------------------------------------------------------------------------ cfg2: 2 x 100k, pairwise point-to-plane
+@pytest.mark.parametrize("param,oparam", [(L.PARAM_SOPHUS_SE3, orclib.PARAM_SOPHUS), (L.PARAM_ANGLE_AXIS, orclib.PARAM_ANGLEAXIS)])
+def test_cfg2_full_size_vs_nanoflann_and_oracle_lm(orc, refnn, param, oparam):
+    """BASELINE config 2 (pairwise point-to-plane, 2 synthetic clouds x 100 000 points, E = 1) at full size against the ORACLE (VERDICT r5 item 5a:
+    test_full_size_properties_cfg2 only compares HIP kernels with each other).  Three ICP rounds, GPU and CPU path each on its own trajectory: the
+    edge's triples / count / float weight vs the real nanoflann at the GPU's poses (bit-exact), every LM solve vs the oracle LM on the CPU path's
+    list (same iterations / termination; poses <= 1e-9 after the first solve, <= 1e-8 after)."""
+    assert refnn is not None, "oracle/_ref/libref_nanoflann.so missing (built by oracle/Makefile where /root/reference exists)"
+    pb = synth.make_problem(2, 100_000)
+    assert len(pb["src"]) == 1 and (pb["src"][0], pb["dst"][0]) == (1, 0)          # knn capped by K - 1; frame 0 never searches (frame.cpp:93)
+    eng = mvicp.Engine(0)
+    eng.set_frames(pb["pts"], pb["nor"]); eng.set_graph(pb["src"], pb["dst"])
+    poses_g = pb["init"].copy()
+    poses_o = pb["init"].copy()
+    for rnd in range(3):
+        counts, weights = eng.correspond(poses_g, pb["fixed"], CUTOFF)
+        want_g = reference_edge(orc, refnn, pb["pts"][1], poses_g[1], pb["pts"][0], poses_g[0])
+        assert_edge_equal(eng, 0, counts, weights, want_g, f"cfg2 round {rnd}")
+        assert counts[0] > 90_000
+        want_o = want_g if np.array_equal(poses_g, poses_o) else reference_edge(orc, refnn, pb["pts"][1], poses_o[1], pb["pts"][0], poses_o[0])
+        poses_g, sm = eng.optimize(poses_g, pb["fixed"], param, 1, True, 50)
+        prob = orc.make_problem(pb["pts"], pb["nor"], pb["fixed"], pb["src"], pb["dst"], [want_o[:2]], [want_o[3]], oparam, 1, 1)
+        poses_o, sm_o = orc.optimize(prob, poses_o, 50)
+        assert sm["iterations"] == sm_o["iterations"] and sm["termination"] == sm_o["termination"], (rnd, sm, sm_o)
+        tol = 1e-9 if rnd == 0 else 1e-8
+        for k in range(2):
+            dt, dr = synth.pose_diff(poses_g[k], poses_o[k])
+            assert dt < tol and dr < tol, (rnd, k, dt, dr)
+    e0 = synth.pose_diff(pb["init"][1], pb["gt"][1])[0]
+    e1 = synth.pose_diff(poses_g[1], pb["gt"][1])[0]
+    assert e1 < 0.2 * e0, (e0, e1)                                                  # a pair with full overlap converges fast
+    eng.close()
+
+
 # ------------------------------------------------------------------------------------------------ cfg3: 8 x 100k, angle-axis
 def test_cfg3_full_size_vs_nanoflann_and_oracle_lm(orc, refnn):
     """BASELINE config 3 (8 views x 100 000 points, E = 14, point-to-plane, angle-axis) at full size, two ICP rounds:
