@@ -883,6 +883,9 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
     for (int e = 0; e < E; ++e) if (c->active[e] && !same_edge[e]) all_same = false;
     if (nn_method == MVICP_NN_AUTO && method == MVICP_NN_GRID && !handed_over && c->tile_cache && c->tile_bounds >= 1 && c->nn_cache_valid &&
         c->nn_cache_enable && !c->nn_cell && !all_same) { method = MVICP_NN_TILE; tile_lb = true; tile_cached = true; handed_over = true; }
+    // experiment (round 6, "tile_cache" = 2): the cache prologue in EVERY tile round that follows a bounds-leaving one (with "tile_bounds" = 2: from
+    // round 3 on), not only after the hand-over — measures how early the temporal cache starts to hit (profiles/r06_tile_ab.txt)
+    if (method == MVICP_NN_TILE && !tile_cached && c->tile_cache >= 2 && tile_lb && c->nn_cache_valid && c->nn_cache_enable && !all_same) tile_cached = true;
   }
   {
     // an edge may keep last round's compacted list only if a kernel that checks every query's acceptance and patches changed
@@ -1277,10 +1280,12 @@ int mvicp_set_option(mvicp_ctx* c, const char* name, double value) try {
   if (std::strcmp(name, "tile_mu") == 0) { if (!(value > 0.0 && value <= 1.0)) { set_error("tile_mu outside (0, 1]"); return MVICP_ERR_ARG; } c->tile_mu = value; return MVICP_OK; }
   if (std::strcmp(name, "mfma_kacc") == 0) { if (!(value >= 1.0 && value <= 1024.0)) { set_error("mfma_kacc outside [1, 1024]"); return MVICP_ERR_ARG; } c->mfma_kacc = value; return MVICP_OK; }
   if (std::strcmp(name, "mfma_lbt") == 0) { c->mfma_lbt = (int)value; return MVICP_OK; }
+  if (std::strcmp(name, "mfma_entry") == 0) { c->mfma_entry = (int)value; return MVICP_OK; }
   if (std::strcmp(name, "mfma_trig") == 0) { c->mfma_trig = (int)value; return MVICP_OK; }
   if (std::strcmp(name, "tile_mfma") == 0) { c->tile_mfma = (int)value; return MVICP_OK; }
   if (std::strcmp(name, "tile_waves") == 0) { c->tile_waves = (int)value; return MVICP_OK; }
-  if (std::strcmp(name, "tile_cache") == 0) { c->tile_cache = value != 0.0; return MVICP_OK; }
+  if (std::strcmp(name, "tile_miss") == 0) { if (!(value >= 0.0 && value <= 64.0)) { set_error("tile_miss outside [0, 64]"); return MVICP_ERR_ARG; } c->tile_miss = (int)value; return MVICP_OK; }
+  if (std::strcmp(name, "tile_cache") == 0) { c->tile_cache = (int)value; return MVICP_OK; }
   if (std::strcmp(name, "spin_wait") == 0) { c->spin_wait = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "fault_inject") == 0) { c->fault_inject = (int)value; return MVICP_OK; }            // tests: the value-th mvicp_correspond from now fails locally before its exchange
   if (std::strcmp(name, "fault_inject_build") == 0) { c->fault_inject_build.store((int)value); return MVICP_OK; }      // tests: the value-th structure build from now fails

@@ -250,14 +250,16 @@ struct mvicp_ctx {
   int tile_bounds = 1;             // 1: the AUTO round that would hand over to the grid kernel runs the tile kernel's BND build instead (it leaves the
                                    // temporal-cache bounds, so the grid kernel starts with cache hits one round later and the uncached grid round — the
                                    // slowest of a registration — never runs); 2: every tile round leaves bounds (tests); 0: off
-  bool tile_cache = true;          // AUTO, after the hand-over: rounds whose transforms still move run the tile kernel's bounds-leaving build WITH the
+  int tile_cache = 1;              // AUTO, after the hand-over: rounds whose transforms still move run the tile kernel's bounds-leaving build WITH the
                                    // temporal-cache check as its prologue (missed lanes are searched wave-cooperatively) instead of the grid kernel
+  int tile_miss = 8;               // cache-aware rounds: waves with at most this many missed lanes use nn_tile.hip's miss_block (0 = off)
   double tile_mu = 0.02;           // BND guard band as a fraction of the target's hash-cell edge (same role as prune_rho in the grid kernel); round 3 sweep on cfg4
                                    // (hand-over round + the two cache-aware rounds after it): 0.02 -> 2.06 ms, 0.05 -> 2.11, 0.1 -> 2.23, 0.2 -> 2.45
   int tile_mfma = 1;               // tile method: 1 = the screen of an opened tile runs on the matrix pipe (nn_mfma.hip) except in cache-aware rounds, 2 = always,
                                    // 0 = never (the fp32 VALU screen of nn_tile.hip)
   double mfma_kacc = 34.0;         // nn_mfma.hip: allowance for the fp32 accumulation inside one matrix instruction, in units of 2^-24 x sum |terms| (see tau_pieces)
   int mfma_lbt = 1;                // nn_mfma.hip: unseeded launches test every tile's box per lane before screening it (scan_block LBT)
+  int mfma_entry = 0;              // nn_mfma.hip experiment (round 6): seeded launches enter at the seeds' blocks + one flat sweep over the block boxes instead of the top-down walk
   int mfma_trig = 2;               // nn_mfma.hip: a lane with more than this many screen hits in a tile triggers the nearest-first second screen
   int tile_waves = 0;              // nn_tile_kernel variant: waves per SIMD it is compiled for (0 = the measured best for the depth)
   double auto_prev_dist = 0.0; int auto_last_method = -1; double auto_settle = 0.5;   // MVICP_NN_AUTO policy state (api.cpp)

@@ -419,7 +419,58 @@ __device__ void visit(const TileView& g, int first, int nchild, LaneM& L, const 
   }
 }
 
-template <int WPE, int TOP, bool BND, bool CEN, bool LBT>
+// ENTRY (round 6 experiment, option "mfma_entry"; seeded launches): instead of walking the hierarchy top-down, the wave ENTERS at the blocks its
+// seeds lie in (bpos >> 11: one scan_block per distinct seed block, typically 1-2) — after which every lane's threshold is as tight as its own
+// neighbourhood makes it — and then proves completeness with one flat sweep over the block boxes (level 1, 64 per coalesced load): a block is
+// scanned only if it passes the coarse cull against the patch AND some lane's own box test, in index order (no nearest-first pick: the
+// thresholds no longer depend on the order).  This is VERDICT r5's "block-adjacency list entered at the seed's block" with the list left
+// implicit: at the reference's default cutoff the kernels' search radius (4 x 0.05 m) spans the whole 0.2 m object, so "the blocks within
+// `search` of a block" are all blocks, and the one 64-wide test per 64 blocks is the sweep.  Same candidates as the walk (every block whose box
+// reaches some lane's ball is scanned), so the same results bit for bit.
+template <bool BND, bool CEN>
+__device__ void entry_walk(const TileView& g, LaneM& L, const GroupM& G, Census& C) {
+  const int lane = threadIdx.x & 63;
+  const float inf = __int_as_float(0x7f800000);
+  const int nblk = g.cnt[1], ntile = g.cnt[0];
+  const float sm = G.slack + G.mu;
+  unsigned int scanned = 0u;   // lane t, bit c: block 64 c + t was scanned
+  const int sb = (L.active && L.bpos >= 0) ? (L.bpos >> 11) : -1;
+  unsigned long long m = __ballot(sb >= 0);
+  while (m != 0ull) {
+    const int b = __builtin_amdgcn_readlane(sb, __ffsll((long long)m) - 1);
+    m &= ~__ballot(sb == b);
+    scan_block<BND, CEN, false>(g, b * FAN, min(FAN, ntile - b * FAN), L, G, C, G.kacc, G.trig, nullptr);
+    if (lane == (b & 63)) scanned |= 1u << (b >> 6);
+  }
+  float gmax = box_thr(wave_max_f(L.active ? L.rbest : 0.f), sm);
+  for (int c = 0; c * 64 < nblk; ++c) {
+    const int idx = c * 64 + lane;
+    float b0 = inf, b1 = inf, b2 = inf, b3 = -inf, b4 = -inf, b5 = -inf, ddf = inf;
+    if (idx < nblk) {
+      const float* base = g.wide + g.off[1] + idx;
+      const long long st = nblk;
+      b0 = base[0]; b1 = base[st]; b2 = base[2 * st]; b3 = base[3 * st]; b4 = base[4 * st]; b5 = base[5 * st];
+      const float e0 = fmaxf(fmaxf(b0 - G.hi[0], G.lo[0] - b3), 0.f);
+      const float e1 = fmaxf(fmaxf(b1 - G.hi[1], G.lo[1] - b4), 0.f);
+      const float e2 = fmaxf(fmaxf(b2 - G.hi[2], G.lo[2] - b5), 0.f);
+      ddf = (e0 * e0 + e1 * e1 + e2 * e2) * 0.999999f;
+    }
+    MV_CEN(C.box += (unsigned)min(64, nblk - c * 64));
+    unsigned long long pm = __ballot(idx < nblk && ((scanned >> c) & 1u) == 0u && ddf <= gmax);
+    while (pm != 0ull) {
+      const int t = __ffsll((long long)pm) - 1;
+      pm &= pm - 1ull;
+      if (!(bcast(ddf, t) <= gmax)) continue;
+      const float lb = box_lb32(L, bcast(b0, t), bcast(b1, t), bcast(b2, t), bcast(b3, t), bcast(b4, t), bcast(b5, t));
+      if (__ballot(L.active && lb <= box_thr(L.rbest, sm)) == 0ull) continue;
+      const int b = c * 64 + t;
+      scan_block<BND, CEN, false>(g, b * FAN, min(FAN, ntile - b * FAN), L, G, C, G.kacc, G.trig, nullptr);
+      gmax = box_thr(wave_max_f(L.active ? L.rbest : 0.f), sm);
+    }
+  }
+}
+
+template <int WPE, int TOP, bool BND, bool CEN, bool LBT, bool ENTRY = false>
 __global__ __launch_bounds__(MT, WPE) void nn_mfma_kernel(const TileJob* __restrict__ jobs, double bound, double search, unsigned long long* __restrict__ stats) {
   __shared__ float2 s_box[MT / 64][(LBT ? 3 : 2) * 3 * FAN];   // levels 1 and 2 (LBT: and the tiles of the current block): 64 child boxes x 24 B each, per wave
   __shared__ double sxf[kEdgeXf];
@@ -519,7 +570,8 @@ __global__ __launch_bounds__(MT, WPE) void nn_mfma_kernel(const TileJob* __restr
   Census C = {0u, 0u, 0u, 0u, 0u, 0u};
   const int top = g.levels - 1;
   float2* sbox = s_box[wave];
-  if (TOP >= 0) visit<(TOP >= 0 ? TOP : 0), BND, CEN, LBT>(g, 0, g.cnt[TOP >= 0 ? TOP : 0], L, G, sbox, C);
+  if (ENTRY && g.levels >= 2 && job.seed) entry_walk<BND, CEN>(g, L, G, C);
+  else if (TOP >= 0) visit<(TOP >= 0 ? TOP : 0), BND, CEN, LBT>(g, 0, g.cnt[TOP >= 0 ? TOP : 0], L, G, sbox, C);
   else switch (top) {
     case 0: visit<0, BND, CEN, LBT>(g, 0, g.cnt[0], L, G, sbox, C); break;
     case 1: visit<1, BND, CEN, LBT>(g, 0, g.cnt[1], L, G, sbox, C); break;
@@ -672,9 +724,12 @@ int launch_nn_mfma_edges(mvicp_ctx* c, double d2_bound, bool with_bounds, bool w
     if (unseeded && !with_bounds && top == 2 && !d_stats) MVICP_MFMA_L(5, 2, false, false, true);   // no seed anywhere: per-lane box test per tile (scan_block)
     else if (unseeded && !with_bounds && top == 2) MVICP_MFMA_L(5, 2, false, true, true);
     else if (with_bounds && with_cache && top == 2 && c->mfma_lbt >= 2 && !d_stats) MVICP_MFMA_L(5, 2, true, false, true);   // cache-aware round (tile_mfma = 2): most lanes sit out, so the per-lane box test prunes nearly every tile
+    else if (with_bounds && c->mfma_entry && !unseeded && !d_stats && top == 2) hipLaunchKernelGGL((nn_mfma_kernel<5, 2, true, false, false, true>), grid, dim3(MT), 0, c->stream, d_jobs, d2_bound, search_bound(c, d2_bound), d_stats);
     else if (with_bounds) {
       if (top == 2) MVICP_MFMA_K(5, 2, true); else MVICP_MFMA_K(5, -1, true);
     }
+    else if (c->mfma_entry && !unseeded && !d_stats && top == 2 && !with_bounds) hipLaunchKernelGGL((nn_mfma_kernel<5, 2, false, false, false, true>), grid, dim3(MT), 0, c->stream, d_jobs, d2_bound, search_bound(c, d2_bound), d_stats);
+    else if (c->mfma_entry && !unseeded && d_stats && top == 2 && !with_bounds) hipLaunchKernelGGL((nn_mfma_kernel<5, 2, false, true, false, true>), grid, dim3(MT), 0, c->stream, d_jobs, d2_bound, search_bound(c, d2_bound), d_stats);
     else if (top == 2 && waves == 6) MVICP_MFMA_K(6, 2, false);
     else if (top == 2 && waves == 4) MVICP_MFMA_K(4, 2, false);
     else if (top == 2) MVICP_MFMA_K(5, 2, false);

@@ -166,14 +166,105 @@ __device__ __forceinline__ void leaf_scan(const TileView& g, int leaf, Lane& L, 
   *n_cand += (unsigned)cnt;
 }
 
+// 64-bit wave broadcast (two v_readlane)
+__device__ __forceinline__ double bcast_d(double v, int lane) {
+  const long long b = __double_as_longlong(v);
+  const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
+  const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// MISS path (round 6; cache-aware rounds only).  After the temporal-cache prologue a wave is typically left with a handful of missed lanes
+// (cfg4 rounds 6 / 7: 6 % / 1 % of the queries).  The lanes-over-queries scan above then stages a whole tile in LDS and runs the packed screen
+// in all 64 lanes for the sake of one or two of them — ~440 VALU instructions and 900 B per opened tile whoever needs it.  Here the roles are
+// swapped: the missed queries are taken ONE BY ONE (their state broadcast into SGPRs) and the 64 lanes are spread over the DATA —
+//   * block level: lane t holds the box of the block's tile t and tests it against the query's ball (one ballot = the query's tile set);
+//   * tile level: two tiles per step, lane l evaluates point l & 31 of tile l >> 5 in the reference's fp64 arithmetic straight from the 32-B sorted
+//     records (one coalesced 2-KB load, no LDS staging, no fp32 screen); the few lanes that come within the running best update the scalar state
+//     by leaf_scan's own rules, one after the other.
+// BND's second-best is kept as a LOWER bound here (fp32, rounded down, of the points beyond the best) — all the temporal cache needs; exact ties
+// set the tie flag explicitly (the BND build's `second == best` test would miss one under a rounded-down second).  Results (index, d2) are
+// those of the scan above bit for bit: the same candidates — every point of every tile whose box reaches the query's ball — by the same rules.
+template <bool BND>
+__device__ void miss_block(const TileView& g, int first, int nchild, Lane& L, const Group& G, unsigned int* n_cand, unsigned int* n_box) {
+  const int lane = threadIdx.x & 63;
+  const float inf = __int_as_float(0x7f800000);
+  float b0 = inf, b1 = inf, b2 = inf, b3 = -inf, b4 = -inf, b5 = -inf;
+  if (lane < nchild) {
+    const float* base = g.wide + g.off[0] + first + lane;
+    const long long st = g.cnt[0];
+    b0 = base[0]; b1 = base[st]; b2 = base[2 * st]; b3 = base[3 * st]; b4 = base[4 * st]; b5 = base[5 * st];
+  }
+  *n_box += (unsigned)nchild;
+  unsigned long long am = __ballot(L.active);
+  while (am != 0ull) {
+    const int a = __ffsll((long long)am) - 1;
+    am &= am - 1ull;
+    const float qxf = bcast(L.qx2.x, a), qyf = bcast(L.qy2.x, a), qzf = bcast(L.qz2.x, a);
+    float thr = bcast(L.thr, a);
+    const float g0 = fmaxf(fmaxf(b0 - qxf, qxf - b3), 0.f);
+    const float g1 = fmaxf(fmaxf(b1 - qyf, qyf - b4), 0.f);
+    const float g2 = fmaxf(fmaxf(b2 - qzf, qzf - b5), 0.f);
+    const float lb = __builtin_fmaf(g2, g2, __builtin_fmaf(g1, g1, g0 * g0));   // box_lb32 of the broadcast query (same guard-band argument)
+    unsigned long long tm = __ballot(lane < nchild && lb <= thr);
+    if (tm == 0ull) continue;
+    const double qx = bcast_d(L.qx, a), qy = bcast_d(L.qy, a), qz = bcast_d(L.qz, a);
+    double best = bcast_d(L.best, a), second = bcast_d(L.second, a);
+    int bi = __builtin_amdgcn_readlane(L.bi, a);
+    bool tie = __builtin_amdgcn_readlane((int)L.tie, a) != 0;
+    bool changed = false;
+    while (tm != 0ull) {
+      const int t0 = __ffsll((long long)tm) - 1;
+      tm &= tm - 1ull;
+      int t1 = -1;
+      if (tm != 0ull) { t1 = __ffsll((long long)tm) - 1; tm &= tm - 1ull; }
+      const int t = lane < 32 ? t0 : t1;
+      const int k = (first + t) * LEAF + (lane & 31);
+      const bool valid = t >= 0 && k < g.n;
+      double2 u = make_double2(0.0, 0.0), v = make_double2(0.0, 0.0);
+      if (valid) {
+        const double2* pr = reinterpret_cast<const double2*>(g.srec + k);
+        u = pr[0]; v = pr[1];
+      }
+      const double d0 = __dsub_rn(qx, u.x), d1 = __dsub_rn(qy, u.y), d2 = __dsub_rn(qz, v.x);
+      const double d = __dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2));
+      const int oi = (int)__double_as_longlong(v.y);
+      *n_cand += (unsigned)(min(LEAF, g.n - (first + t0) * LEAF) + (t1 >= 0 ? min(LEAF, g.n - (first + t1) * LEAF) : 0));
+      unsigned long long pm = __ballot(valid && d <= best);
+      if (BND) {
+        // everything beyond the running best only lowers `second`: its fp32 floor is a valid (and nearly tight) lower bound
+        const float far32 = wave_min_f(valid && d > best ? __double2float_rd(d) : inf);
+        second = fmin(second, (double)far32);
+      }
+      while (pm != 0ull) {
+        const int j = __ffsll((long long)pm) - 1;
+        pm &= pm - 1ull;
+        const double dj = bcast_d(d, j);
+        const int oj = __builtin_amdgcn_readlane(oi, j);
+        if (dj < best) {
+          if (BND) second = fmin(second, best);
+          best = dj; bi = oj; changed = true;
+        } else if (dj == best) {
+          if (oj != bi) { if (BND) second = fmin(second, dj); tie = true; if (oj < bi) bi = oj; }
+        } else if (BND) {
+          second = fmin(second, dj);
+        }
+      }
+    }
+    if (changed) thr = fminf(thr, thr_of(best, G.slack + G.mu));
+    if (lane == a) { L.best = best; L.bi = bi; L.tie = tie; L.second = second; L.thr = thr; }
+  }
+}
+
 // Test the `nchild` boxes [first, first + nchild) of level LEVEL (one per lane) and open what is needed.
 // Register budget: the traversal recurses (level 2 -> 1 -> 0 -> tile scan) and everything a level keeps across the descent
 // is live in all deeper levels.  Levels 1 and 2 therefore park their 64 child boxes in wave-private LDS (32 B each, read
 // back with one uniform-address load per step) and keep only {cull distance, order key, pending} per lane; level 0, the
 // hot one, keeps its boxes in registers and broadcasts them with v_readlane.
-template <int LEVEL, bool BND>
+template <int LEVEL, bool BND, bool MISS>
 __device__ void visit(const TileView& g, int first, int nchild, Lane& L, const Group& G, TileLds* __restrict__ T,
                       float2* __restrict__ sbox, unsigned int* n_cand, unsigned int* n_box) {
+  if constexpr (LEVEL == 0 && MISS) { miss_block<BND>(g, first, nchild, L, G, n_cand, n_box); return; } else {
   constexpr bool IN_LDS = LEVEL == 1 || LEVEL == 2;
   const int lane = threadIdx.x & 63;
   const float inf = __int_as_float(0x7f800000);
@@ -234,9 +325,10 @@ __device__ void visit(const TileView& g, int first, int nchild, Lane& L, const G
       leaf_scan<BND>(g, child, L, G.slack, G.mu, T, n_cand);
     } else {
       const int cf = child * FAN;
-      visit<(LEVEL > 0 ? LEVEL - 1 : 0), BND>(g, cf, min(FAN, g.cnt[LEVEL > 0 ? LEVEL - 1 : 0] - cf), L, G, T, sbox, n_cand, n_box);
+      visit<(LEVEL > 0 ? LEVEL - 1 : 0), BND, MISS>(g, cf, min(FAN, g.cnt[LEVEL > 0 ? LEVEL - 1 : 0] - cf), L, G, T, sbox, n_cand, n_box);
     }
     gmax = wave_max_f(L.active ? L.thr : 0.f);
+  }
   }
 }
 
@@ -346,14 +438,23 @@ __global__ __launch_bounds__(TT, WPE) void nn_tile_kernel(const TileJob* __restr
   const int top = g.levels - 1;
   TileLds* T = &s_tile[wave];
   float2* sbox = s_box[wave];
-  if (TOP >= 0) visit<(TOP >= 0 ? TOP : 0), BND>(g, 0, g.cnt[TOP >= 0 ? TOP : 0], L, G, T, sbox, &n_cand, &n_box);
-  else switch (top) {
-    case 0: visit<0, BND>(g, 0, g.cnt[0], L, G, T, sbox, &n_cand, &n_box); break;
-    case 1: visit<1, BND>(g, 0, g.cnt[1], L, G, T, sbox, &n_cand, &n_box); break;
-    case 2: visit<2, BND>(g, 0, g.cnt[2], L, G, T, sbox, &n_cand, &n_box); break;
-    case 3: visit<3, BND>(g, 0, g.cnt[3], L, G, T, sbox, &n_cand, &n_box); break;
-    default: visit<4, BND>(g, 0, g.cnt[4], L, G, T, sbox, &n_cand, &n_box); break;
-  }
+  // cache-aware rounds: a wave left with at most job.miss_max missed lanes takes them one by one with the lanes spread over the data (miss_block)
+  const bool miss_path = BND && job.cache && job.miss_max > 0 && __popcll(__ballot(L.active)) <= job.miss_max;
+  unsigned int n_exam = 0;
+#define MVICP_VISIT(M)                                                                                                          \
+  do {                                                                                                                          \
+    if (TOP >= 0) visit<(TOP >= 0 ? TOP : 0), BND, M>(g, 0, g.cnt[TOP >= 0 ? TOP : 0], L, G, T, sbox, &n_cand, &n_box);           \
+    else switch (top) {                                                                                                         \
+      case 0: visit<0, BND, M>(g, 0, g.cnt[0], L, G, T, sbox, &n_cand, &n_box); break;                                            \
+      case 1: visit<1, BND, M>(g, 0, g.cnt[1], L, G, T, sbox, &n_cand, &n_box); break;                                            \
+      case 2: visit<2, BND, M>(g, 0, g.cnt[2], L, G, T, sbox, &n_cand, &n_box); break;                                            \
+      case 3: visit<3, BND, M>(g, 0, g.cnt[3], L, G, T, sbox, &n_cand, &n_box); break;                                            \
+      default: visit<4, BND, M>(g, 0, g.cnt[4], L, G, T, sbox, &n_cand, &n_box); break;                                           \
+    }                                                                                                                           \
+  } while (0)
+  if (BND && miss_path) { MVICP_VISIT(BND); n_exam = n_cand; }   // (MISS only exists in BND builds: the plain build never compiles it)
+  else MVICP_VISIT(false);
+#undef MVICP_VISIT
   if (L.active) {
     const int out = i;   // sorted order of the source cloud
     job.out_idx[out] = L.bi == 0x7fffffff ? -1 : (job.inv ? job.inv[L.bi] : L.bi);
@@ -365,13 +466,13 @@ __global__ __launch_bounds__(TT, WPE) void nn_tile_kernel(const TileJob* __restr
     // keeps its acceptance patches its own entry and operands, so compaction + gather only run for edges whose MEMBERSHIP changed —
     // also in the plain seeded rounds, where nearly every neighbour changes but hardly any acceptance does (round 3)
     if (job.list.dirty) update_list_entry(job.list, i, L.bi == 0x7fffffff ? -1 : job.inv[L.bi], L.best, bound, false);
-    if ((BND ? L.second == L.best : L.tie) && L.bi != 0x7fffffff) tie_report(job.tie, (unsigned int)i);
+    if ((BND ? (L.second == L.best || L.tie) : L.tie) && L.bi != 0x7fffffff) tie_report(job.tie, (unsigned int)i);   // (BND: L.tie is set by miss_block only)
   }
   if (stats && (threadIdx.x & 63) == 0) {
     // wave-uniform counters: candidates examined PER LANE x active lanes, boxes tested per wave
     const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (TT / 64) + wave;
     const unsigned long long act = (unsigned long long)min(64, job.n - (i & ~63));
-    stats[8 * slot] = n_cand; stats[8 * slot + 1] = n_box; stats[8 * slot + 2] = (unsigned long long)n_cand * act;
+    stats[8 * slot] = n_cand; stats[8 * slot + 1] = n_box; stats[8 * slot + 2] = miss_path ? (unsigned long long)n_exam : (unsigned long long)n_cand * act;
   }
   if (stats && BND && job.cache) {
     const unsigned long long hits = __popcll(__ballot(n_hit != 0u));

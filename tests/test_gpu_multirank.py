@@ -96,6 +96,57 @@ def test_partition_of_config4_and_config5_over_8_ranks():
         assert sizes.min() >= lo and sizes.max() <= hi and np.all(np.diff(own) >= 0), sizes
 
 
+# ---------------------------------------------------------------- regime transitions, sharded
+def _regime_worker(rank, world, port, out, seed, spec):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, "mv-lm-icp_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import mvicp
+    import regime_seq
+    from mvicp import synth
+
+    def allreduce(a):
+        t = torch.from_numpy(a)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+    pb = synth.make_problem(5, 3500, cone_deg=100.0 if seed % 2 == 0 else 45.0, pose_seed=800 + seed)
+    eng = mvicp.Engine(0, rank=rank, world=world)
+    eng.set_option("spec_eval", spec)
+    eng.set_frames(pb["pts"], pb["nor"]); eng.set_graph(pb["src"], pb["dst"])
+    eng.comm_set_callback(allreduce)
+    log = regime_seq.run(eng, pb, regime_seq.script(seed, 5))
+    eng.close()
+    regime_seq.save(f"{out}.{rank}.npz", log)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("seed,spec", [(0, 1), (1, 1), (2, 0), (3, 1)])
+def test_regime_transitions_sharded_match_single_process(tmp_path, seed, spec):
+    """mvicp_correspond's cross-round state (tie_skip / far_skip / spec_arm / bracket select / list reuse / AUTO policy) under a scripted
+    registration that changes the cutoff, the fixed mask, the kernel method and options, resets the history and repeats poses — on TWO ranks
+    sharing the edges (host-staged transport): after EVERY round each rank's counts, float weights and poses equal the single process's bit for
+    bit, with the queued first evaluation on (spec 1) and off (spec 0)."""
+    sys.path.insert(0, os.path.join(ROOT, "mv-lm-icp_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import mvicp
+    import regime_seq
+    from mvicp import synth
+    out = str(tmp_path / "regime")
+    mp.spawn(_regime_worker, args=(2, _free_port(), out, seed, spec), nprocs=2, join=True)
+    pb = synth.make_problem(5, 3500, cone_deg=100.0 if seed % 2 == 0 else 45.0, pose_seed=800 + seed)
+    eng = mvicp.Engine(0)
+    eng.set_option("spec_eval", spec)
+    eng.set_frames(pb["pts"], pb["nor"]); eng.set_graph(pb["src"], pb["dst"])
+    events = regime_seq.script(seed, 5)
+    log = regime_seq.run(eng, pb, events)
+    eng.close()
+    kinds = [e["kind"] for e in events]
+    assert len(set(kinds)) >= 4, kinds                                  # the script really mixes events
+    for r in range(2):
+        regime_seq.assert_equal(f"{out}.{r}.npz", log, (seed, spec, r, kinds))
+
+
 # ---------------------------------------------------------------- a rank that fails locally must not leave its peers in the collective
 def _fault_worker(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)

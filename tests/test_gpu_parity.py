@@ -1304,8 +1304,8 @@ def test_correspond_regime_transitions_match_a_fresh_context(orc, seed):
         elif ev == "method":
             method = int(rng.choice([L.NN_AUTO, L.NN_AUTO, L.NN_BRUTE, L.NN_GRID, L.NN_TILE]))
         elif ev == "option":
-            name = str(rng.choice(["list_reuse", "nn_cache", "sel_bracket", "spec_eval", "tile_cache", "tile_seed"]))
-            A.set_option(name, float(rng.integers(0, 2)))
+            name = str(rng.choice(["list_reuse", "nn_cache", "sel_bracket", "spec_eval", "tile_cache", "tile_seed", "tile_miss", "mfma_entry"]))
+            A.set_option(name, float(rng.integers(0, 2)) * (8.0 if name == "tile_miss" else 1.0))
             if rng.random() < 0.5:
                 A.set_option("tile_mfma", float(rng.integers(0, 3)))
         elif ev == "explicit":

@@ -10,7 +10,10 @@ from mvicp import lib as L, synth
 K, N, R = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 variants = sys.argv[4:] or [""]
 method = {"auto": L.NN_AUTO, "tile": L.NN_TILE}[os.environ.get("AB_METHOD", "auto")]
-pb = synth.make_problem(K, N)
+# AB_WORKLOAD=cfg4_partial: bench.py's partial-overlap variant (20-degree views, 5 mm cutoff) at the K, N given
+EXTRA = {"cfg4_partial": {"cone_deg": 20.0, "sigma": 0.004, "sigmat": 0.002, "cutoff": 0.005}}.get(os.environ.get("AB_WORKLOAD", ""), {})
+CUTOFF = EXTRA.pop("cutoff", 0.05)
+pb = synth.make_problem(K, N, **EXTRA)
 ref = None
 for v in variants:
     eng = mvicp.Engine(0)
@@ -23,16 +26,16 @@ for v in variants:
     poses = pb["init"].copy(); rows = []; trace = []
     for r in range(R):
         eng.profile_reset()
-        c, w = eng.correspond(poses, pb["fixed"], 0.05, method)
+        c, w = eng.correspond(poses, pb["fixed"], CUTOFF, method)
         ms = eng.profile_get("nn")[0]
         cs = eng.nn_census() if os.environ.get("AB_CENSUS") == "1" else None
         poses, sm = eng.optimize(poses, pb["fixed"], 2, 1, 1, 50)
         if cs is None:
             rows.append(round(ms, 3))
-        else:   # ms, candidates per query, [per wave: second screens, confirmation rounds, blocks], fp64 confirmations per query
-            w = max(cs["queries"], 1) / 64.0
-            rows.append((round(ms, 3), round(float(cs["candidates"] / max(cs["queries"], 1)), 1), round(float(cs["rescreens"] / w), 2), round(float(cs["confirm_rounds"] / w), 2),
-                         round(float(cs["blocks"] / w), 2), round(float(cs["confirmations"] / max(cs["queries"], 1)), 2)))
+        else:   # ms, candidates per query, [per wave: second screens, confirmation rounds, blocks], fp64 confirmations per query, temporal-cache hit fraction
+            wv = max(cs["queries"], 1) / 64.0
+            rows.append((round(ms, 3), round(float(cs["candidates"] / max(cs["queries"], 1)), 1), round(float(cs["rescreens"] / wv), 2), round(float(cs["confirm_rounds"] / wv), 2),
+                         round(float(cs["blocks"] / wv), 2), round(float(cs["confirmations"] / max(cs["queries"], 1)), 2), "hit %.3f" % float(cs["hits"] / max(cs["queries"], 1))))
         trace.append((c.copy(), w.copy(), poses.copy()))
     same = None
     if ref is None:
