@@ -47,7 +47,7 @@ WORKLOADS = {
 WORKLOAD_EXTRAS = {"cfg4_partial": {"cone_deg": 20.0, "sigma": 0.004, "sigmat": 0.002, "cutoff": 0.005}}
 ROUNDS_PER_REGISTRATION = 20   # main_multiview.cpp:150
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 
 def source_sha16():

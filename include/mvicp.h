@@ -128,6 +128,13 @@ int mvicp_get_correspondences(mvicp_ctx* ctx, int edge, int cap, int* first, int
  * first call after a search does the work, later calls (and mvicp_get_correspondences, which slices the same buffer) are free. */
 typedef struct mvicp_corr { int first; int second; double dist; } mvicp_corr;
 int mvicp_map_correspondences(mvicp_ctx* ctx, const mvicp_corr** triples, const long long** offsets);
+/* The same export WITHOUT waiting for it: the device pass is queued and the triples travel to the pinned buffer in chunks (one per run of edges with
+ * the same source frame, in edge order).  *triples / *offsets are valid at once (the offsets are known from the search's counts); the BYTES of edge e
+ * may be read after mvicp_wait_correspondences(ctx, e) returned — which waits for e's chunk only, so a caller that fills Frame::neighbours frame by
+ * frame (frame.cpp:91-185 is called once per frame, main_multiview.cpp:119-127) copies frame i while the lists of frames i + 1 .. are still on the
+ * bus.  Any later library call that waits for the stream (mvicp_map_correspondences, mvicp_get_correspondences, mvicp_optimize ...) completes it too. */
+int mvicp_map_correspondences_async(mvicp_ctx* ctx, const mvicp_corr** triples, const long long** offsets);
+int mvicp_wait_correspondences(mvicp_ctx* ctx, int edge);
 /* Per-edge change counters of the lists, for callers that keep their own copy (the Frame mirror's `neighbours[j].correspondances`,
  * frame.cpp:110,156-160: the reference clears and refills every list every round; a caller that holds edge e's list with epoch x may skip the
  * refill while (*epochs)[e] == x).  An edge keeps its epoch across an mvicp_correspond iff its list is PROVABLY last search's bit for bit — same

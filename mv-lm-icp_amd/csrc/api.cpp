@@ -153,7 +153,9 @@ void free_graph(mvicp_ctx* c) {
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   c->h_pin = nullptr; c->h_pin_doubles = 0; c->d_res_host = nullptr; c->d_blocks_host = nullptr; c->lin_out = nullptr;
   c->census_pending = false; c->spec_ready = false; c->spec_arm = false; c->d_spec_host = nullptr; c->d_adev_host = nullptr; c->d_res_target = nullptr; c->d_a_check = nullptr;
-  dev_free(c->d_xblock_cnt); c->export_valid = false;
+  dev_free(c->d_xblock_cnt); c->export_valid = false; c->export_in_flight = false; c->export_chunks = 0;
+  for (hipEvent_t ev : c->export_events) (void)hipEventDestroy(ev);
+  c->export_events.clear();
   if (c->d_export) (void)hipFree(c->d_export);
   if (c->h_export) (void)hipHostFree(c->h_export);
   c->d_export = nullptr; c->h_export = nullptr; c->export_cap = 0;
@@ -1100,13 +1102,17 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
 } MVICP_GUARD_ABI
 
 // every exportable edge's list of the last search, un-sorted on the device into the reference's layout and copied once (export.hip)
-static int ensure_export(mvicp_ctx* c) {
-  if (c->export_valid) return MVICP_OK;
-  HostScope hs(c, "host.export");
-  MV_CHECK(launch_export(c));
-  MV_CHECK(stream_wait(c));
-  c->export_valid = true;
-  if (c->profile) prof_collect(c);
+static int ensure_export(mvicp_ctx* c, bool wait = true) {
+  if (!c->export_valid) {
+    HostScope hs(c, "host.export");
+    MV_CHECK(launch_export(c));
+    c->export_valid = true;
+  }
+  if (wait && c->export_in_flight) {
+    MV_CHECK(stream_wait(c));
+    c->export_in_flight = false;
+    if (c->profile) prof_collect(c);
+  }
   return MVICP_OK;
 }
 
@@ -1117,6 +1123,27 @@ int mvicp_map_correspondences(mvicp_ctx* c, const mvicp_corr** triples, const lo
   MV_CHECK(ensure_export(c));
   *triples = (const mvicp_corr*)c->h_export;
   *offsets = c->export_off.data();
+  return MVICP_OK;
+} MVICP_GUARD_ABI
+
+int mvicp_map_correspondences_async(mvicp_ctx* c, const mvicp_corr** triples, const long long** offsets) try {
+  MV_CHECK(bind(c));
+  if (!triples || !offsets) { set_error("null output"); return MVICP_ERR_ARG; }
+  if (!c->have_corr) { set_error("no correspondences yet"); return MVICP_ERR_STATE; }
+  MV_CHECK(ensure_export(c, false));
+  *triples = (const mvicp_corr*)c->h_export;
+  *offsets = c->export_off.data();
+  return MVICP_OK;
+} MVICP_GUARD_ABI
+
+int mvicp_wait_correspondences(mvicp_ctx* c, int edge) try {
+  MV_CHECK(bind(c));
+  if (edge < 0 || edge >= c->E) { set_error("edge %d out of range", edge); return MVICP_ERR_ARG; }
+  if (!c->export_valid) { set_error("no export in flight: call mvicp_map_correspondences_async after the search"); return MVICP_ERR_STATE; }
+  if (!c->export_in_flight || c->export_chunks == 0) return MVICP_OK;
+  const int k = c->export_edge_chunk[edge];
+  MV_HIP(hipEventSynchronize(c->export_events[k]));
+  if (k == c->export_chunks - 1) c->export_in_flight = false;   // (the last chunk's event is behind every other one on the stream)
   return MVICP_OK;
 } MVICP_GUARD_ABI
 

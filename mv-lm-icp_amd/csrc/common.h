@@ -158,6 +158,9 @@ struct mvicp_ctx {
   int* d_xblock_cnt = nullptr;
   std::vector<long long> export_off; // E+1: edge e's triples = h_export[export_off[e] .. export_off[e + 1])
   bool export_valid = false;         // h_export holds the lists as they are on the device now
+  // the copy of the export into pinned memory goes in CHUNKS (one per run of edges with the same source frame), each followed by an event, so that a
+  // caller that fills its lists frame by frame (host/frame.cpp) slices frame i while frames i+1.. are still on the bus (mvicp_map_correspondences_async)
+  std::vector<hipEvent_t> export_events; std::vector<int> export_edge_chunk; int export_chunks = 0; bool export_in_flight = false;
   std::vector<char> qpos_valid;      // E: d_qpos / d_second / d_cd2 describe the LAST SEARCH's result of this edge (what the export reads).  Unlike list_valid
                                      // (= the list may be maintained in place next round) it survives mvicp_recompute_normals, which only re-gathers operands
   std::vector<unsigned long long> corr_epoch;   // E: changes whenever the edge's list (count, triples, weight) may differ from what it was (mvicp_correspondence_epochs)

@@ -153,6 +153,7 @@ int launch_export(mvicp_ctx* c) {
     c->export_off[e + 1] = c->export_off[e] + (ok ? c->h_count[e] : 0);
   }
   total = c->export_off[E];
+  c->export_chunks = 0; c->export_in_flight = false;
   if (total == 0 || c->n_cblocks == 0) return MVICP_OK;
   if ((size_t)total > c->export_cap) {
     MV_HIP(hipStreamSynchronize(c->stream));
@@ -187,7 +188,23 @@ int launch_export(mvicp_ctx* c) {
                        c->d_second, c->d_cd2, c->d_xblock_cnt, d_off, (Triple*)c->d_export);
   }
   MV_HIP(hipGetLastError());
-  MV_HIP(hipMemcpyAsync(c->h_export, c->d_export, (size_t)total * sizeof(Triple), hipMemcpyDeviceToHost, c->stream));
+  // device -> pinned host in chunks (runs of edges with one source frame), an event behind each: mvicp_wait_correspondences(edge) waits for the
+  // chunk that holds the edge only.  The chunks are queued back to back on the library's stream, so the bus never idles between them.
+  c->export_edge_chunk.assign(E, 0);
+  int chunks = 0;
+  for (int e = 0; e < E;) {
+    int e1 = e + 1;
+    while (e1 < E && c->esrc[e1] == c->esrc[e]) ++e1;
+    const long long a = c->export_off[e], b = c->export_off[e1];
+    for (int k = e; k < e1; ++k) c->export_edge_chunk[k] = chunks;
+    if ((int)c->export_events.size() <= chunks) { hipEvent_t ev = nullptr; MV_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); c->export_events.push_back(ev); }
+    if (b > a) MV_HIP(hipMemcpyAsync((Triple*)c->h_export + a, (const Triple*)c->d_export + a, (size_t)(b - a) * sizeof(Triple), hipMemcpyDeviceToHost, c->stream));
+    MV_HIP(hipEventRecord(c->export_events[chunks], c->stream));
+    ++chunks;
+    e = e1;
+  }
+  c->export_chunks = chunks;
+  c->export_in_flight = true;
   return MVICP_OK;
 }
 

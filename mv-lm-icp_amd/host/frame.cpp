@@ -86,7 +86,7 @@ void Session::correspond(std::vector<std::shared_ptr<Frame>>& frames, float thre
   corr = nullptr; corr_off = nullptr;
   // the literal drop-in contract: every list in the reference's layout, un-sorted on the device, ONE copy per round for all edges
   if (copy_back) {
-    check(mvicp_map_correspondences(ctx, &corr, &corr_off));   // (no device work when the search reproduced every list: mvicp.h)
+    check(mvicp_map_correspondences_async(ctx, &corr, &corr_off));   // (no device work when the search reproduced every list: mvicp.h); chunks arrive frame by frame
     check(mvicp_correspondence_epochs(ctx, &epochs));
   }
 }
@@ -206,6 +206,7 @@ void Frame::computeClosestPointsToNeighbours(std::vector<std::shared_ptr<Frame>>
         ++S.edges_skipped; ++e; continue;
       }
       edge.correspondances.resize(n);
+      if (n) check(mvicp_wait_correspondences(S.ctx, (int)e));   // this edge's chunk has landed (later frames' chunks are still on the bus)
       if (n) pieces.push_back(std::make_pair(std::make_pair((char*)edge.correspondances.data(), (const char*)(S.corr + S.corr_off[e])), n * sizeof(Correspondance)));
       if (h) { h->epoch = S.epochs[e]; h->data = (const void*)edge.correspondances.data(); h->n = n; }
       ++S.edges_copied;

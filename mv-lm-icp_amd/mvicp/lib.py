@@ -14,7 +14,7 @@ EDGE_BLOCK = 91
 SYMBOLS = [
     "mvicp_last_error", "mvicp_version", "mvicp_create", "mvicp_destroy", "mvicp_set_num_frames", "mvicp_set_frame",
     "mvicp_recompute_normals", "mvicp_set_graph", "mvicp_set_shard", "mvicp_edge_owner", "mvicp_comm_unique_id", "mvicp_comm_init", "mvicp_comm_nranks", "mvicp_comm_set_callback", "mvicp_correspond",
-    "mvicp_get_correspondences", "mvicp_map_correspondences", "mvicp_correspondence_epochs", "mvicp_set_correspondences", "mvicp_nn_query", "mvicp_linearize", "mvicp_optimize",
+    "mvicp_get_correspondences", "mvicp_map_correspondences", "mvicp_map_correspondences_async", "mvicp_wait_correspondences", "mvicp_correspondence_epochs", "mvicp_set_correspondences", "mvicp_nn_query", "mvicp_linearize", "mvicp_optimize",
     "mvicp_lm_solve", "mvicp_set_option", "mvicp_nn_census", "mvicp_nn_census_ex", "mvicp_reset_history", "mvicp_profile_enable", "mvicp_profile_reset", "mvicp_profile_get", "mvicp_profile_get_ex", "mvicp_stream", "mvicp_sync",
     "mvicp_closedform_point_to_point", "mvicp_closedform_point_to_plane",
 ]
@@ -65,6 +65,8 @@ def load_library(path=None):
     lib.mvicp_correspond.argtypes = [vp, dp, u8p, C.c_float, C.c_int, ip, fp]
     lib.mvicp_get_correspondences.argtypes = [vp, C.c_int, C.c_int, ip, ip, dp]
     lib.mvicp_map_correspondences.argtypes = [vp, C.POINTER(vp), C.POINTER(C.POINTER(C.c_longlong))]
+    lib.mvicp_map_correspondences_async.argtypes = [vp, C.POINTER(vp), C.POINTER(C.POINTER(C.c_longlong))]
+    lib.mvicp_wait_correspondences.argtypes = [vp, C.c_int]
     lib.mvicp_correspondence_epochs.argtypes = [vp, C.POINTER(C.POINTER(C.c_ulonglong))]
     lib.mvicp_set_correspondences.argtypes = [vp, C.c_int, C.c_int, ip, ip, C.c_float]
     lib.mvicp_nn_query.argtypes = [vp, C.c_int, dp, C.c_int, C.c_int, ip, dp]
@@ -319,6 +321,20 @@ class Engine:
         buf = (C.c_char * (16 * total)).from_address(tp.value)
         t = np.frombuffer(buf, dtype=self.CORR_DTYPE, count=total)
         return (t.copy() if copy else t), off
+
+    def map_correspondences_async(self):
+        """mvicp_map_correspondences_async: VIEWS (triples, offsets) of the library's pinned buffer; edge e's bytes are defined after wait_correspondences(e)."""
+        tp, op = C.c_void_p(), C.POINTER(C.c_longlong)()
+        _check(self.lib, self.lib.mvicp_map_correspondences_async(self.h, C.byref(tp), C.byref(op)))
+        off = np.ctypeslib.as_array(op, shape=(self.E + 1,)).copy()
+        total = int(off[-1])
+        if total == 0:
+            return np.zeros(0, dtype=self.CORR_DTYPE), off
+        buf = (C.c_char * (16 * total)).from_address(tp.value)
+        return np.frombuffer(buf, dtype=self.CORR_DTYPE, count=total), off
+
+    def wait_correspondences(self, edge):
+        _check(self.lib, self.lib.mvicp_wait_correspondences(self.h, int(edge)))
 
     def correspondence_epochs(self):
         """Per-edge change counters of the lists (mvicp_correspondence_epochs): an edge whose list is provably last search's keeps its epoch."""

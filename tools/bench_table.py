@@ -1,4 +1,4 @@
-"""Markdown tables from bench lines (DESIGN.md's measurement section):  python tools/bench_table.py gpurun_out/fin5_*.json"""
+"""Markdown tables from bench lines (DESIGN.md's measurement section):  python tools/bench_table.py gpurun_out/fin6_*.json   (full records: bench.py --detail-file)"""
 import json, sys
 
 def load(f):

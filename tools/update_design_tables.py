@@ -1,7 +1,7 @@
-"""Regenerates the two measurement tables of DESIGN.md section 8 (between the bench-table markers) from gpurun_out/fin5_*.json."""
+"""Regenerates the two measurement tables of DESIGN.md section 8 (between the bench-table markers) from the full bench records gpurun_out/fin6_*.json (bench.py --detail-file)."""
 import io, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-files = [os.path.join(ROOT, "gpurun_out", f"fin5_{w}.json") for w in ("cfg4_w5s20", "cfg4", "cfg2", "cfg3", "cfg5", "shard8", "shard8_cfg5", "cfg4_partial")]
+files = [os.path.join(ROOT, "gpurun_out", f"fin6_{w}.json") for w in ("cfg4_w5s20", "cfg4", "cfg2", "cfg3", "cfg5", "shard8", "shard8_cfg5", "cfg4_partial")]
 out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "bench_table.py")] + files).decode()
 t1, t2 = out.strip().split("\n\n")
 keep = ("| cfg4 (5+20)", "| cfg5 (5+20)", "| cfg4_partial (5+20) | nn_tile")
