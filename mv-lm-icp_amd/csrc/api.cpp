@@ -116,6 +116,13 @@ HostScope::~HostScope() {
   pe.ms += now_ms() - t0;
   pe.launches += 1;
 }
+// The hot calls (mvicp_correspond / mvicp_optimize / mvicp_linearize) only collect once a scope holds more than 256 unresolved event pairs: resolving
+// them costs a hipEventSynchronize + hipEventElapsedTime per pair — 10-30 us of host time per ICP round with four scopes live, INSIDE the timed
+// region of a bench run that needs the scopes for its roofline (5 % of a cfg4 fixed-point round, 15 % of a shard8 one).  The readers
+// (mvicp_profile_get / _reset) always collect everything.
+void prof_collect_lazy(mvicp_ctx* c) {
+  for (auto& kv : c->prof) if (kv.second.pending.size() > 256) { prof_collect(c); return; }
+}
 void prof_collect(mvicp_ctx* c) {
   for (auto& kv : c->prof) {
     ProfEntry& pe = kv.second;
@@ -549,7 +556,7 @@ int mvicp_recompute_normals(mvicp_ctx* c, int frame, int k, double* nrm_out, int
       MV_HIP(hipStreamSynchronize(c->stream));
     }
   }
-  if (c->profile) prof_collect(c);
+  if (c->profile) prof_collect_lazy(c);
   return st;
 } MVICP_GUARD_ABI
 
@@ -1097,7 +1104,7 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   for (int e = 0; e < E; ++e) if (!unchanged[e]) c->corr_epoch[e] = ++c->epoch_counter;
   c->have_corr = true;
   mark("host.corr.finish");
-  if (c->profile) prof_collect(c);
+  if (c->profile) prof_collect_lazy(c);
   return MVICP_OK;
 } MVICP_GUARD_ABI
 
@@ -1111,7 +1118,7 @@ static int ensure_export(mvicp_ctx* c, bool wait = true) {
   if (wait && c->export_in_flight) {
     MV_CHECK(stream_wait(c));
     c->export_in_flight = false;
-    if (c->profile) prof_collect(c);
+    if (c->profile) prof_collect_lazy(c);
   }
   return MVICP_OK;
 }
@@ -1269,7 +1276,7 @@ int mvicp_nn_query(mvicp_ctx* c, int frame, const double* queries, int n, int nn
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { set_error("nn_query copy-back failed"); st = MVICP_ERR_HIP; }
   }
   dev_free(dq); dev_free(di); dev_free(dd);
-  if (c->profile) prof_collect(c);
+  if (c->profile) prof_collect_lazy(c);
   return st;
 } MVICP_GUARD_ABI
 
@@ -1278,7 +1285,7 @@ int mvicp_linearize(mvicp_ctx* c, const double* poses, int point_to_plane, int r
   if (!poses || !out) { set_error("null argument"); return MVICP_ERR_ARG; }
   if (c->E == 0) { set_error("no graph"); return MVICP_ERR_STATE; }
   MV_CHECK(evaluate_blocks(c, poses, point_to_plane, robust, out));
-  if (c->profile) prof_collect(c);
+  if (c->profile) prof_collect_lazy(c);
   return MVICP_OK;
 } MVICP_GUARD_ABI
 

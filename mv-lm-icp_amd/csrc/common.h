@@ -324,6 +324,7 @@ struct ProfScope {
   ~ProfScope();
 };
 void prof_collect(mvicp_ctx* c);
+void prof_collect_lazy(mvicp_ctx* c);   // the hot calls: only once a scope holds > 256 unresolved event pairs
 // host wall-clock sections (same table, names prefixed "host."), only while profiling
 struct HostScope {
   mvicp_ctx* c; const char* name; double t0; bool on;

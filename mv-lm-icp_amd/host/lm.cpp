@@ -322,7 +322,7 @@ int mvicp_optimize(mvicp_ctx* c, double* poses, unsigned char* fixed, int param,
     for (int e = 0; e < c->E; ++e) n += c->h_count[e];
     c->last_rms = n > 0.0 && summary->final_cost >= 0.0 ? std::sqrt(2.0 * summary->final_cost / n) : -1.0;
   }
-  if (c->profile) prof_collect(c);
+  if (c->profile) prof_collect_lazy(c);
   return st;
 } MVICP_GUARD_ABI
 
