@@ -22,6 +22,7 @@ void set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(
 int abi_exception() noexcept { std::snprintf(g_err, sizeof(g_err), "exception"); return MVICP_ERR_INTERNAL; }
 int evaluate_blocks(mvicp_ctx*, const double*, int, int, double*) { return MVICP_ERR_STATE; }   // (device evaluator: not in this build)
 void prof_collect(mvicp_ctx*) {}
+void prof_collect_lazy(mvicp_ctx*) {}
 HostScope::HostScope(mvicp_ctx* ctx, const char* nm) : c(ctx), name(nm), t0(0.0), on(false) {}
 HostScope::~HostScope() {}
 }  // namespace mvicp
