@@ -826,6 +826,9 @@ def test_tile_kernel_lower_bounds_feed_the_temporal_cache(orc, mu):
     # the matrix-pipe tile kernel (nn_mfma.hip) against the VALU one (nn_tile.hip), in every role, and its own tunables
     {"tile_mfma": 0}, {"tile_mfma": 2}, {"tile_mfma": 2, "tile_bounds": 2}, {"tile_mfma": 0, "tile_bounds": 2}, {"tile_mfma": 2, "tile_cache": 1, "tile_mu": 0.5},
     {"mfma_trig": 0}, {"mfma_trig": 33}, {"mfma_kacc": 4}, {"mfma_kacc": 512}, {"tile_mfma": 2, "tile_seed": 0}, {"mfma_lbt": 0}, {"mfma_lbt": 0, "tile_seed": 0}, {"tile_mfma": 2, "tile_waves": 6}, {"tile_mfma": 2, "tile_waves": 4},
+    # round 6: the miss_block path of the cache-aware rounds (off / every wave), the early cache prologue, the seed-block entry of the seeded launches
+    {"tile_miss": 0}, {"tile_miss": 64}, {"tile_miss": 64, "tile_mu": 0.5}, {"tile_miss": 2, "auto_settle": 5.0}, {"tile_bounds": 2, "tile_cache": 2}, {"tile_bounds": 2, "tile_cache": 2, "tile_mfma": 2, "tile_miss": 64},
+    {"mfma_entry": 1}, {"mfma_entry": 1, "tile_bounds": 2}, {"mfma_entry": 1, "tile_seed": 0},
 ])
 def test_tuning_options_never_change_results(opts):
     """Every speed knob (kernel variants, seeding, cell pruning, AUTO hand-over policy, caches) must leave the whole ICP
