@@ -211,7 +211,9 @@ int mvicp_closedform_point_to_plane(const double* src, const double* dst, const 
  * tile makes the wave confirm nearest-first and screen the tile again; "mfma_lbt" (0/1, default 1): launches without any seed test a tile's box per
  * lane before screening it; "nn_search_factor" (default 4; 0 = unbounded): the kernels look for a neighbour within this many cutoffs (a query the
  * cutoff rejects keeps a seed and a temporal-cache bound; results are filtered by the cutoff afterwards, like the reference); "tie_rule" (0/1,
- * default 1): exact distance ties are decided the way nanoflann decides them (first visited target; 0 = lowest original index); "sel_bracket" (0/1, default 1): one-pass median select around last round's median
+ * default 1): exact distance ties are decided the way nanoflann decides them (first visited target; 0 = lowest original index); "tie_lazy" (0/1, default 1;
+ * single rank only, read at mvicp_set_graph): the reference-equivalent trees that decide ties are built when a search first reports a tie on a target
+ * without one — that search is then repeated once — like the reference's own lazily built index (frame.cpp:188-193); 0 = built for every target at mvicp_set_graph; "sel_bracket" (0/1, default 1): one-pass median select around last round's median
  * once it has settled; "spec_eval" (0/1, default 1): mvicp_correspond queues the first linearization of the following
  * mvicp_optimize (same poses, previous solve's flags) behind its own kernels so the round waits once, not twice; "lin_share_p"
  * (0/1, default 1): the linearization reads the source points of an all-accepted edge from the shared sorted cloud; "nn_cell"

@@ -676,7 +676,7 @@ int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) t
     c->far_cap = cap;
   }
   MV_CHECK(warm_nn_grid(c)); MV_CHECK(warm_nn_tile(c)); MV_CHECK(warm_nn_mfma(c));
-  if (c->tie_rule) {   // the reference's own trees over the targets of the edges THIS RANK owns: they decide exact distance ties (the others are never searched here)
+  if (c->tie_rule && !(c->tie_lazy && c->world == 1)) {   // the reference's own trees over the targets of the edges THIS RANK owns: they decide exact distance ties (the others are never searched here)
     std::vector<int> need;
     for (int e = 0; e < E; ++e) if (c->owned[e]) need.push_back(dst[e]);
     MV_CHECK(ensure_tie_trees(c, need));
@@ -765,8 +765,28 @@ int mvicp_reset_history(mvicp_ctx* c) try {
 //   export_valid                  ensure_export                            h_export holds the lists as they are on the device     every search that can change a list, set_correspondences, reset
 //   qpos_valid[e]                 end of the NN stage                      d_qpos / second / cd2 = the last search's result (export)  set_correspondences, failed search, reset
 //   corr_epoch[e]                 end of this call                         callers skip copying a list whose epoch they hold      bumped unless the edge's inputs are bit-identical to last search's
+static int correspond_once(mvicp_ctx* c, const double* poses, const unsigned char* fixed, float thresh, int nn_method, int* counts, float* weights, bool* tie_unresolved);
+
 int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fixed, float thresh, int nn_method, int* counts, float* weights) try {
   MV_CHECK(bind(c));
+  bool unresolved = false;
+  MV_CHECK(correspond_once(c, poses, fixed, thresh, nn_method, counts, weights, &unresolved));
+  if (!unresolved) return MVICP_OK;
+  // Lazy tie trees (single rank): the search reported an exact distance tie on a target whose reference-equivalent tree does not exist yet, so that
+  // query still carries the kernels' own rule (lowest index).  Build the trees of every searched target now — once per cloud, like the reference's
+  // lazily built index — forget what this search left behind and search again: this time the fix-up decides the ties the way nanoflann does.
+  std::vector<int> need;
+  for (int e = 0; e < c->E; ++e) if (c->active[e] && !c->frames[c->edst[e]].has_tie) need.push_back(c->edst[e]);
+  MV_HIP(hipStreamSynchronize(c->stream));
+  MV_CHECK(ensure_tie_trees(c, need));
+  forget_history(c);
+  unresolved = false;
+  MV_CHECK(correspond_once(c, poses, fixed, thresh, nn_method, counts, weights, &unresolved));
+  if (unresolved) { set_error("tie fix-up still without a tree after building them"); return MVICP_ERR_INTERNAL; }
+  return MVICP_OK;
+} MVICP_GUARD_ABI
+
+static int correspond_once(mvicp_ctx* c, const double* poses, const unsigned char* fixed, float thresh, int nn_method, int* counts, float* weights, bool* tie_unresolved) {
   if (!poses) { set_error("poses is null"); return MVICP_ERR_ARG; }
   if (c->E == 0) { set_error("no graph: call mvicp_set_graph first"); return MVICP_ERR_STATE; }
   const int E = c->E;
@@ -831,7 +851,7 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   // returns an error from this same call — the failing rank its own status, the others MVICP_ERR_COMM.  (A device that no longer executes
   // anything cannot poison or exchange: that stays fatal for the job, as any collective library has it.)
   int st_local = MVICP_OK;
-  if (c->tie_rule) {   // a cloud uploaded after mvicp_set_graph has no tree yet (the reference builds its index lazily as well, frame.cpp:188-193)
+  if (c->tie_rule && !(c->tie_lazy && c->world == 1)) {   // a cloud uploaded after mvicp_set_graph has no tree yet (the reference builds its index lazily as well, frame.cpp:188-193)
     std::vector<int> need;
     for (int e = 0; e < E; ++e) if (c->active[e] && !c->frames[c->edst[e]].has_tie) need.push_back(c->edst[e]);
     if (!need.empty()) st_local = ensure_tie_trees(c, need);
@@ -1034,6 +1054,7 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   census_resolve(c);
   // what THIS search's tie fix-up / far launch reported (a skipped launch keeps last search's zero): the next search's skip decisions
   if (tie_launched) c->corr_tie_seen = c->h_tie_seen ? *c->h_tie_seen : 1u;
+  if (tie_launched && c->h_tie_seen && c->h_tie_seen[1] != 0u) *tie_unresolved = true;
   if (far_launched) c->corr_far_seen = c->h_far_seen ? *c->h_far_seen : 1u;
   else if (method != MVICP_NN_GRID) c->corr_far_seen = 1u;
   mark("host.corr.wait");
@@ -1106,7 +1127,7 @@ int mvicp_correspond(mvicp_ctx* c, const double* poses, const unsigned char* fix
   mark("host.corr.finish");
   if (c->profile) prof_collect_lazy(c);
   return MVICP_OK;
-} MVICP_GUARD_ABI
+}
 
 // every exportable edge's list of the last search, un-sorted on the device into the reference's layout and copied once (export.hip)
 static int ensure_export(mvicp_ctx* c, bool wait = true) {
@@ -1309,6 +1330,7 @@ int mvicp_set_option(mvicp_ctx* c, const char* name, double value) try {
   if (std::strcmp(name, "nn_cell") == 0) { c->nn_cell = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "nn_search_factor") == 0) { if (!(value >= 0.0)) { set_error("nn_search_factor < 0"); return MVICP_ERR_ARG; } c->nn_search_factor = value; c->nn_cache_valid = false; return MVICP_OK; }
   if (std::strcmp(name, "tie_rule") == 0) { c->tie_rule = value != 0.0; return MVICP_OK; }
+  if (std::strcmp(name, "tie_lazy") == 0) { c->tie_lazy = value != 0.0; return MVICP_OK; }   // takes effect at the next mvicp_set_graph
   if (std::strcmp(name, "tile_seed") == 0) { c->tile_seed = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "tile_bounds") == 0) { c->tile_bounds = (int)value; return MVICP_OK; }
   if (std::strcmp(name, "tile_mu") == 0) { if (!(value > 0.0 && value <= 1.0)) { set_error("tile_mu outside (0, 1]"); return MVICP_ERR_ARG; } c->tile_mu = value; return MVICP_OK; }

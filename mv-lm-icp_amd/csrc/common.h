@@ -243,6 +243,9 @@ struct mvicp_ctx {
   double nn_search_factor = 4.0;   // the kernels look for a neighbour within this many cutoffs (0 = unbounded, like the reference's findNeighbors): a query the
                                    // cutoff rejects then still has a neighbour to seed next round's search with and a temporal-cache bound, instead of being
                                    // searched from scratch every round (partial overlap: a third of the queries); the filter of frame.cpp:156 is applied after
+  bool tie_lazy = true;            // single rank: the reference-equivalent trees (kdvisit.h) are built when a search first REPORTS a tie on a target without one (the
+                                   // search is then repeated once), like the reference's own lazily built index (frame.cpp:188-193) — synthetic clouds never tie, and
+                                   // the eager build was most of cfg5's set-up time.  N > 1 ranks build them at mvicp_set_graph (a repeated search is a collective)
   bool tie_rule = true;            // exact distance ties are decided as nanoflann decides them (first visited; nn_tie.hip); false: lowest original index
   unsigned long long* d_tie_list = nullptr; size_t tie_cap = 0; unsigned int* d_tie_count = nullptr; int tie_parity = 0;   // queries reported by the NN kernels
   unsigned int* h_tie_seen = nullptr; unsigned int* d_tie_seen = nullptr;   // mapped host word: reports of the last fix-up launch (read after the round's wait)

@@ -113,7 +113,8 @@ __global__ __launch_bounds__(64) void nn_tie_kernel(const TieJob* __restrict__ j
       jb = (int)(e >> 32); i = (int)(e & 0xffffffffull);
     }
     const TieJob& J = jobs[jb];
-    if (i >= J.n || J.nodes == nullptr) continue;
+    if (i >= J.n) continue;
+    if (J.nodes == nullptr) { seen[1] = 1u; continue; }   // lazy trees (api.cpp): this target has none yet — the host builds it and repeats the search
     const int cur = J.out_idx[i];
     if (cur < 0) continue;
     double qx, qy, qz;
@@ -220,8 +221,9 @@ int launch_tie_fixup(mvicp_ctx* c, const std::vector<TieJob>& jobs, double d2_bo
   if (!c->tie_rule || jobs.empty() || !c->d_tie_count) return MVICP_OK;
   if (c->tie_skip) return MVICP_OK;   // (the launch's counter stays zero and keeps its turn)
   if (!c->h_tie_seen) {
-    MV_HIP(hipHostMalloc((void**)&c->h_tie_seen, sizeof(unsigned int), hipHostMallocMapped));
-    *c->h_tie_seen = 1u;   // unknown until a launch has written it
+    MV_HIP(hipHostMalloc((void**)&c->h_tie_seen, 2 * sizeof(unsigned int), hipHostMallocMapped));   // [0] reports of the launch, [1] "a reported query's target has no tree"
+    c->h_tie_seen[0] = 1u;   // unknown until a launch has written it
+    c->h_tie_seen[1] = 0u;
     MV_HIP(hipHostGetDevicePointer((void**)&c->d_tie_seen, c->h_tie_seen, 0));
   }
   std::vector<TieJob> tab(jobs);
@@ -232,6 +234,7 @@ int launch_tie_fixup(mvicp_ctx* c, const std::vector<TieJob>& jobs, double d2_bo
   unsigned int* cnt = c->d_tie_count + c->tie_parity;
   unsigned int* nxt = c->d_tie_count + (c->tie_parity ^ 1);
   c->tie_parity ^= 1;
+  c->h_tie_seen[1] = 0u;   // (host store to the mapped word before the launch; the kernel only ever stores 1)
   ProfScope ps(c, "nn_tie", 0.0);
   hipLaunchKernelGGL(nn_tie_kernel, dim3(256), dim3(64), 0, c->stream, d_tab, (int)tab.size(), c->d_tie_list, cnt, nxt, (unsigned int)c->tie_cap, d2_bound, c->d_tie_seen);
   MV_HIP(hipGetLastError());

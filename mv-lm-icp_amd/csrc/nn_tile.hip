@@ -182,8 +182,8 @@ __device__ __forceinline__ double bcast_d(double v, int lane) {
 //   * tile level: two tiles per step, lane l evaluates point l & 31 of tile l >> 5 in the reference's fp64 arithmetic straight from the 32-B sorted
 //     records (one coalesced 2-KB load, no LDS staging, no fp32 screen); the few lanes that come within the running best update the scalar state
 //     by leaf_scan's own rules, one after the other.
-// BND's second-best is kept as a LOWER bound here (fp32, rounded down, of the points beyond the best) — all the temporal cache needs; exact ties
-// set the tie flag explicitly (the BND build's `second == best` test would miss one under a rounded-down second).  Results (index, d2) are
+// BND's second-best is kept as a LOWER bound here (the fp32 floor of the points beyond the best, clamped at the best) — all the temporal cache needs;
+// an exact tie still leaves second == best, the BND builds' tie signal.  Results (index, d2) are
 // those of the scan above bit for bit: the same candidates — every point of every tile whose box reaches the query's ball — by the same rules.
 template <bool BND>
 __device__ void miss_block(const TileView& g, int first, int nchild, Lane& L, const Group& G, unsigned int* n_cand, unsigned int* n_box) {
@@ -233,8 +233,11 @@ __device__ void miss_block(const TileView& g, int first, int nchild, Lane& L, co
       unsigned long long pm = __ballot(valid && d <= best);
       if (BND) {
         // everything beyond the running best only lowers `second`: its fp32 floor is a valid (and nearly tight) lower bound
+        // (clamped from below at the smallest double ABOVE the running best: d > best means d >= that, so it is still a lower bound of every such d,
+        // and it keeps `second == best` — the BND builds' tie signal — for exact ties only: an fp32 floor that rounds down onto the best would report one
+        // false tie per ~1e7 queries, i.e. every launch)
         const float far32 = wave_min_f(valid && d > best ? __double2float_rd(d) : inf);
-        second = fmin(second, (double)far32);
+        second = fmin(second, fmax((double)far32, __longlong_as_double(__double_as_longlong(best) + 1ll)));
       }
       while (pm != 0ull) {
         const int j = __ffsll((long long)pm) - 1;
@@ -245,14 +248,14 @@ __device__ void miss_block(const TileView& g, int first, int nchild, Lane& L, co
           if (BND) second = fmin(second, best);
           best = dj; bi = oj; changed = true;
         } else if (dj == best) {
-          if (oj != bi) { if (BND) second = fmin(second, dj); tie = true; if (oj < bi) bi = oj; }
+          if (oj != bi) { if (BND) second = fmin(second, dj); else tie = true; if (oj < bi) bi = oj; }
         } else if (BND) {
           second = fmin(second, dj);
         }
       }
     }
     if (changed) thr = fminf(thr, thr_of(best, G.slack + G.mu));
-    if (lane == a) { L.best = best; L.bi = bi; L.tie = tie; L.second = second; L.thr = thr; }
+    if (lane == a) { L.best = best; L.bi = bi; if (!BND) L.tie = tie; L.second = second; L.thr = thr; }
   }
 }
 
@@ -261,10 +264,13 @@ __device__ void miss_block(const TileView& g, int first, int nchild, Lane& L, co
 // is live in all deeper levels.  Levels 1 and 2 therefore park their 64 child boxes in wave-private LDS (32 B each, read
 // back with one uniform-address load per step) and keep only {cull distance, order key, pending} per lane; level 0, the
 // hot one, keeps its boxes in registers and broadcasts them with v_readlane.
-template <int LEVEL, bool BND, bool MISS>
+// `miss` (wave-uniform, BND builds only): below the block level the wave runs miss_block instead of the tile loop — a run-time flag, not a template
+// parameter, so that the levels above exist once (two instantiations of the whole traversal cost the regular path 3-4 %: instruction cache)
+template <int LEVEL, bool BND>
 __device__ void visit(const TileView& g, int first, int nchild, Lane& L, const Group& G, TileLds* __restrict__ T,
-                      float2* __restrict__ sbox, unsigned int* n_cand, unsigned int* n_box) {
-  if constexpr (LEVEL == 0 && MISS) { miss_block<BND>(g, first, nchild, L, G, n_cand, n_box); return; } else {
+                      float2* __restrict__ sbox, unsigned int* n_cand, unsigned int* n_box, bool miss) {
+  if (BND && LEVEL == 0 && miss) { miss_block<BND>(g, first, nchild, L, G, n_cand, n_box); return; }
+  {
   constexpr bool IN_LDS = LEVEL == 1 || LEVEL == 2;
   const int lane = threadIdx.x & 63;
   const float inf = __int_as_float(0x7f800000);
@@ -325,7 +331,7 @@ __device__ void visit(const TileView& g, int first, int nchild, Lane& L, const G
       leaf_scan<BND>(g, child, L, G.slack, G.mu, T, n_cand);
     } else {
       const int cf = child * FAN;
-      visit<(LEVEL > 0 ? LEVEL - 1 : 0), BND, MISS>(g, cf, min(FAN, g.cnt[LEVEL > 0 ? LEVEL - 1 : 0] - cf), L, G, T, sbox, n_cand, n_box);
+      visit<(LEVEL > 0 ? LEVEL - 1 : 0), BND>(g, cf, min(FAN, g.cnt[LEVEL > 0 ? LEVEL - 1 : 0] - cf), L, G, T, sbox, n_cand, n_box, miss);
     }
     gmax = wave_max_f(L.active ? L.thr : 0.f);
   }
@@ -440,21 +446,15 @@ __global__ __launch_bounds__(TT, WPE) void nn_tile_kernel(const TileJob* __restr
   float2* sbox = s_box[wave];
   // cache-aware rounds: a wave left with at most job.miss_max missed lanes takes them one by one with the lanes spread over the data (miss_block)
   const bool miss_path = BND && job.cache && job.miss_max > 0 && __popcll(__ballot(L.active)) <= job.miss_max;
-  unsigned int n_exam = 0;
-#define MVICP_VISIT(M)                                                                                                          \
-  do {                                                                                                                          \
-    if (TOP >= 0) visit<(TOP >= 0 ? TOP : 0), BND, M>(g, 0, g.cnt[TOP >= 0 ? TOP : 0], L, G, T, sbox, &n_cand, &n_box);           \
-    else switch (top) {                                                                                                         \
-      case 0: visit<0, BND, M>(g, 0, g.cnt[0], L, G, T, sbox, &n_cand, &n_box); break;                                            \
-      case 1: visit<1, BND, M>(g, 0, g.cnt[1], L, G, T, sbox, &n_cand, &n_box); break;                                            \
-      case 2: visit<2, BND, M>(g, 0, g.cnt[2], L, G, T, sbox, &n_cand, &n_box); break;                                            \
-      case 3: visit<3, BND, M>(g, 0, g.cnt[3], L, G, T, sbox, &n_cand, &n_box); break;                                            \
-      default: visit<4, BND, M>(g, 0, g.cnt[4], L, G, T, sbox, &n_cand, &n_box); break;                                           \
-    }                                                                                                                           \
-  } while (0)
-  if (BND && miss_path) { MVICP_VISIT(BND); n_exam = n_cand; }   // (MISS only exists in BND builds: the plain build never compiles it)
-  else MVICP_VISIT(false);
-#undef MVICP_VISIT
+  if (TOP >= 0) visit<(TOP >= 0 ? TOP : 0), BND>(g, 0, g.cnt[TOP >= 0 ? TOP : 0], L, G, T, sbox, &n_cand, &n_box, miss_path);
+  else switch (top) {
+    case 0: visit<0, BND>(g, 0, g.cnt[0], L, G, T, sbox, &n_cand, &n_box, miss_path); break;
+    case 1: visit<1, BND>(g, 0, g.cnt[1], L, G, T, sbox, &n_cand, &n_box, miss_path); break;
+    case 2: visit<2, BND>(g, 0, g.cnt[2], L, G, T, sbox, &n_cand, &n_box, miss_path); break;
+    case 3: visit<3, BND>(g, 0, g.cnt[3], L, G, T, sbox, &n_cand, &n_box, miss_path); break;
+    default: visit<4, BND>(g, 0, g.cnt[4], L, G, T, sbox, &n_cand, &n_box, miss_path); break;
+  }
+  const unsigned int n_exam = n_cand;
   if (L.active) {
     const int out = i;   // sorted order of the source cloud
     job.out_idx[out] = L.bi == 0x7fffffff ? -1 : (job.inv ? job.inv[L.bi] : L.bi);
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(TT, WPE) void nn_tile_kernel(const TileJob* __restr
     // keeps its acceptance patches its own entry and operands, so compaction + gather only run for edges whose MEMBERSHIP changed —
     // also in the plain seeded rounds, where nearly every neighbour changes but hardly any acceptance does (round 3)
     if (job.list.dirty) update_list_entry(job.list, i, L.bi == 0x7fffffff ? -1 : job.inv[L.bi], L.best, bound, false);
-    if ((BND ? (L.second == L.best || L.tie) : L.tie) && L.bi != 0x7fffffff) tie_report(job.tie, (unsigned int)i);   // (BND: L.tie is set by miss_block only)
+    if ((BND ? L.second == L.best : L.tie) && L.bi != 0x7fffffff) tie_report(job.tie, (unsigned int)i);
   }
   if (stats && (threadIdx.x & 63) == 0) {
     // wave-uniform counters: candidates examined PER LANE x active lanes, boxes tested per wave

@@ -95,11 +95,13 @@ def test_duplicate_targets_follow_nanoflanns_visit_order(eng, orc, refnn):
         eng.set_option("tie_rule", 1)
 
 
-@pytest.mark.parametrize("opts", [{}, {"tile_mfma": 0}, {"tile_mfma": 2, "tile_bounds": 2}, {"nn_cache": 0}])
+@pytest.mark.parametrize("opts", [{}, {"tile_mfma": 0}, {"tile_mfma": 2, "tile_bounds": 2}, {"nn_cache": 0}, {"tie_lazy": 0}])
 @pytest.mark.parametrize("method", [L.NN_BRUTE, L.NN_GRID, L.NN_TILE, L.NN_AUTO])
 def test_duplicate_targets_through_the_correspondence_path(refnn, orc, method, opts):
     """The same on the edge path, round after round (seeded, bounds-leaving and cache-aware rounds included): the `second` index of every
-    correspondence is the real nanoflann's, the lists / weights / poses follow the reference-equivalent CPU path."""
+    correspondence is the real nanoflann's, the lists / weights / poses follow the reference-equivalent CPU path.  By default (tie_lazy = 1, round 6)
+    the reference-equivalent trees do not exist when the first search reports its ties: that search is repeated once after building them —
+    {"tie_lazy": 0} is the eager build at mvicp_set_graph."""
     import cpupath
     assert refnn is not None
     pb = synth.make_problem(3, 3000)
