@@ -14,16 +14,16 @@ if grep -q "failed\|Error" gpurun_out/fin6_tests.txt || ! grep -q "passed" gpuru
 fi
 ROUND=$R bash tools/profile.sh cfg4 5 20 5 > gpurun_out/fin6_profile_w5s20.txt 2>&1
 ROUND=$R bash tools/profile.sh cfg4 1 19 5 > gpurun_out/fin6_profile_w1s19.txt 2>&1
-# the bench lines below quote `traffic` from these summaries (same sources, same arguments): put them where bench.py looks
-for t in w5s20 w1s19; do cp gpurun_out/prof/${R}_cfg4_$t/${R}_cfg4_${t}_kernels.json gpurun_out/prof/${R}_cfg4_$t/${R}_cfg4_${t}_summary.txt profiles/ 2>/dev/null; done
-timeout 600 python bench.py --warmup 5 --steps 20 --detail-file gpurun_out/fin6_cfg4_w5s20.json > gpurun_out/fin6_cfg4_w5s20.line 2> gpurun_out/fin6_cfg4_w5s20.err
-timeout 600 python bench.py --detail-file gpurun_out/fin6_cfg4.json > gpurun_out/fin6_cfg4.line 2> gpurun_out/fin6_cfg4.err
-for wl in cfg2 cfg3 shard8 shard8_cfg5 cfg4_partial; do timeout 300 python bench.py --workload $wl --warmup 5 --steps 20 --no-cpu-baseline --detail-file gpurun_out/fin6_$wl.json > gpurun_out/fin6_$wl.line 2> gpurun_out/fin6_$wl.err; done
-timeout 600 python bench.py --workload cfg5 --warmup 5 --steps 20 --no-cpu-baseline --detail-file gpurun_out/fin6_cfg5.json > gpurun_out/fin6_cfg5.line 2> gpurun_out/fin6_cfg5.err
 if [ -n "${PROFILE_MORE:-}" ]; then
 ROUND=$R bash tools/profile.sh cfg4_partial 5 20 3 > gpurun_out/fin6_profile_partial.txt 2>&1
 ROUND=$R bash tools/profile.sh cfg5 5 20 1 > gpurun_out/fin6_profile_cfg5.txt 2>&1
 fi
+# the bench lines below quote `traffic` from these summaries (same sources, same arguments): put them where bench.py looks
+for t in cfg4_w5s20 cfg4_w1s19 cfg4_partial_w5s20 cfg5_w5s20; do cp gpurun_out/prof/${R}_$t/${R}_${t}_kernels.json gpurun_out/prof/${R}_$t/${R}_${t}_summary.txt profiles/ 2>/dev/null; done
+timeout 600 python bench.py --warmup 5 --steps 20 --detail-file gpurun_out/fin6_cfg4_w5s20.json > gpurun_out/fin6_cfg4_w5s20.line 2> gpurun_out/fin6_cfg4_w5s20.err
+timeout 600 python bench.py --detail-file gpurun_out/fin6_cfg4.json > gpurun_out/fin6_cfg4.line 2> gpurun_out/fin6_cfg4.err
+for wl in cfg2 cfg3 shard8 shard8_cfg5 cfg4_partial; do timeout 300 python bench.py --workload $wl --warmup 5 --steps 20 --no-cpu-baseline --detail-file gpurun_out/fin6_$wl.json > gpurun_out/fin6_$wl.line 2> gpurun_out/fin6_$wl.err; done
+timeout 600 python bench.py --workload cfg5 --warmup 5 --steps 20 --no-cpu-baseline --detail-file gpurun_out/fin6_cfg5.json > gpurun_out/fin6_cfg5.line 2> gpurun_out/fin6_cfg5.err
 TRACE_CENSUS=1 TRACE_METHODS=auto timeout 60 python tools/round_trace.py 32 200000 10 2>&1 | grep -a nn_ms > gpurun_out/fin6_trace_auto.txt
 AB_CENSUS=1 timeout 120 python tools/tile_ab.py 32 200000 7 "tile_miss=0" "" > gpurun_out/fin6_tile_ab.txt 2>&1
 ls gpurun_out/fin6_*
