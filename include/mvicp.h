@@ -222,7 +222,11 @@ int mvicp_closedform_point_to_plane(const double* src, const double* dst, const 
  * bounds (2: every tile round does, 0: off), "tile_mu" (default 0.02): its guard band in hash-cell edges; "tile_cache" (0/1, default 1):
  * after that hand-over, rounds whose poses still move run the same build with the temporal-cache check as its prologue (lanes whose
  * neighbour provably did not change sit out; the wave searches for its missed lanes only) and the grid kernel only re-verifies the fixed point (2: the
- * prologue in EVERY tile round that follows a bounds-leaving one — an experiment, profiles/r06_tile_ab.txt); "tile_miss" (default 8; 0 = off): in those
+ * prologue in EVERY tile round that follows a bounds-leaving one — an experiment, profiles/r06_tile_ab.txt); "reject_cache" (0/1, default 1): in those rounds a query whose old neighbour
+ * AND every other target are provably beyond the cutoff after the pose update is a cache hit too (it stays rejected, frame.cpp:156; its exact neighbour is never
+ * output) — the lanes with the largest search balls leave the traversal; "cache_mfma_ratio" (default 3; 0 = never): a cache-aware round runs on the
+ * matrix-pipe build instead when the median displacement bound of the queries since the last search exceeds this many guard bands (low expected hit rate);
+ * "tile_miss" (default 8; 0 = off): in those
  * cache-aware rounds a wave left with at most this many missed lanes answers them one by one with its 64 lanes spread over the tile boxes / the points
  * (nn_tile.hip miss_block); "mfma_entry" (0/1, default 0): seeded matrix-pipe launches enter at the blocks their seeds lie in and prove completeness with one
  * flat sweep over the block boxes instead of the top-down walk (an experiment: faster only once the poses have settled); "prune_rho", "auto_settle", "auto_switch",

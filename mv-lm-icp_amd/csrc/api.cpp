@@ -798,6 +798,7 @@ static int correspond_once(mvicp_ctx* c, const double* poses, const unsigned cha
   // last search's — whichever kernel runs.  Such an edge keeps its epoch (mvicp_correspondence_epochs), and if every edge does, the export too.
   std::vector<char> unchanged(E, 0);
   const bool hist_ok = c->have_corr && (int)c->nn_cache_edge.size() == E && c->nn_cache_thresh == thresh && (int)c->qpos_valid.size() == E;
+  std::vector<double> eps_ratio;       // per active edge: displacement bound of its queries since the last search / guard band mu
   bool same_active_set = (int)c->nn_cache_edge.size() == E;   // the set of searched edges is last search's (a changed `fixed` mask changes it)
   double* hx = c->h_pin;
   for (int e = 0; e < E; ++e) {
@@ -823,6 +824,15 @@ static int correspond_once(mvicp_ctx* c, const double* poses, const unsigned cha
     double scale = 0.0;
     for (int k = 0; k < 12; ++k) { x[25 + k] = Mq[k] - pq[k]; scale = std::max(scale, std::fabs(Mq[k])); }
     const double rmax = c->frames[c->esrc[e]].max_norm;
+    if (c->active[e]) {
+      // how far this edge's queries can have moved since the last search, in units of the bounds-leaving builds' guard band: what decides the
+      // temporal-cache hit rate of a cache-aware round before it runs (a hit needs d_new < d_old + mu - eps)
+      double fro = 0.0;
+      for (int k = 0; k < 9; ++k) fro += x[25 + k] * x[25 + k];
+      const double eps_e = std::sqrt(fro) * rmax + std::sqrt(x[34] * x[34] + x[35] * x[35] + x[36] * x[36]);
+      const double mu_e = c->tile_mu * c->frames[c->edst[e]].grid.cell;
+      eps_ratio.push_back(mu_e > 0.0 ? eps_e / mu_e : 1e300);
+    }
     const bool cache_on = c->nn_cache_valid && c->nn_cache_enable && c->active[e] && (int)c->nn_cache_edge.size() == E && c->nn_cache_edge[e] &&
                           c->nn_cache_thresh == thresh;
     // allowance for the rounding of the fp64 query map itself (both evaluations): ~1e-16 (|M||p| + |v|), taken 1e4 times larger.
@@ -983,7 +993,19 @@ static int correspond_once(mvicp_ctx* c, const double* poses, const unsigned cha
   if (c->fault_inject > 0 && --c->fault_inject == 0) { set_error("injected launch failure (option fault_inject)"); return MVICP_ERR_HIP; }   // tests: a local failure before the exchange
   if (method == MVICP_NN_BRUTE) MV_CHECK(launch_nn_brute_edges(c));
   else if (method == MVICP_NN_GRID) MV_CHECK(launch_nn_grid_edges(c, bound));
-  else MV_CHECK(launch_nn_tile_edges(c, bound, tile_lb, tile_cached, c->list_reuse));
+  else {
+    // Cache-aware rounds: which build?  With most lanes finished by the cache, nn_tile_kernel (per-lane box tests, miss_block) wins; with hit rates
+    // below ~80 % the matrix-pipe build does (cfg4_partial rounds 5-13: -4 ... -10 %, profiles/r06_tile_ab.txt).  The hit rate is not known before
+    // the launch, but what decides it is: the median displacement bound of the queries in units of the guard band (eps / mu).
+    c->cached_on_mfma = false;
+    if (tile_cached && c->tile_mfma == 1 && c->cache_mfma_ratio > 0.0 && !eps_ratio.empty()) {
+      std::nth_element(eps_ratio.begin(), eps_ratio.begin() + eps_ratio.size() / 2, eps_ratio.end());
+      const double med = eps_ratio[eps_ratio.size() / 2];
+      if (c->profile) { ProfEntry& pe = c->prof["auto.eps_over_mu"]; pe.ms = med; pe.launches += 1; }   // (observable: the last cache-aware round's ratio)
+      c->cached_on_mfma = med > c->cache_mfma_ratio;
+    }
+    MV_CHECK(launch_nn_tile_edges(c, bound, tile_lb, tile_cached, c->list_reuse));
+  }
   c->tie_skip = false; c->far_skip = false;
   c->prev_grid_kernel = method == MVICP_NN_GRID;
   // only the grid kernel and the tile kernel's BND build leave the per-query lower bounds the temporal cache needs; the cutoff must
@@ -1340,6 +1362,8 @@ int mvicp_set_option(mvicp_ctx* c, const char* name, double value) try {
   if (std::strcmp(name, "mfma_trig") == 0) { c->mfma_trig = (int)value; return MVICP_OK; }
   if (std::strcmp(name, "tile_mfma") == 0) { c->tile_mfma = (int)value; return MVICP_OK; }
   if (std::strcmp(name, "tile_waves") == 0) { c->tile_waves = (int)value; return MVICP_OK; }
+  if (std::strcmp(name, "cache_mfma_ratio") == 0) { c->cache_mfma_ratio = value; return MVICP_OK; }
+  if (std::strcmp(name, "reject_cache") == 0) { c->reject_cache = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "tile_miss") == 0) { if (!(value >= 0.0 && value <= 64.0)) { set_error("tile_miss outside [0, 64]"); return MVICP_ERR_ARG; } c->tile_miss = (int)value; return MVICP_OK; }
   if (std::strcmp(name, "tile_cache") == 0) { c->tile_cache = (int)value; return MVICP_OK; }
   if (std::strcmp(name, "spin_wait") == 0) { c->spin_wait = value != 0.0; return MVICP_OK; }

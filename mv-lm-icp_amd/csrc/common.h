@@ -258,6 +258,11 @@ struct mvicp_ctx {
                                    // slowest of a registration — never runs); 2: every tile round leaves bounds (tests); 0: off
   int tile_cache = 1;              // AUTO, after the hand-over: rounds whose transforms still move run the tile kernel's bounds-leaving build WITH the
                                    // temporal-cache check as its prologue (missed lanes are searched wave-cooperatively) instead of the grid kernel
+  double cache_mfma_ratio = 3.0;   // cache-aware rounds run on the matrix-pipe build when the median displacement bound of the queries exceeds this many guard bands
+                                   // (eps / mu; 0 = never: always nn_tile_kernel).  Measured (profiles/r06_tile_ab.txt): eps / mu <= 2.2 <-> hit rates >= 0.86 (nn_tile_kernel +
+                                   // miss_block faster), eps / mu >= 3.4 <-> hit rates <= 0.77 (nn_mfma_kernel 6-12 % faster)
+  bool cached_on_mfma = false;     // this launch's decision (api.cpp -> launch_nn_tile_edges)
+  bool reject_cache = true;        // cache-aware rounds: "provably still rejected by the cutoff" counts as a temporal-cache hit (nn_tile.hip / nn_mfma.hip prologue)
   int tile_miss = 8;               // cache-aware rounds: waves with at most this many missed lanes use nn_tile.hip's miss_block (0 = off)
   double tile_mu = 0.02;           // BND guard band as a fraction of the target's hash-cell edge (same role as prune_rho in the grid kernel); round 3 sweep on cfg4
                                    // (hand-over round + the two cache-aware rounds after it): 0.02 -> 2.06 ms, 0.05 -> 2.11, 0.1 -> 2.23, 0.2 -> 2.45

@@ -527,7 +527,13 @@ __global__ __launch_bounds__(MT, WPE) void nn_mfma_kernel(const TileJob* __restr
       const double e2 = sxf[27] * p0 + sxf[30] * p1 + sxf[33] * p2 + sxf[36];
       const double eps = sqrt(e0 * e0 + e1 * e1 + e2 * e2) * (1.0 + 1e-9) + cslack;
       const double nlb = (double)job.out_lb[i] - eps;
-      if (eps == 0.0 || sqrt(seed_d) * (1.0 + 1e-12) < nlb) {   // (eps == 0: the same query bit for bit keeps last search's exact answer)
+      // ... or (round 6) the query is provably still REJECTED: its old neighbour is beyond the cutoff now (exact) and every other target was at least
+      // out_lb away, i.e. is at least nlb away now — if that is beyond the cutoff too, no target is inside it, which is all the reference's filter
+      // (frame.cpp:156) asks; the exact neighbour of a rejected query is never output.  out_d2 then holds the distance to the OLD neighbour (>= bound:
+      // the query stays rejected downstream), out_idx keeps it as a seed, the bound is carried on.  These are the lanes with the LARGEST balls (their
+      // thresholds reach the search radius): taking them out of the traversal is what makes a partial-overlap round cheap.
+      const bool still_rejected = eps != 0.0 && seed_d >= bound && nlb > sqrt(bound) * (1.0 + 1e-9);
+      if (eps == 0.0 || sqrt(seed_d) * (1.0 + 1e-12) < nlb || (job.reject_cache && still_rejected)) {   // (eps == 0: the same query bit for bit keeps last search's exact answer)
         if (eps != 0.0) {   // (eps == 0: bit-identical query transform, everything stored is already exact)
           job.out_d2[i] = seed_d;
           job.out_lb[i] = __double2float_rd(nlb);

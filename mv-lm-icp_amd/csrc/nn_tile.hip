@@ -400,7 +400,13 @@ __global__ __launch_bounds__(TT, WPE) void nn_tile_kernel(const TileJob* __restr
       const double e2 = sxf[27] * p0 + sxf[30] * p1 + sxf[33] * p2 + sxf[36];
       const double eps = sqrt(e0 * e0 + e1 * e1 + e2 * e2) * (1.0 + 1e-9) + cslack;
       const double nlb = (double)job.out_lb[i] - eps;
-      if (eps == 0.0 || sqrt(seed_d) * (1.0 + 1e-12) < nlb) {   // (eps == 0: the same query bit for bit keeps last search's exact answer)
+      // ... or (round 6) the query is provably still REJECTED: its old neighbour is beyond the cutoff now (exact) and every other target was at least
+      // out_lb away, i.e. is at least nlb away now — if that is beyond the cutoff too, no target is inside it, which is all the reference's filter
+      // (frame.cpp:156) asks; the exact neighbour of a rejected query is never output.  out_d2 then holds the distance to the OLD neighbour (>= bound:
+      // the query stays rejected downstream), out_idx keeps it as a seed, the bound is carried on.  These are the lanes with the LARGEST balls (their
+      // thresholds reach the search radius): taking them out of the traversal is what makes a partial-overlap round cheap.
+      const bool still_rejected = eps != 0.0 && seed_d >= bound && nlb > sqrt(bound) * (1.0 + 1e-9);
+      if (eps == 0.0 || sqrt(seed_d) * (1.0 + 1e-12) < nlb || (job.reject_cache && still_rejected)) {   // (eps == 0: the same query bit for bit keeps last search's exact answer)
         if (eps != 0.0) {   // (eps == 0: bit-identical query transform, everything stored is already exact)
           job.out_d2[i] = seed_d;
           job.out_lb[i] = __double2float_rd(nlb);
@@ -540,7 +546,7 @@ int launch_nn_tile_edges(mvicp_ctx* c, double d2_bound, bool with_bounds, bool w
   // the matrix-pipe build of the same search (nn_mfma.hip).  Cache-aware rounds (a few missed lanes per wave) stay here by default: with
   // most lanes finished by the cache the per-lane box tests prune nearly every tile, and the 7-wave occupancy of this build hides the
   // latency of the few that remain (cfg4 rounds 6 / 7: 0.57 / 0.38 ms here against 0.65 / 0.57 ms there)
-  if (c->tile_mfma >= 2 || (c->tile_mfma == 1 && !with_cache)) return launch_nn_mfma_edges(c, d2_bound, with_bounds, with_cache, with_list);
+  if (c->tile_mfma >= 2 || (c->tile_mfma == 1 && (!with_cache || c->cached_on_mfma))) return launch_nn_mfma_edges(c, d2_bound, with_bounds, with_cache, with_list);
   std::vector<TileJob> jobs;
   int max_n = 0;
   double nq = 0;

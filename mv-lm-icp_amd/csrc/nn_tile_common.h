@@ -50,6 +50,7 @@ struct TileJob {
   // allowance (xf[24] >= 0): a lane whose neighbour provably did not change sits the traversal out, like in nn_grid_kernel.  `list`
   // (list.dirty != null) = the edge's compacted list is maintained in place by this launch (nn_list.h).
   int cache;
+  int reject_cache; // cache-aware rounds: a query that is provably still rejected by the cutoff (old neighbour and every other target beyond it) is a hit too
   int miss_max;     // cache-aware rounds of nn_tile_kernel: a wave with at most this many missed lanes answers them one by one (miss_block); 0 = off
   ListRef list;
   float kacc; int trig;   // nn_mfma.hip tunables (ctx::mfma_kacc, mfma_trig)
@@ -161,7 +162,7 @@ inline int build_tile_jobs(mvicp_ctx* c, bool with_bounds, bool with_cache, bool
     j.inv = d.grid.inv;
     j.seed = (c->tile_seed && (int)c->nn_cache_edge.size() == c->E && c->nn_cache_edge[e]) ? 1 : 0;
     if (with_bounds) { j.out_lb = c->d_nn_lb + c->cap_off[e]; j.mu = (float)(c->tile_mu * d.grid.cell); }
-    if (with_bounds && with_cache) { j.cache = 1; j.miss_max = c->tile_miss; }
+    if (with_bounds && with_cache) { j.cache = 1; j.miss_max = c->tile_miss; j.reject_cache = c->reject_cache ? 1 : 0; }
     if (with_list) {
       j.list = ListRef{c->d_qpos + c->cap_off[e], c->d_second + c->cap_off[e], c->d_cd2 + c->cap_off[e], c->d_dirty + e, c->d_dirty_slots + c->dslot_off[e],
                        c->d_stream + c->cap_off[e], c->total_cap, d.grid.snor, (const PointRec*)d.grid.srec};

@@ -21,7 +21,7 @@ def script(seed, K, rounds=14):
         elif kind == "method":
             e["method"] = int(rng.choice([0, 0, 1, 2, 3]))          # AUTO, AUTO, BRUTE, GRID, TILE
         elif kind == "option":
-            e["name"] = str(rng.choice(["list_reuse", "nn_cache", "sel_bracket", "tile_cache", "tile_seed", "tile_miss", "mfma_entry"]))
+            e["name"] = str(rng.choice(["list_reuse", "nn_cache", "sel_bracket", "tile_cache", "tile_seed", "tile_miss", "mfma_entry", "reject_cache"]))
             e["value"] = float(rng.integers(0, 2)) * (8.0 if e["name"] == "tile_miss" else 1.0)
         e["param"] = int(rng.integers(0, 3)); e["plane"] = int(rng.integers(0, 2)); e["robust"] = bool(rng.integers(0, 2))
         ev.append(e)

@@ -831,6 +831,7 @@ def test_tile_kernel_lower_bounds_feed_the_temporal_cache(orc, mu):
     # round 6: the miss_block path of the cache-aware rounds (off / every wave), the early cache prologue, the seed-block entry of the seeded launches
     {"tile_miss": 0}, {"tile_miss": 64}, {"tile_miss": 64, "tile_mu": 0.5}, {"tile_miss": 2, "auto_settle": 5.0}, {"tile_bounds": 2, "tile_cache": 2}, {"tile_bounds": 2, "tile_cache": 2, "tile_mfma": 2, "tile_miss": 64},
     {"mfma_entry": 1}, {"mfma_entry": 1, "tile_bounds": 2}, {"mfma_entry": 1, "tile_seed": 0},
+    {"reject_cache": 0}, {"reject_cache": 0, "tile_mfma": 2}, {"tile_mfma": 2, "auto_settle": 5.0}, {"cache_mfma_ratio": 0}, {"cache_mfma_ratio": 0.01}, {"cache_mfma_ratio": 0.01, "auto_settle": 5.0},
 ])
 def test_tuning_options_never_change_results(opts):
     """Every speed knob (kernel variants, seeding, cell pruning, AUTO hand-over policy, caches) must leave the whole ICP
@@ -1309,7 +1310,7 @@ def test_correspond_regime_transitions_match_a_fresh_context(orc, seed):
         elif ev == "method":
             method = int(rng.choice([L.NN_AUTO, L.NN_AUTO, L.NN_BRUTE, L.NN_GRID, L.NN_TILE]))
         elif ev == "option":
-            name = str(rng.choice(["list_reuse", "nn_cache", "sel_bracket", "spec_eval", "tile_cache", "tile_seed", "tile_miss", "mfma_entry"]))
+            name = str(rng.choice(["list_reuse", "nn_cache", "sel_bracket", "spec_eval", "tile_cache", "tile_seed", "tile_miss", "mfma_entry", "reject_cache"]))
             A.set_option(name, float(rng.integers(0, 2)) * (8.0 if name == "tile_miss" else 1.0))
             if rng.random() < 0.5:
                 A.set_option("tile_mfma", float(rng.integers(0, 3)))
