@@ -662,7 +662,7 @@ def main():
                 out.update(legs)
                 out["speedup_vs_cpu_baseline"] = {"value": out["value"] / out["cpu_baseline"]["value"],
                                                   "vs_all_cores": out["value"] / [v for k, v in out["cpu_baseline"]["variants"].items() if "allcores" in k or "threadpool" in k][0]["value"],
-                                                  "note": "GPU whole-job rate / CPU path rate over the same timed rounds (1 thread -O2 sampled and scaled; all cores measured on all edges); a reported baseline, not a kernel-quality figure"}
+                                                  "note": "GPU whole-job rate / CPU path rate over the same timed rounds (1 thread -O2: one moving + one fixed-point round on all edges up to cfg4's size; all cores: every compared round on all edges); a reported baseline, not a kernel-quality figure"}
             except Exception as ex:  # the baseline is a reported extra, never the measurement
                 out["cpu_baseline"] = {"error": repr(ex)}
         detail = args.detail_file
