@@ -215,7 +215,9 @@ int mvicp_closedform_point_to_plane(const double* src, const double* dst, const 
  * single rank only, read at mvicp_set_graph): the reference-equivalent trees that decide ties are built when a search first reports a tie on a target
  * without one — that search is then repeated once — like the reference's own lazily built index (frame.cpp:188-193); 0 = built for every target at mvicp_set_graph; "sel_bracket" (0/1, default 1): one-pass median select around last round's median
  * once it has settled; "spec_eval" (0/1, default 1): mvicp_correspond queues the first linearization of the following
- * mvicp_optimize (same poses, previous solve's flags) behind its own kernels so the round waits once, not twice; "lin_share_p"
+ * mvicp_optimize (same poses, previous solve's flags) behind its own kernels so the round waits once, not twice; "spec2_eval" (0/1, default 1; single rank): when a
+ * search's poses are bit-identical to the last search's (a converged registration), the candidate evaluation of the last solve is queued as well — the fixed-point
+ * round's solve then needs no further device launch and no second wait (used only if the solve asks for exactly those poses); "lin_share_p"
  * (0/1, default 1): the linearization reads the source points of an all-accepted edge from the shared sorted cloud; "nn_cell"
  * (0/1, default 0): wave-cooperative cell-staging variant of the grid kernel; "tile_bounds" (default 1): the MVICP_NN_AUTO round
  * that hands over from the tile kernel to the grid kernel runs a build of the tile kernel that also leaves the temporal-cache

@@ -159,7 +159,7 @@ void free_graph(mvicp_ctx* c) {
   dev_free(c->d_chunk_first); dev_free(c->d_partials); dev_free(c->d_out);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   c->h_pin = nullptr; c->h_pin_doubles = 0; c->d_res_host = nullptr; c->d_blocks_host = nullptr; c->lin_out = nullptr;
-  c->census_pending = false; c->spec_ready = false; c->spec_arm = false; c->d_spec_host = nullptr; c->d_adev_host = nullptr; c->d_res_target = nullptr; c->d_a_check = nullptr;
+  c->census_pending = false; c->spec_ready = false; c->spec2_ready = false; c->spec_arm = false; c->d_spec_host = nullptr; c->d_adev_host = nullptr; c->d_res_target = nullptr; c->d_a_check = nullptr;
   dev_free(c->d_xblock_cnt); c->export_valid = false; c->export_in_flight = false; c->export_chunks = 0;
   for (hipEvent_t ev : c->export_events) (void)hipEventDestroy(ev);
   c->export_events.clear();
@@ -210,8 +210,11 @@ int ensure_pin(mvicp_ctx* c, size_t doubles) {
 }  // namespace
 
 // Per-edge relative transform for the LM kernels: A = R_d^T R_s, t = R_d^T (t_s - t_d).
+static void fill_rel_into(mvicp_ctx* c, const double* poses, double* h);
 void fill_rel(mvicp_ctx* c, const double* poses) {
-  double* h = c->h_pin + c->ctl_r2_off;  // region 2 of the control block: rel | a (a = SoftLOne scales, set by correspond)
+  fill_rel_into(c, poses, c->h_pin + c->ctl_r2_off);  // region 2 of the control block: rel | a (a = SoftLOne scales, set by correspond)
+}
+static void fill_rel_into(mvicp_ctx* c, const double* poses, double* h) {
   for (int e = 0; e < c->E; ++e) {
     const double* Ps = poses + 16 * (size_t)c->esrc[e];
     const double* Pd = poses + 16 * (size_t)c->edst[e];
@@ -368,7 +371,21 @@ int evaluate_blocks(mvicp_ctx* c, const double* poses, int plane, int robust, do
       if (c->profile) c->prof["spec.hit"].launches += 1;   // (observable for tests / bench: evaluations served by the queued launch)
       return MVICP_OK;
     }
+    c->spec2_ready = false;   // the solve did not start where the queued evaluations assumed: the second one is void as well
   }
+  if (c->spec2_ready) {
+    // the second queued evaluation (see common.h): valid only for exactly these poses and flags
+    c->spec2_ready = false;
+    if (plane == c->spec2_plane && robust == c->spec2_robust && c->spec2_poses.size() == 16 * (size_t)c->n_frames &&
+        std::memcmp(poses, c->spec2_poses.data(), sizeof(double) * c->spec2_poses.size()) == 0) {
+      std::memcpy(out, c->h_pin + c->pin_spec2_off, sizeof(double) * n);
+      if (c->profile) c->prof["spec2.hit"].launches += 1;
+      c->last_cand_poses.assign(poses, poses + 16 * (size_t)c->n_frames); c->last_cand_plane = plane; c->last_cand_robust = robust;
+      return MVICP_OK;
+    }
+  }
+  // (an evaluation beyond the solve's first: what the next solve's candidate evaluation will most likely be asked at, if the poses do not move)
+  c->last_cand_poses.assign(poses, poses + 16 * (size_t)c->n_frames); c->last_cand_plane = plane; c->last_cand_robust = robust;
   double* h = c->h_pin + c->pin_blocks_off;
   if (c->comm || c->ar_fn) {
     // One collective per evaluation: [E x 91 blocks | poison slot].  The slot right behind the blocks (the buffer's tail region, rewritten
@@ -541,7 +558,7 @@ int mvicp_recompute_normals(mvicp_ctx* c, int frame, int k, double* nrm_out, int
     if (e != hipSuccess) { set_error("recompute_normals: %s", hipGetErrorString(e)); st = MVICP_ERR_HIP; }
   }
   dev_free(d_knn);
-  c->spec_ready = false;
+  c->spec_ready = false; c->spec2_ready = false;
   if (st == MVICP_OK && c->E > 0) {
     // The packed operand stream bakes the dst normals in (n and c = n . q, gathered at correspond time) while the reference
     // reads dstCloud.nor when it builds the problem (icp-ceres.cpp:270-292): every list that points INTO this frame is stale.
@@ -706,7 +723,9 @@ int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) t
   c->pin_spec_off = c->pin_misc_off + 4 * (size_t)E + 64;          // blocks of the speculative first evaluation (+ the exchanged tail with N > 1 ranks)
   c->pin_adev_off = c->pin_spec_off + (size_t)E * (MVICP_EDGE_BLOCK + 3) + 2; // SoftLOne scales as the device computed them (single rank)
   if (c->h_pin) { MV_HIP(hipHostFree(c->h_pin)); c->h_pin = nullptr; c->h_pin_doubles = 0; }
-  MV_CHECK(ensure_pin(c, c->pin_adev_off + (size_t)E + 8));
+  c->pin_spec2_off = (c->pin_adev_off + (size_t)E + 8 + 1) & ~(size_t)1;                 // blocks of the second queued evaluation (16-B aligned)
+  c->pin_rel2_off = c->pin_spec2_off + (size_t)E * MVICP_EDGE_BLOCK + ((size_t)E * MVICP_EDGE_BLOCK & 1);   // its relative transforms (E x 12), copied into d_rel in stream order
+  MV_CHECK(ensure_pin(c, c->pin_rel2_off + (size_t)E * kEdgeRel + 8));
   {
     void* dp = nullptr;
     MV_HIP(hipHostGetDevicePointer(&dp, c->h_pin, 0));
@@ -714,8 +733,10 @@ int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) t
     c->d_res_host = (double*)dp + c->pin_res_off;
     c->d_spec_host = (double*)dp + c->pin_spec_off;
     c->d_adev_host = (double*)dp + c->pin_adev_off;
+    c->d_spec2_host = (double*)dp + c->pin_spec2_off;
   }
   c->spec_ready = false; c->spec_arm = false; c->bracket_counters_clean = false;
+  c->spec2_ready = false; c->spec2_armed = false; c->last_cand_poses.clear();
   c->prev_xf.assign((size_t)E * 24, 0.0);
   if (!c->h_census) MV_HIP(hipHostMalloc((void**)&c->h_census, 8 * sizeof(unsigned long long), hipHostMallocDefault));
   return MVICP_OK;
@@ -735,6 +756,7 @@ static void forget_history(mvicp_ctx* c) {
   for (int e = 0; e < E; ++e) c->corr_epoch[e] = ++c->epoch_counter;
   c->sel_med1.assign(E, -1.0); c->sel_med2.assign(E, -1.0);
   c->spec_ready = false; c->spec_arm = false; c->spec_flags_valid = false;
+  c->spec2_ready = false; c->spec2_armed = false; c->last_cand_poses.clear();
   c->have_corr = false;
   std::fill(c->h_count.begin(), c->h_count.end(), 0); std::fill(c->h_weight.begin(), c->h_weight.end(), 0.f);
 }
@@ -965,7 +987,7 @@ static int correspond_once(mvicp_ctx* c, const double* poses, const unsigned cha
   // used only if every rank armed — a rank that did not arm still takes part in the same collective with the same size.  (A rank that fails
   // LOCALLY before the exchange — a launch error — returns without it and its peers block in the collective: a failed launch is fatal for the job.)
   const bool exchange = c->comm != nullptr || c->ar_fn != nullptr;
-  c->spec_ready = false;
+  c->spec_ready = false; c->spec2_ready = false;
   c->spec_arm = c->spec_enable && c->spec_flags_valid;
   if (c->spec_arm && c->spec_plane)
     for (int e = 0; e < E; ++e) if (!(fixed && fixed[c->esrc[e]]) && c->frames[c->edst[e]].n > 0 && c->frames[c->edst[e]].grid.snor == nullptr) c->spec_arm = false;
@@ -1058,6 +1080,17 @@ static int correspond_once(mvicp_ctx* c, const double* poses, const unsigned cha
   } else if (c->spec_arm) {
     c->lin_out = c->d_spec_host;
     st_q = launch_linearize(c, c->spec_q_plane, c->spec_q_robust);
+    // second queued evaluation: this search's poses are last search's bit for bit, so the solve that follows will ask for last solve's candidate again
+    c->spec2_armed = false;
+    if (st_q == MVICP_OK && c->spec2_enable && all_same && same_active_set && c->have_corr && c->last_cand_poses.size() == 16 * (size_t)c->n_frames &&
+        c->last_cand_plane == c->spec_q_plane && c->last_cand_robust == c->spec_q_robust) {
+      fill_rel_into(c, c->last_cand_poses.data(), c->h_pin + c->pin_rel2_off);
+      if (hipMemcpyAsync(c->d_rel, c->h_pin + c->pin_rel2_off, sizeof(double) * (size_t)E * kEdgeRel, hipMemcpyHostToDevice, c->stream) == hipSuccess) {
+        c->lin_out = c->d_spec2_host;
+        st_q = launch_linearize(c, c->spec_q_plane, c->spec_q_robust);
+        if (st_q == MVICP_OK) { c->spec2_armed = true; c->spec2_poses = c->last_cand_poses; c->spec2_plane = c->spec_q_plane; c->spec2_robust = c->spec_q_robust; }
+      }
+    }
   }
   mark("host.corr.post_launch");
   // (count, median d2) per edge arrive in mapped host memory, written by select_final_kernel (single rank), or summed over ranks
@@ -1134,6 +1167,8 @@ static int correspond_once(mvicp_ctx* c, const double* poses, const unsigned cha
       }
   }
   c->spec_ready = c->spec_arm && !spec_bad;
+  c->spec2_ready = c->spec_ready && c->spec2_armed;   // (same scales, same lists: valid whenever the first one is)
+  c->spec2_armed = false;
   c->spec_arm = false;
   double* ha = c->h_pin + c->ctl_r2_off + (size_t)E * kEdgeRel;   // `a` slice of region 2: uploaded with rel by the next evaluation
   for (int e = 0; e < E; ++e) {
@@ -1270,7 +1305,7 @@ int mvicp_set_correspondences(mvicp_ctx* c, int edge, int n, const int* first, c
     MV_HIP(hipMemset(c->d_cd2 + off, 0, sizeof(double) * n));
   }
   c->nn_cache_valid = false;
-  c->spec_ready = false;
+  c->spec_ready = false; c->spec2_ready = false;
   c->list_valid[edge] = 0; c->explicit_list[edge] = 1; c->export_valid = false;
   c->qpos_valid[edge] = 0; c->corr_epoch[edge] = ++c->epoch_counter;
   c->sel_med1[edge] = c->sel_med2[edge] = -1.0;
@@ -1370,7 +1405,8 @@ int mvicp_set_option(mvicp_ctx* c, const char* name, double value) try {
   if (std::strcmp(name, "fault_inject") == 0) { c->fault_inject = (int)value; return MVICP_OK; }            // tests: the value-th mvicp_correspond from now fails locally before its exchange
   if (std::strcmp(name, "fault_inject_build") == 0) { c->fault_inject_build.store((int)value); return MVICP_OK; }      // tests: the value-th structure build from now fails
   if (std::strcmp(name, "fault_inject_eval") == 0) { c->fault_inject_eval = (int)value; return MVICP_OK; }  // tests: the value-th exchanged LM evaluation from now fails locally
-  if (std::strcmp(name, "spec_eval") == 0) { c->spec_enable = value != 0.0; c->spec_ready = false; return MVICP_OK; }
+  if (std::strcmp(name, "spec_eval") == 0) { c->spec_enable = value != 0.0; c->spec_ready = false; c->spec2_ready = false; return MVICP_OK; }
+  if (std::strcmp(name, "spec2_eval") == 0) { c->spec2_enable = value != 0.0; c->spec2_ready = false; return MVICP_OK; }
   if (std::strcmp(name, "grid_target") == 0) {
     if (!(value >= 0.5 && value <= 64.0)) { set_error("grid_target out of range"); return MVICP_ERR_ARG; }
     c->grid_target = value;

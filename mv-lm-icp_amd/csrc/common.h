@@ -204,6 +204,16 @@ struct mvicp_ctx {
   bool spec_ready = false;          // blocks of spec_poses are in the pinned spec region
   std::vector<double> spec_poses;   // n_frames x 16: poses the speculative evaluation was made at (after the parameterization round trip)
   size_t pin_spec_off = 0, pin_adev_off = 0; double* d_spec_host = nullptr; double* d_adev_host = nullptr;
+  // Second queued evaluation (round 6, single rank).  At the fixed point of a registration every round's solve is: first evaluation (queued, above) -> one LM
+  // iteration -> candidate evaluation -> function-tolerance stop, and the candidate poses are last round's bit for bit (same inputs).  When this search's poses
+  // are bit-identical to the last search's, the candidate evaluation of the LAST solve is queued right behind the first one (relative transforms from a second
+  // pinned slice, copied into d_rel in stream order between the two), so the round waits ONCE for both.  Used only if the solve really asks for exactly those
+  // poses; nothing is skipped — the work is queued earlier.
+  bool spec2_enable = true, spec2_armed = false, spec2_ready = false; int spec2_plane = 0, spec2_robust = 0;
+  std::vector<double> spec2_poses;       // poses the second queued evaluation was made at
+  std::vector<double> last_cand_poses;   // poses of the last evaluation a solve asked for beyond its first (the prediction for the next solve's candidate)
+  int last_cand_plane = -1, last_cand_robust = -1;
+  size_t pin_spec2_off = 0, pin_rel2_off = 0; double* d_spec2_host = nullptr;
   double* d_a_check = nullptr;      // where this search's select kernels copy the SoftLOne scales they derive: mapped host memory (single rank) or d_out's tail
   bool spin_wait = false;           // poll the stream instead of a blocking wait (measured: no gain, HIP's own wait already spins)
   unsigned long long* h_census = nullptr;   // pinned: 8 counters of the last NN launch, resolved after the round's own sync

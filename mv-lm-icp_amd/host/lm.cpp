@@ -316,7 +316,7 @@ int mvicp_optimize(mvicp_ctx* c, double* poses, unsigned char* fixed, int param,
   c->spec_flags_valid = true; c->spec_param = param; c->spec_plane = point_to_plane ? 1 : 0; c->spec_robust = robust ? 1 : 0;
   CtxEval u{c, point_to_plane ? 1 : 0, robust ? 1 : 0};
   const int st = lm_solve(c->n_frames, c->E, c->esrc.data(), c->edst.data(), poses, fixed, param, max_iterations, ctx_eval, &u, summary);
-  if (st != MVICP_OK) { c->spec_flags_valid = false; c->spec_ready = false; }   // a failed solve must not arm the next search's queued evaluation
+  if (st != MVICP_OK) { c->spec_flags_valid = false; c->spec_ready = false; c->spec2_ready = false; c->last_cand_poses.clear(); }   // a failed solve must not arm the next search's queued evaluation
   if (st == MVICP_OK && summary) {   // feeds the AUTO kernel choice of the next search (api.cpp): RMS residual the solve ended on
     double n = 0.0;
     for (int e = 0; e < c->E; ++e) n += c->h_count[e];

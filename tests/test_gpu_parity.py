@@ -831,7 +831,7 @@ def test_tile_kernel_lower_bounds_feed_the_temporal_cache(orc, mu):
     # round 6: the miss_block path of the cache-aware rounds (off / every wave), the early cache prologue, the seed-block entry of the seeded launches
     {"tile_miss": 0}, {"tile_miss": 64}, {"tile_miss": 64, "tile_mu": 0.5}, {"tile_miss": 2, "auto_settle": 5.0}, {"tile_bounds": 2, "tile_cache": 2}, {"tile_bounds": 2, "tile_cache": 2, "tile_mfma": 2, "tile_miss": 64},
     {"mfma_entry": 1}, {"mfma_entry": 1, "tile_bounds": 2}, {"mfma_entry": 1, "tile_seed": 0},
-    {"reject_cache": 0}, {"reject_cache": 0, "tile_mfma": 2}, {"tile_mfma": 2, "auto_settle": 5.0}, {"cache_mfma_ratio": 0}, {"cache_mfma_ratio": 0.01}, {"cache_mfma_ratio": 0.01, "auto_settle": 5.0},
+    {"spec2_eval": 0}, {"reject_cache": 0}, {"reject_cache": 0, "tile_mfma": 2}, {"tile_mfma": 2, "auto_settle": 5.0}, {"cache_mfma_ratio": 0}, {"cache_mfma_ratio": 0.01}, {"cache_mfma_ratio": 0.01, "auto_settle": 5.0},
 ])
 def test_tuning_options_never_change_results(opts):
     """Every speed knob (kernel variants, seeding, cell pruning, AUTO hand-over policy, caches) must leave the whole ICP
@@ -1017,6 +1017,46 @@ def test_speculative_first_evaluation_is_used_and_exact():
     assert np.array_equal(res[1][0], res[0][0])
     assert res[0][1] == [0] * 6
     assert res[1][1] == [0, 1, 1, 0, 0, 1], res[1][1]   # round 0: no flags yet; round 3: flags differ; round 4: flags differ from round 3's
+
+
+def test_second_queued_evaluation_at_the_fixed_point_is_used_and_exact():
+    """Round 6 (spec2_eval): once a registration has converged, a round's poses are last round's bit for bit and its solve is `first evaluation -> one LM iteration ->
+    candidate evaluation -> function-tolerance stop`, with last round's candidate poses.  mvicp_correspond then queues BOTH evaluations behind its own kernels, so the
+    round waits once instead of twice.  From the second fixed-point round on every solve's two evaluations are served by the queued launches; a round whose poses moved
+    gets none; a change of flags voids both; the whole trajectory (poses, counts, weights, LM summaries) is bit-identical to spec2_eval = 0."""
+    pb = synth.make_problem(4, 4000)
+    res = {}
+    for spec2 in (1, 0):
+        e = mvicp.Engine(0)
+        e.set_option("spec2_eval", spec2)
+        e.set_frames(pb["pts"], pb["nor"]); e.set_graph(pb["src"], pb["dst"])
+        e.profile(True)
+        poses = pb["init"].copy()
+        log = []
+        for r in range(16):
+            e.profile_reset()
+            before = poses.copy()
+            c, w = e.correspond(poses, pb["fixed"], 0.05)
+            param, plane = (L.PARAM_ANGLE_AXIS, 0) if r == 14 else (L.PARAM_SOPHUS_SE3, 1)   # round 14 changes the flags at the fixed point
+            poses, sm = e.optimize(poses, pb["fixed"], param, plane, True, 50)
+            log.append((c.copy(), w.tobytes(), poses.copy(), sm["iterations"], sm["evaluations"], sm["termination"], e.profile_get("spec.hit")[1], e.profile_get("spec2.hit")[1],
+                        bool(np.array_equal(before, poses))))
+        res[spec2] = log
+        e.close()
+    for a, b in zip(res[1], res[0]):
+        assert np.array_equal(a[0], b[0]) and a[1] == b[1] and np.array_equal(a[2], b[2]) and a[3:6] == b[3:6]
+    assert all(l[7] == 0 for l in res[0])
+    still = [l[8] for l in res[1]]                       # rounds whose solve left the poses untouched
+    assert sum(still) >= 6 and not still[0], still
+    h2 = [l[7] for l in res[1]]
+    for r in range(2, 14):
+        # two consecutive untouched rounds before r: the search of round r saw last search's poses, and last solve ended on a candidate evaluation
+        if still[r - 2] and still[r - 1] and still[r]:
+            assert h2[r] == 1 and res[1][r][4] == 2, (r, h2, still)      # both evaluations of the solve were queued ones
+        if not still[r - 1]:
+            assert h2[r] == 0, (r, h2, still)                            # the poses moved since the last search: nothing queued
+    assert sum(h2[:14]) >= 4, (h2, still)
+    assert h2[14] == 0 and res[1][14][6] == 0                            # flags changed: both queued evaluations are ignored
 
 
 def test_changed_fixed_mask_at_identical_poses_is_not_mistaken_for_a_fixed_point():
