@@ -1304,6 +1304,32 @@ def test_rejected_queries_become_cache_hits_without_changing_any_list(orc):
     assert all(hits[1][r] >= hits[0][r] for r in range(8)) and any(hits[1][r] > hits[0][r] for r in moving), hits   # (small problem, fast convergence: the gain is a fraction of a per cent here, 20 points on cfg4_partial)
 
 
+def test_async_map_and_per_edge_wait(eng, orc):
+    """mvicp_map_correspondences_async + mvicp_wait_correspondences (round 6): the export travels in chunks (one per source frame); after wait(e) the bytes of edge e
+    are the oracle's list, whatever order the edges are waited for in; a wait without an export and an edge out of range are errors, not garbage."""
+    pb = synth.make_problem(5, 5000)
+    eng.set_frames(pb["pts"], pb["nor"]); eng.set_graph(pb["src"], pb["dst"])
+    eng.reset_history()
+    with pytest.raises(mvicp.MvicpError):
+        eng.wait_correspondences(0)                       # nothing searched, nothing exported
+    poses = pb["init"].copy()
+    for rnd in range(3):
+        counts, weights = eng.correspond(poses, pb["fixed"], 0.05)
+        trip, off = eng.map_correspondences_async()       # views of the pinned buffer: defined edge by edge
+        assert np.array_equal(np.diff(off), counts)
+        for e in list(range(eng.E))[::-1] if rnd % 2 else range(eng.E):
+            eng.wait_correspondences(e)
+            s_, d_ = pb["src"][e], pb["dst"][e]
+            f, sec, dist, w, _, _ = orc.correspond_edge(pb["pts"][s_], poses[s_], pb["pts"][d_], poses[d_], 0.05)
+            t = trip[off[e]:off[e + 1]]
+            assert np.array_equal(t["first"], f) and np.array_equal(t["second"], sec) and t["dist"].tobytes() == dist.tobytes(), (rnd, e)
+        with pytest.raises(mvicp.MvicpError):
+            eng.wait_correspondences(eng.E)
+        t2, off2 = eng.map_correspondences()              # the blocking form afterwards: the same buffer
+        assert np.array_equal(off2, off) and np.array_equal(t2, trip)
+        poses, _ = eng.optimize(poses, pb["fixed"], L.PARAM_SOPHUS_SE3, 1, True, 50)
+
+
 def test_map_correspondences_skips_explicit_and_fixed_edges(eng, orc):
     """Edges whose source is fixed are never searched (frame.cpp:93) and an edge that holds an explicit list (mvicp_set_correspondences: any
     order, repeats) has no per-query positions: both have zero width in the map; mvicp_get_correspondences still returns the explicit list
