@@ -212,6 +212,43 @@ def test_cfg4_full_size_vs_nanoflann(orc, refnn, cfg4):
     eng.close()
 
 
+def test_cfg4_partial_full_size_vs_nanoflann(orc, refnn):
+    """The partial-overlap variant of config 4 (bench.py `cfg4_partial`: 32 x 200 000 points, 20-degree views, 5 mm cutoff: a quarter of the queries rejected) at full
+    size through 18 rounds of its registration — the workload round 6's cache changes act on: rounds 1-4 plain seeded launches, 5-13 cache-aware rounds on the
+    matrix-pipe build (eps / mu > 3) with "provably still rejected" hits, 14-17 cache-aware rounds on nn_tile_kernel with miss_block, then the verify pass.  Every
+    second round six sampled edges against the REAL nanoflann: counts, float weights, (first, second, dist) triples bit for bit; the rejected fraction and the
+    regimes are asserted so that the test keeps covering what it is meant to cover."""
+    assert refnn is not None
+    cutoff = 0.005
+    pb = synth.make_problem(32, 200_000, cone_deg=20.0, sigma=0.004, sigmat=0.002)
+    eng = mvicp.Engine(0)
+    eng.set_frames(pb["pts"], pb["nor"]); eng.set_graph(pb["src"], pb["dst"])
+    eng.profile(True); eng.set_option("nn_census", 1)
+    E = len(pb["src"])
+    sample = sorted(set(np.linspace(0, E - 1, 6).astype(int).tolist()))
+    poses = pb["init"].copy()
+    hits, on_mfma = [], []
+    for rnd in range(18):
+        eng.profile_reset()
+        counts, weights = eng.correspond(poses, pb["fixed"], cutoff)
+        cs = eng.nn_census()
+        hits.append(cs["hits"] / max(cs["queries"], 1.0))
+        on_mfma.append(eng.profile_get("nn_mfma")[1] > 0)
+        if rnd % 2 == 0 or rnd >= 15:
+            want = [orc.filter_median(*refnn.query(pb["pts"][pb["dst"][e]], orc.query_transform(poses[pb["src"][e]], poses[pb["dst"][e]], pb["pts"][pb["src"][e]])), cutoff) for e in sample]
+            for e, w in zip(sample, want):
+                assert_edge_equal(eng, e, counts, weights, w, f"cfg4_partial round {rnd}")
+        if rnd == 0:
+            tot = sum(len(pb["pts"][s]) for s in pb["src"])
+            assert 0.6 * tot < counts.sum() < 0.9 * tot, (counts.sum(), tot)          # the cutoff really rejects a good part of the queries
+        poses, sm = eng.optimize(poses, pb["fixed"], L.PARAM_SOPHUS_SE3, 1, True, 50)
+    eng.close()
+    cached = [r for r in range(18) if 0.0 < hits[r] < 0.9999]
+    assert len(cached) >= 8, hits                                                      # many cache-aware rounds with the poses still moving
+    assert any(on_mfma[r] for r in cached) and any(not on_mfma[r] for r in cached), (hits, on_mfma)   # both builds ran cache-aware rounds (eps / mu rule)
+    assert hits[cached[0]] > 0.15, hits                                                # the first cache-aware round already has the rejection hits (4 % without them)
+
+
 @pytest.mark.parametrize("curve", [2, 1])
 def test_cfg4_moving_rounds_cache_and_list_reuse_are_bit_identical(cfg4, curve):
     """Full-size twin of test_temporal_cache_is_bit_identical_to_full_search: two engines on config 4, one with the temporal NN
