@@ -86,7 +86,7 @@ def test_compact_line_fits_the_driver_tail_and_round_trips():
     must = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
             "roofline", "cpu_baseline", "source_sha16", "detail_file"}
     seen = 0
-    for name in ("r05_cfg4_w5s20_bench_line.json", "r05_cfg4_bench_line.json", "r04_cfg4_w5s20_bench_line.json", "r05_cfg5_bench_line.json", "r05_shard8_bench_line.json"):
+    for name in ("r06_cfg4_w5s20_bench_line.json", "r06_cfg5_bench_line.json", "r06_cfg4_partial_bench_line.json", "r05_cfg4_w5s20_bench_line.json", "r05_cfg4_bench_line.json", "r04_cfg4_w5s20_bench_line.json", "r05_cfg5_bench_line.json", "r05_shard8_bench_line.json"):
         p = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(p):
             continue
