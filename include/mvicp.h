@@ -218,7 +218,9 @@ int mvicp_closedform_point_to_plane(const double* src, const double* dst, const 
  * mvicp_optimize (same poses, previous solve's flags) behind its own kernels so the round waits once, not twice; "spec2_eval" (0/1, default 1; single rank): when a
  * search's poses are bit-identical to the last search's (a converged registration), the candidate evaluation of the last solve is queued as well — the fixed-point
  * round's solve then needs no further device launch and no second wait (used only if the solve asks for exactly those poses); "lin_share_p"
- * (0/1, default 1): the linearization reads the source points of an all-accepted edge from the shared sorted cloud; "nn_cell"
+ * (0/1, default 1): the linearization reads the source points of an all-accepted edge from the shared sorted cloud; "lin_interleave" (0/1, default 1; read at
+ * mvicp_set_graph): the linearization's workgroups of the edges that share a source cloud are launched interleaved in groups of 8, so that the second reader of a
+ * piece of the cloud runs on the XCD whose L2 still holds it; "nn_cell"
  * (0/1, default 0): wave-cooperative cell-staging variant of the grid kernel; "tile_bounds" (default 1): the MVICP_NN_AUTO round
  * that hands over from the tile kernel to the grid kernel runs a build of the tile kernel that also leaves the temporal-cache
  * bounds (2: every tile round does, 0: off), "tile_mu" (default 0.02): its guard band in hash-cell edges; "tile_cache" (0/1, default 1):

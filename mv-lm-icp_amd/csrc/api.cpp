@@ -647,6 +647,25 @@ int mvicp_set_graph(mvicp_ctx* c, int n_edges, const int* src, const int* dst) t
   c->total_cap = c->cap_off[E];
   c->n_cblocks = c->cblock_off[E];
   c->n_chunks = c->chunk_first[E];
+  if (c->lin_interleave) {
+    // Launch order of the linearize workgroups (option "lin_interleave"): the edges of one source cloud read the same p (identity lists, lin_share_p).  Their
+    // chunks are interleaved in groups of 8 — A0..A7, B0..B7, A8..A15, ... — so that chunk k of the second edge runs on the XCD (workgroup b runs on XCD b % 8)
+    // that chunk k of the first edge ran on a moment ago: its piece of p is still in that XCD's L2.  Slots of the partials are per edge (linearize.hip).
+    std::vector<int> ce, cs;
+    for (int e0 = 0; e0 < E;) {
+      int e1 = e0 + 1;
+      while (e1 < E && src[e1] == src[e0]) ++e1;
+      int maxc = 0;
+      for (int e = e0; e < e1; ++e) maxc = std::max(maxc, c->chunk_first[e + 1] - c->chunk_first[e]);
+      for (int g = 0; g < maxc; g += 8)
+        for (int e = e0; e < e1; ++e) {
+          const int nch = c->chunk_first[e + 1] - c->chunk_first[e];
+          for (int k = g; k < std::min(g + 8, nch); ++k) { ce.push_back(e); cs.push_back(k * kLinChunk); }
+        }
+      e0 = e1;
+    }
+    chunk_edge.swap(ce); chunk_start.swap(cs);
+  }
   const size_t cap = (size_t)c->total_cap;
   MV_CHECK(dev_alloc(&c->d_esrc, E)); MV_CHECK(dev_alloc(&c->d_edst, E)); MV_CHECK(dev_alloc(&c->d_cap_off, E + 1));
   MV_CHECK(dev_alloc(&c->d_count, E));
@@ -1376,6 +1395,7 @@ int mvicp_set_option(mvicp_ctx* c, const char* name, double value) try {
   if (std::strcmp(name, "nn_cache") == 0) { c->nn_cache_enable = value != 0.0; c->nn_cache_valid = false; return MVICP_OK; }
   if (std::strcmp(name, "lin_chunk") == 0) { c->lin_chunk_override = (int)value; return MVICP_OK; }  // takes effect at the next mvicp_set_graph
   if (std::strcmp(name, "list_reuse") == 0) { c->list_reuse = value != 0.0; return MVICP_OK; }
+  if (std::strcmp(name, "lin_interleave") == 0) { c->lin_interleave = value != 0.0; return MVICP_OK; }   // takes effect at the next mvicp_set_graph
   if (std::strcmp(name, "lin_share_p") == 0) { c->lin_share_p = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "nn_census") == 0) { c->nn_census = value != 0.0; return MVICP_OK; }
   if (std::strcmp(name, "nn_skip_far") == 0) { c->nn_skip_far = value != 0.0; return MVICP_OK; }

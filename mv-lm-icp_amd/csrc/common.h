@@ -179,6 +179,7 @@ struct mvicp_ctx {
   bool bracket_counters_clean = false;   // the bracket pass's two per-edge counters are zero on the device (left so by bracket_final_kernel)
   double* d_sel_keys1 = nullptr; double* d_sel_keys2 = nullptr;                  // compact key buffers of passes B and C (total_cap each)
   // linearize chunks
+  bool lin_interleave = true;       // launch order of the linearize workgroups: chunks of the edges that share a source cloud interleaved in groups of 8 (api.cpp mvicp_set_graph)
   bool lin_share_p = true;          // linearize reads p from the sorted source cloud when an edge's list is the identity (option "lin_share_p")
   int lin_chunk_override = 0;
   int lin_chunk = 4096;             // correspondences per linearize workgroup (chosen from the GLOBAL problem size)

@@ -109,10 +109,14 @@ __global__ __launch_bounds__(NT) void linearize_kernel(const int* __restrict__ c
                                                        const int* __restrict__ count, const long long* __restrict__ cap_off, long long total_cap,
                                                        const double* __restrict__ rel, const double* __restrict__ a_scale,
                                                        const double* __restrict__ stream, double* __restrict__ partials,
-                                                       const double* const* __restrict__ src_pts, const int* __restrict__ nsrc) {
-  const int c = blockIdx.x;
-  const int e = chunk_edge[c];
-  const int start = chunk_start[c];
+                                                       const double* const* __restrict__ src_pts, const int* __restrict__ nsrc,
+                                                       const int* __restrict__ chunk_first) {
+  const int e = chunk_edge[blockIdx.x];
+  const int start = chunk_start[blockIdx.x];
+  // the partial's slot is the chunk's place in ITS EDGE's run (chunk_first[e] + k), whatever the launch order of the workgroups (api.cpp interleaves the chunks
+  // of the edges that share a source cloud, so that the second reader of a piece of p finds it in the same XCD's L2); reduce_expand_kernel sums an edge's slots
+  // in order, so the result does not depend on that order
+  const int c = chunk_first[e] + start / chunk;
   const int cnt = count[e];
   if (start >= cnt) return;
   const int end = min(cnt, start + chunk);
@@ -342,8 +346,19 @@ int launch_linearize(mvicp_ctx* c, int plane, int robust) {
   if (c->E == 0) return MVICP_OK;
   const int chunk = c->lin_chunk;
   if (c->n_chunks > 0) {
+    // algorithmic bytes of the launch: 32 B (plane: n, n.q) / 24 B (point: q) per correspondence + the source point p, 24 B — per correspondence when the edge
+    // reads its private copy from the stream, ONCE PER SOURCE POINT for the edges of one source cloud that read the shared sorted cloud side by side (identity
+    // lists, lin_share_p + lin_interleave: the second edge's read is an L2 hit by construction; PMC: 0.695 -> 0.551 GB per launch at cfg4)
     double bytes = 0;
-    for (int e = 0; e < c->E; ++e) if (c->owned[e]) bytes += (plane ? 56.0 : 48.0) * c->h_count[e];
+    std::vector<char> src_counted((size_t)c->n_frames, 0);
+    for (int e = 0; e < c->E; ++e) {
+      if (!c->owned[e]) continue;
+      const double cnt = c->h_count[e];
+      const int s = c->esrc[e];
+      bytes += (plane ? 32.0 : 24.0) * cnt;
+      if (c->lin_share_p && c->lin_interleave && c->h_count[e] == c->frames[s].n) { if (!src_counted[s]) { bytes += 24.0 * cnt; src_counted[s] = 1; } }
+      else bytes += 24.0 * cnt;
+    }
     // per-edge sorted source clouds (identity-list fast path of the kernel); table cached by content
     const double* const* d_src = nullptr;
     if (c->lin_share_p) {
@@ -354,7 +369,7 @@ int launch_linearize(mvicp_ctx* c, int plane, int robust) {
     ProfScope ps(c, "linearize", bytes);
 #define LAUNCH(P, R)                                                                                                                           \
   hipLaunchKernelGGL((linearize_kernel<P, R>), dim3(c->n_chunks), dim3(NT), 0, c->stream, c->d_chunk_edge, c->d_chunk_start, chunk, c->d_count, \
-                     c->d_cap_off, c->total_cap, c->d_rel, c->d_a, c->d_stream, c->d_partials, d_src, (const int*)c->d_nsrc)
+                     c->d_cap_off, c->total_cap, c->d_rel, c->d_a, c->d_stream, c->d_partials, d_src, (const int*)c->d_nsrc, (const int*)c->d_chunk_first)
     if (plane && robust) LAUNCH(true, true);
     else if (plane) LAUNCH(true, false);
     else if (robust) LAUNCH(false, true);

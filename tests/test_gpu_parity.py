@@ -831,7 +831,7 @@ def test_tile_kernel_lower_bounds_feed_the_temporal_cache(orc, mu):
     # round 6: the miss_block path of the cache-aware rounds (off / every wave), the early cache prologue, the seed-block entry of the seeded launches
     {"tile_miss": 0}, {"tile_miss": 64}, {"tile_miss": 64, "tile_mu": 0.5}, {"tile_miss": 2, "auto_settle": 5.0}, {"tile_bounds": 2, "tile_cache": 2}, {"tile_bounds": 2, "tile_cache": 2, "tile_mfma": 2, "tile_miss": 64},
     {"mfma_entry": 1}, {"mfma_entry": 1, "tile_bounds": 2}, {"mfma_entry": 1, "tile_seed": 0},
-    {"spec2_eval": 0}, {"reject_cache": 0}, {"reject_cache": 0, "tile_mfma": 2}, {"tile_mfma": 2, "auto_settle": 5.0}, {"cache_mfma_ratio": 0}, {"cache_mfma_ratio": 0.01}, {"cache_mfma_ratio": 0.01, "auto_settle": 5.0},
+    {"spec2_eval": 0}, {"lin_interleave": 0}, {"lin_interleave": 0, "lin_share_p": 0}, {"reject_cache": 0}, {"reject_cache": 0, "tile_mfma": 2}, {"tile_mfma": 2, "auto_settle": 5.0}, {"cache_mfma_ratio": 0}, {"cache_mfma_ratio": 0.01}, {"cache_mfma_ratio": 0.01, "auto_settle": 5.0},
 ])
 def test_tuning_options_never_change_results(opts):
     """Every speed knob (kernel variants, seeding, cell pruning, AUTO hand-over policy, caches) must leave the whole ICP
